@@ -1,0 +1,54 @@
+"""ctypes binding of libdifferender_hip.so (C ABI: include/differender_hip.h).
+
+There is deliberately NO fallback: if the HIP library is missing or a call fails, this raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdifferender_hip.so")
+
+DR_F32, DR_F16 = 0, 1
+DR_MODE_DIFF, DR_MODE_NONDIFF = 0, 1
+DR_VARIANT_AUTO, DR_VARIANT_BASELINE = 0, 1
+
+_c = ctypes
+_P, _I, _L, _F, _D, _U = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_double, _c.c_uint32
+
+# name -> (restype, argtypes); must list every symbol the header declares (tests/test_abi.py checks)
+SIGNATURES = {
+    "dr_abi_version": (_I, []),
+    "dr_error_string": (_c.c_char_p, [_I]),
+    "dr_ray_setup": (_I, [_P, _I, _I, _I, _I, _I, _I, _D, _D, _F, _U, _U, _P, _P, _P, _P, _P]),
+    "dr_march_fwd": (_I, [_P, _I, _I, _I, _I, _L, _L, _L, _L, _P, _I, _L, _P, _P, _P, _P, _P,
+                          _I, _I, _I, _I, _F, _I, _I, _P, _P, _P]),
+    "dr_march_bwd": (_I, [_P, _I, _I, _I, _I, _L, _L, _L, _L, _P, _I, _L, _P, _P, _P, _P, _P,
+                          _I, _I, _I, _I, _F, _I, _P, _P, _P, _L, _L, _L, _L, _P, _L, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library (once). Raises ImportError with a build hint if it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C differender_amd/csrc`). differender_amd has no CPU or PyTorch fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        if handle.dr_abi_version() != 1:
+            raise ImportError("libdifferender_hip.so ABI version mismatch; rebuild it")
+        _lib = handle
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().dr_error_string(code)
+        raise RuntimeError(f"{what} failed: {msg.decode() if msg else code} (code {code})")

@@ -1,0 +1,90 @@
+// capi.hip -- extern "C" boundary of libdifferender_hip.so (declared in include/differender_hip.h).
+// Argument validation + dispatch only; kernels live in the other translation units.
+#include <hip/hip_runtime.h>
+
+#include "../../include/differender_hip.h"
+#include "dr_kernels.h"
+
+using namespace dr;
+
+extern "C" {
+
+int dr_abi_version(void) { return DR_ABI_VERSION; }
+
+const char *dr_error_string(int code) {
+    switch (code) {
+        case 0: return "success";
+        case DR_EINVAL: return "differender_hip: invalid argument";
+        case DR_EUNSUPPORTED: return "differender_hip: unsupported configuration";
+        default: break;
+    }
+    if (code > 0) return hipGetErrorString((hipError_t)code);
+    return "differender_hip: unknown error";
+}
+
+int dr_ray_setup(const float *cam, int n_views, int W, int H, int VX, int VY, int VZ, double fov_rad,
+                 double near_plane, float sampling_rate, uint32_t jitter_seed, uint32_t view_base, float *entry,
+                 float *exit_, float *rays, int32_t *nsamp, void *stream) {
+    if (!cam || !entry || !exit_ || !rays || !nsamp) return DR_EINVAL;
+    if (n_views <= 0 || W <= 0 || H <= 0 || VX < 2 || VY < 2 || VZ < 2) return DR_EINVAL;
+    if (n_views > 65535 || !(sampling_rate > 0.0f)) return DR_EINVAL;
+    return (int)launch_ray_setup(cam, n_views, W, H, VX, VY, VZ, fov_rad, near_plane, sampling_rate, jitter_seed,
+                                 view_base, entry, exit_, rays, nsamp, (hipStream_t)stream);
+}
+
+static int fill_common(MarchArgs &a, const void *vol, int vol_dtype, int VX, int VY, int VZ, int64_t sx, int64_t sy,
+                       int64_t sz, int64_t vol_view_stride, const float *tf, int R, int64_t tf_view_stride,
+                       const float *cam, const float *entry, const float *exit_, const float *rays,
+                       const int32_t *nsamp, int n_views, int W, int H, int max_samples, float sampling_rate) {
+    if (!vol || !tf || !cam || !entry || !exit_ || !rays || !nsamp) return DR_EINVAL;
+    if (vol_dtype != DR_F32 && vol_dtype != DR_F16) return DR_EINVAL;
+    if (n_views <= 0 || n_views > 65535 || W <= 0 || H <= 0 || VX < 2 || VY < 2 || VZ < 2 || R < 1) return DR_EINVAL;
+    if (max_samples < 0 || !(sampling_rate > 0.0f)) return DR_EINVAL;
+    if (tf_view_stride % 4 != 0) return DR_EINVAL;
+    a = MarchArgs{};
+    a.vol = vol; a.vol_dtype = vol_dtype; a.VX = VX; a.VY = VY; a.VZ = VZ;
+    a.sx = sx; a.sy = sy; a.sz = sz; a.vol_vs = vol_view_stride;
+    a.tf = tf; a.R = R; a.tf_vs = tf_view_stride;
+    a.cam = cam; a.entry = entry; a.exit_ = exit_; a.rays = rays; a.nsamp = nsamp;
+    a.n_views = n_views; a.W = W; a.H = H; a.S = max_samples; a.sr = sampling_rate;
+    return 0;
+}
+
+int dr_march_fwd(const void *vol, int vol_dtype, int VX, int VY, int VZ, int64_t sx, int64_t sy, int64_t sz,
+                 int64_t vol_view_stride, const float *tf, int R, int64_t tf_view_stride, const float *cam,
+                 const float *entry, const float *exit_, const float *rays, const int32_t *nsamp, int n_views, int W,
+                 int H, int max_samples, float sampling_rate, int mode, int variant, float *out_rgba, int32_t *steps,
+                 void *stream) {
+    MarchArgs a;
+    int rc = fill_common(a, vol, vol_dtype, VX, VY, VZ, sx, sy, sz, vol_view_stride, tf, R, tf_view_stride, cam,
+                         entry, exit_, rays, nsamp, n_views, W, H, max_samples, sampling_rate);
+    if (rc) return rc;
+    if (!out_rgba) return DR_EINVAL;
+    if (mode != DR_MODE_DIFF && mode != DR_MODE_NONDIFF) return DR_EINVAL;
+    if (variant != DR_VARIANT_AUTO && variant != DR_VARIANT_BASELINE) return DR_EINVAL;
+    a.mode = mode; a.out = out_rgba; a.steps = steps;
+    return launch_march_fwd_baseline(a, (hipStream_t)stream);
+}
+
+int dr_march_bwd(const void *vol, int vol_dtype, int VX, int VY, int VZ, int64_t sx, int64_t sy, int64_t sz,
+                 int64_t vol_view_stride, const float *tf, int R, int64_t tf_view_stride, const float *cam,
+                 const float *entry, const float *exit_, const float *rays, const int32_t *nsamp, int n_views, int W,
+                 int H, int max_samples, float sampling_rate, int variant, const float *grad_out,
+                 const float *out_rgba, float *d_vol, int64_t dsx, int64_t dsy, int64_t dsz,
+                 int64_t dvol_view_stride, float *d_tf, int64_t dtf_view_stride, void *stream) {
+    MarchArgs a;
+    int rc = fill_common(a, vol, vol_dtype, VX, VY, VZ, sx, sy, sz, vol_view_stride, tf, R, tf_view_stride, cam,
+                         entry, exit_, rays, nsamp, n_views, W, H, max_samples, sampling_rate);
+    if (rc) return rc;
+    if (!grad_out || !out_rgba) return DR_EINVAL;
+    if (variant != DR_VARIANT_AUTO && variant != DR_VARIANT_BASELINE) return DR_EINVAL;
+    if (dtf_view_stride % 4 != 0) return DR_EINVAL;
+    if (!d_vol && !d_tf) return 0;  // nothing requested
+    a.mode = DR_MODE_DIFF;
+    a.grad_out = grad_out; a.out_fwd = out_rgba;
+    a.d_vol = d_vol; a.dsx = dsx; a.dsy = dsy; a.dsz = dsz; a.dvol_vs = dvol_view_stride;
+    a.d_tf = d_tf; a.dtf_vs = dtf_view_stride;
+    return launch_march_bwd_baseline(a, (hipStream_t)stream);
+}
+
+}  // extern "C"

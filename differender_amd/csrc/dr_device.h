@@ -1,0 +1,184 @@
+// dr_device.h -- device-side building blocks shared by the gfx950 march kernels.
+// Semantics follow differender/volume_raycaster.py ("VR.py") of the reference; citations inline.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+namespace dr {
+
+struct f3 { float x, y, z; };
+__device__ __forceinline__ f3 make_f3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+// taichi Vector.normalized(): invlen = 1/(norm + 0); invlen * v
+__device__ __forceinline__ f3 normalized3(f3 a) {
+    float inv = 1.0f / (sqrtf(dot3(a, a)) + 0.0f);
+    return make_f3(inv * a.x, inv * a.y, inv * a.z);
+}
+// taichi_glsl mix
+__device__ __forceinline__ float mixf(float x, float y, float a) { return x * (1.0f - a) + y * a; }
+
+// jitter RNG (replaces ti.random, VR.py:255): counter-based integer hash of (seed, view, pixel)
+__device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float jitter_u(uint32_t seed, uint32_t view, uint32_t pix) {
+    uint32_t h = hash_u32(seed ^ 0x9E3779B9U);
+    h = hash_u32(h ^ (view * 0x85EBCA6BU + 0xC2B2AE35U));
+    h = hash_u32(h ^ pix);
+    return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+
+// VR.py:7-21 low_high_frac
+__device__ __forceinline__ void low_high_frac(float x, int &lo, float &fr) {
+    x = fmaxf(x, 0.0f);
+    float low = floorf(x);
+    fr = x - low;
+    lo = (int)low;
+}
+
+__device__ __forceinline__ float ld_voxel(const float *p) { return *p; }
+__device__ __forceinline__ float ld_voxel(const __half *p) { return __half2float(*p); }
+
+// Volume view in the reference's field index space (VR.py:481), element strides.
+template <typename VT>
+struct VolView {
+    const VT *p;
+    int64_t sx, sy, sz;
+    int VX, VY, VZ;
+    float scx, scy, scz;  // shape - 1 - 1e-4, rounded from double (VR.py:165)
+};
+
+struct Cell {
+    int x0, x1, y0, y1, z0, z1;
+    float fx, fy, fz;
+};
+
+// VR.py:163-172: clamp to [0,1], scale, split, clamp the high index
+template <typename VT>
+__device__ __forceinline__ void tri_cell(const VolView<VT> &v, float px, float py, float pz, Cell &c) {
+    float qx = fminf(1.0f, fmaxf(0.0f, 0.5f * px + 0.5f)) * v.scx;
+    float qy = fminf(1.0f, fmaxf(0.0f, 0.5f * py + 0.5f)) * v.scy;
+    float qz = fminf(1.0f, fmaxf(0.0f, 0.5f * pz + 0.5f)) * v.scz;
+    low_high_frac(qx, c.x0, c.fx);
+    low_high_frac(qy, c.y0, c.fy);
+    low_high_frac(qz, c.z0, c.fz);
+    c.x0 = min(c.x0, v.VX - 1); c.y0 = min(c.y0, v.VY - 1); c.z0 = min(c.z0, v.VZ - 1);
+    c.x1 = min(c.x0 + 1, v.VX - 1); c.y1 = min(c.y0 + 1, v.VY - 1); c.z1 = min(c.z0 + 1, v.VZ - 1);
+}
+
+// VR.py:173-189: 8 gathers, lerp order x -> y -> z
+template <typename VT>
+__device__ __forceinline__ float tri_sample(const VolView<VT> &v, float px, float py, float pz) {
+    Cell c;
+    tri_cell(v, px, py, pz, c);
+    const VT *b00 = v.p + c.x0 * v.sx + c.y0 * v.sy, *b10 = v.p + c.x1 * v.sx + c.y0 * v.sy;
+    const VT *b01 = v.p + c.x0 * v.sx + c.y1 * v.sy, *b11 = v.p + c.x1 * v.sx + c.y1 * v.sy;
+    int64_t o0 = c.z0 * v.sz, o1 = c.z1 * v.sz;
+    float a = mixf(ld_voxel(b00 + o0), ld_voxel(b10 + o0), c.fx);
+    float b = mixf(ld_voxel(b01 + o0), ld_voxel(b11 + o0), c.fx);
+    float zl = mixf(a, b, c.fy);
+    a = mixf(ld_voxel(b00 + o1), ld_voxel(b10 + o1), c.fx);
+    b = mixf(ld_voxel(b01 + o1), ld_voxel(b11 + o1), c.fx);
+    float zh = mixf(a, b, c.fy);
+    return mixf(zl, zh, c.fz);
+}
+
+// adjoint of tri_sample w.r.t. the volume (global float atomics; baseline path)
+struct GradView {
+    float *p;
+    int64_t sx, sy, sz;
+};
+template <typename VT>
+__device__ __forceinline__ void tri_scatter_global(const VolView<VT> &v, const GradView &g, float px, float py,
+                                                   float pz, float adj) {
+    Cell c;
+    tri_cell(v, px, py, pz, c);
+    float gx = 1.0f - c.fx, gy = 1.0f - c.fy, gz = 1.0f - c.fz;
+    float *b00 = g.p + c.x0 * g.sx + c.y0 * g.sy, *b10 = g.p + c.x1 * g.sx + c.y0 * g.sy;
+    float *b01 = g.p + c.x0 * g.sx + c.y1 * g.sy, *b11 = g.p + c.x1 * g.sx + c.y1 * g.sy;
+    int64_t o0 = c.z0 * g.sz, o1 = c.z1 * g.sz;
+    unsafeAtomicAdd(b00 + o0, gx * gy * gz * adj);
+    unsafeAtomicAdd(b10 + o0, c.fx * gy * gz * adj);
+    unsafeAtomicAdd(b01 + o0, gx * c.fy * gz * adj);
+    unsafeAtomicAdd(b11 + o0, c.fx * c.fy * gz * adj);
+    unsafeAtomicAdd(b00 + o1, gx * gy * c.fz * adj);
+    unsafeAtomicAdd(b10 + o1, c.fx * gy * c.fz * adj);
+    unsafeAtomicAdd(b01 + o1, gx * c.fy * c.fz * adj);
+    unsafeAtomicAdd(b11 + o1, c.fx * c.fy * c.fz * adj);
+}
+
+// Per-sample quantities of VR.py:270-299
+struct Sample {
+    float px, py, pz;
+    float I, xtf, fr;
+    int lo, hi;
+    float r, g, b, a, op;
+    f3 grad, nrm, ld, rf;
+    float gnorm, m, ndl, q, rdv, spec, Lraw, L;
+    bool flat;
+};
+
+struct RayGeom {
+    float entry, exit_, vx, vy, vz;
+    int n;
+    float t0;      // entry + 0.5*len/n (VR.py:273-275)
+    float inv_nm1; // unused by the baseline (kept exact: division per sample)
+};
+
+// VR.py:277-280: pos = cam + mix(t0, exit, s/(n-1)) * vd
+__device__ __forceinline__ void sample_pos(const RayGeom &rg, float cx, float cy, float cz, int s, float &px, float &py,
+                                           float &pz) {
+    float f = (float)s / (float)(rg.n - 1);
+    float t = mixf(rg.t0, rg.exit_, f);
+    px = cx + t * rg.vx; py = cy + t * rg.vy; pz = cz + t * rg.vz;
+}
+
+// VR.py:205-219 + 284-285. tf is a [R][4] table (LDS or global).
+template <typename VT>
+__device__ __forceinline__ void classify(const VolView<VT> &v, const float4 *tf, int R, float tf_len, float inv_sr,
+                                         Sample &sm) {
+    sm.I = tri_sample(v, sm.px, sm.py, sm.pz);
+    sm.xtf = sm.I * tf_len;
+    low_high_frac(sm.xtf, sm.lo, sm.fr);
+    sm.lo = min(sm.lo, R - 1);  // defined-domain guard for I > 1 (reference reads out of bounds)
+    sm.hi = min(sm.lo + 1, R - 1);
+    float4 t0 = tf[sm.lo], t1 = tf[sm.hi];
+    sm.r = mixf(t0.x, t1.x, sm.fr); sm.g = mixf(t0.y, t1.y, sm.fr);
+    sm.b = mixf(t0.z, t1.z, sm.fr); sm.a = mixf(t0.w, t1.w, sm.fr);
+    float base = 1.0f - sm.a;
+    sm.op = 1.0f - ((inv_sr == 1.0f) ? base : powf(base, inv_sr));
+}
+
+// VR.py:191-203 normal, :287-299 Phong. clampL: the differentiable path clamps lighting (VR.py:298).
+template <typename VT>
+__device__ __forceinline__ void shade(const VolView<VT> &v, f3 light_pos, f3 vd, bool clampL, Sample &sm) {
+    const float delta = 1e-3f;
+    float dx = tri_sample(v, sm.px + delta, sm.py, sm.pz) - tri_sample(v, sm.px - delta, sm.py, sm.pz);
+    float dy = tri_sample(v, sm.px, sm.py + delta, sm.pz) - tri_sample(v, sm.px, sm.py - delta, sm.pz);
+    float dz = tri_sample(v, sm.px, sm.py, sm.pz + delta) - tri_sample(v, sm.px, sm.py, sm.pz - delta);
+    sm.grad = make_f3(dx, dy, dz);
+    sm.gnorm = sqrtf(dot3(sm.grad, sm.grad));
+    sm.flat = !(sm.gnorm > 0.0f);
+    sm.ld = normalized3(make_f3(sm.px - light_pos.x, sm.py - light_pos.y, sm.pz - light_pos.z));
+    if (sm.flat) {
+        // 0/0 normal in the reference; NaN-suppressing max() gives ndl = rdv = 0
+        sm.nrm = make_f3(0.f, 0.f, 0.f);
+        sm.m = 0.f; sm.ndl = 0.f; sm.rf = sm.ld; sm.q = 0.f; sm.rdv = 0.f;
+    } else {
+        float inv = 1.0f / (sm.gnorm + 0.0f);
+        sm.nrm = make_f3(inv * dx, inv * dy, inv * dz);
+        sm.m = dot3(sm.nrm, sm.ld);
+        sm.ndl = fmaxf(sm.m, 0.0f);
+        float two_m = 2.0f * sm.m;
+        sm.rf = make_f3(sm.ld.x - two_m * sm.nrm.x, sm.ld.y - two_m * sm.nrm.y, sm.ld.z - two_m * sm.nrm.z);
+        sm.q = dot3(sm.rf, make_f3(-vd.x, -vd.y, -vd.z));
+        sm.rdv = fmaxf(sm.q, 0.0f);
+    }
+    sm.spec = 0.3f * powf(sm.rdv, 32.0f);
+    sm.Lraw = 0.8f * sm.ndl + sm.spec + 0.4f;
+    sm.L = clampL ? fminf(1.0f, sm.Lraw) : sm.Lraw;
+}
+
+}  // namespace dr

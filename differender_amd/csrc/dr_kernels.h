@@ -1,0 +1,29 @@
+// dr_kernels.h -- host-side launch entry points of the kernel translation units (internal).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dr {
+
+// Everything a march launch needs; filled by capi.cpp from the C-ABI arguments.
+struct MarchArgs {
+    const void *vol; int vol_dtype; int VX, VY, VZ; int64_t sx, sy, sz, vol_vs;
+    const float *tf; int R; int64_t tf_vs;
+    const float *cam, *entry, *exit_, *rays; const int32_t *nsamp;
+    int n_views, W, H, S; float sr; int mode;
+    float *out; int32_t *steps;
+    // backward only
+    const float *grad_out; const float *out_fwd;
+    float *d_vol; int64_t dsx, dsy, dsz, dvol_vs;
+    float *d_tf; int64_t dtf_vs;
+};
+
+hipError_t launch_ray_setup(const float *cam, int n_views, int W, int H, int VX, int VY, int VZ, double fov_rad,
+                            double near_plane, float sr, uint32_t jitter_seed, uint32_t view_base, float *entry,
+                            float *exit_, float *rays, int32_t *nsamp, hipStream_t stream);
+
+// Plain one-lane-per-ray kernels (DR_VARIANT_BASELINE): direct global gathers, global float atomics.
+int launch_march_fwd_baseline(const MarchArgs &a, hipStream_t stream);
+int launch_march_bwd_baseline(const MarchArgs &a, hipStream_t stream);
+
+}  // namespace dr

@@ -1,0 +1,246 @@
+// march_baseline.hip -- DR_VARIANT_BASELINE march kernels for gfx950: one lane per ray, a wave per
+// 8x8 pixel tile, direct global gathers, TF table in LDS, global float atomics for d_vol.
+// Kept as the simplest correct device implementation; the optimised kernels are tested against it
+// and against the CPU oracle.
+//
+// Forward   : VR.py:261-306 (raycast) + 363-372 (get_final_image); nondiff: VR.py:308-361.
+// Backward  : tape-free equivalent of raycast.grad/get_final_image.grad (VR.py:460-461,470-471).
+//   With T_s = 1 - A_{s-1}, q_s = gC.(L_s rgb_s) + gA and P_s = sum_{k<=s} T_k op_k q_k the adjoint of
+//   the sample opacity is  d/d op_s = T_s q_s - (Total - P_s) / (1 - op_s),  Total = gC.C_final + gA.A_final,
+//   which needs only a forward-order walk and the saved forward output (no per-sample tape).
+#include "dr_device.h"
+#include "dr_kernels.h"
+#include "../../include/differender_hip.h"
+
+namespace dr {
+
+template <typename VT>
+struct MarchParams {
+    VolView<VT> vol; int64_t vol_vs;
+    const float4 *tf; int64_t tf_vs; int R; float tf_len;
+    const float *cam, *entry, *exit_, *rays; const int32_t *nsamp;
+    int W, H, S; float sr, inv_sr;
+    float *out; int32_t *steps;
+    const float *grad_out, *out_fwd;
+    GradView dvol; int64_t dvol_vs;
+    float *d_tf; int64_t dtf_vs;
+};
+
+__device__ __forceinline__ bool tile_pixel(int W, int H, int &i, int &j) {
+    const int tiles_j = (H + 7) >> 3;
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    i = (wave / tiles_j) * 8 + (lane >> 3);
+    j = (wave % tiles_j) * 8 + (lane & 7);
+    return i < W && j < H;
+}
+
+template <typename VT, int MODE>
+__global__ __launch_bounds__(256) void march_fwd_baseline_kernel(MarchParams<VT> P) {
+    extern __shared__ __attribute__((aligned(16))) float4 lds_tf[];
+    const int view = blockIdx.y;
+    const float4 *tfg = P.tf + view * P.tf_vs;
+    for (int k = threadIdx.x; k < P.R; k += 256) lds_tf[k] = tfg[k];
+    __syncthreads();
+
+    int i, j;
+    if (!tile_pixel(P.W, P.H, i, j)) return;
+    const size_t p = ((size_t)view * P.W + i) * P.H + j;
+    VolView<VT> vol = P.vol;
+    vol.p += view * P.vol_vs;
+    const float cx = P.cam[3 * view], cy = P.cam[3 * view + 1], cz = P.cam[3 * view + 2];
+    const f3 light = make_f3(cx + 0.0f, cy + 1.0f, cz + 0.0f);
+
+    RayGeom rg;
+    rg.n = P.nsamp[p]; rg.entry = P.entry[p]; rg.exit_ = P.exit_[p];
+    rg.vx = P.rays[3 * p]; rg.vy = P.rays[3 * p + 1]; rg.vz = P.rays[3 * p + 2];
+    rg.t0 = rg.entry + 0.5f * (rg.exit_ - rg.entry) / (float)rg.n;
+    const f3 vd = make_f3(rg.vx, rg.vy, rg.vz);
+    const int nmarch = (MODE == DR_MODE_DIFF && rg.n > P.S) ? P.S : rg.n;
+
+    float C0 = 0.f, C1 = 0.f, C2 = 0.f, A = 0.f;
+    int cnt = 0;
+    for (int s = 0; s < nmarch; ++s) {
+        if (!(A < 0.99f)) break;
+        Sample sm;
+        sample_pos(rg, cx, cy, cz, s, sm.px, sm.py, sm.pz);
+        classify(vol, lds_tf, P.R, P.tf_len, P.inv_sr, sm);
+        ++cnt;
+        if (MODE == DR_MODE_NONDIFF && !(sm.a > 1e-3f)) continue;
+        shade(vol, light, vd, MODE == DR_MODE_DIFF, sm);
+        const float T = 1.0f - A;
+        C0 = T * (sm.L * sm.r * sm.op) + C0;
+        C1 = T * (sm.L * sm.g * sm.op) + C1;
+        C2 = T * (sm.L * sm.b * sm.op) + C2;
+        A = T * sm.op + A;
+    }
+    if (MODE == DR_MODE_NONDIFF) {
+        C0 = fminf(1.0f, C0); C1 = fminf(1.0f, C1); C2 = fminf(1.0f, C2); A = fminf(1.0f, A);
+    }
+    reinterpret_cast<float4 *>(P.out)[p] = make_float4(C0, C1, C2, A);
+    if (P.steps) P.steps[p] = cnt;
+}
+
+template <typename VT>
+__global__ __launch_bounds__(256) void march_bwd_baseline_kernel(MarchParams<VT> P) {
+    extern __shared__ __attribute__((aligned(16))) float4 lds_tf[];  // [R] TF, then [R] dTF accumulators
+    const int view = blockIdx.y;
+    const float4 *tfg = P.tf + view * P.tf_vs;
+    float *lds_dtf = reinterpret_cast<float *>(lds_tf + P.R);
+    for (int k = threadIdx.x; k < P.R; k += 256) {
+        lds_tf[k] = tfg[k];
+        lds_tf[P.R + k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+
+    int i, j;
+    const bool active = tile_pixel(P.W, P.H, i, j);
+    if (active) {
+        const size_t p = ((size_t)view * P.W + i) * P.H + j;
+        VolView<VT> vol = P.vol;
+        vol.p += view * P.vol_vs;
+        GradView dv = P.dvol;
+        const bool want_vol = dv.p != nullptr;
+        const bool want_tf = P.d_tf != nullptr;
+        if (want_vol) dv.p += view * P.dvol_vs;
+        const float cx = P.cam[3 * view], cy = P.cam[3 * view + 1], cz = P.cam[3 * view + 2];
+        const f3 light = make_f3(cx + 0.0f, cy + 1.0f, cz + 0.0f);
+
+        RayGeom rg;
+        rg.n = P.nsamp[p]; rg.entry = P.entry[p]; rg.exit_ = P.exit_[p];
+        rg.vx = P.rays[3 * p]; rg.vy = P.rays[3 * p + 1]; rg.vz = P.rays[3 * p + 2];
+        rg.t0 = rg.entry + 0.5f * (rg.exit_ - rg.entry) / (float)rg.n;
+        const f3 vd = make_f3(rg.vx, rg.vy, rg.vz);
+        const int nmarch = rg.n > P.S ? P.S : rg.n;
+
+        const float4 go = reinterpret_cast<const float4 *>(P.grad_out)[p];
+        const float4 of = reinterpret_cast<const float4 *>(P.out_fwd)[p];
+        const float total = (go.x * of.x + go.y * of.y + go.z * of.z) + go.w * of.w;
+        const float delta = 1e-3f;
+
+        float A = 0.f, Pfx = 0.f;
+        for (int s = 0; s < nmarch; ++s) {
+            if (!(A < 0.99f)) break;
+            Sample sm;
+            sample_pos(rg, cx, cy, cz, s, sm.px, sm.py, sm.pz);
+            classify(vol, lds_tf, P.R, P.tf_len, P.inv_sr, sm);
+            shade(vol, light, vd, true, sm);
+            const float T = 1.0f - A;
+            const float A_next = T * sm.op + A;
+            const bool last = (s == nmarch - 1) || !(A_next < 0.99f);
+            const float rgbdot = go.x * sm.r + go.y * sm.g + go.z * sm.b;  // gC . rgb
+            const float qs = sm.L * rgbdot + go.w;
+            Pfx += T * sm.op * qs;
+            const float suffix = last ? 0.0f : (total - Pfx) / (1.0f - sm.op);
+            const float op_bar = T * qs - suffix;
+            const float Lop = sm.L * sm.op * T;
+            const float r_bar = Lop * go.x, g_bar = Lop * go.y, b_bar = Lop * go.z;
+            const float L_bar = sm.op * T * rgbdot;
+            const float Lraw_bar = (1.0f < sm.Lraw) ? 0.0f : L_bar;
+            const float base = 1.0f - sm.a;
+            const float a_bar = op_bar * ((P.inv_sr == 1.0f) ? 1.0f : P.inv_sr * powf(base, P.inv_sr - 1.0f));
+            A = A_next;
+
+            if (want_tf) {
+                const float w0 = 1.0f - sm.fr, w1 = sm.fr;
+                float *d0 = lds_dtf + 4 * sm.lo, *d1 = lds_dtf + 4 * sm.hi;
+                atomicAdd(d0 + 0, w0 * r_bar); atomicAdd(d0 + 1, w0 * g_bar);
+                atomicAdd(d0 + 2, w0 * b_bar); atomicAdd(d0 + 3, w0 * a_bar);
+                atomicAdd(d1 + 0, w1 * r_bar); atomicAdd(d1 + 1, w1 * g_bar);
+                atomicAdd(d1 + 2, w1 * b_bar); atomicAdd(d1 + 3, w1 * a_bar);
+            }
+            if (want_vol) {
+                const float4 t0 = lds_tf[sm.lo], t1 = lds_tf[sm.hi];
+                const float fr_bar =
+                    (t1.x - t0.x) * r_bar + (t1.y - t0.y) * g_bar + (t1.z - t0.z) * b_bar + (t1.w - t0.w) * a_bar;
+                const float I_bar = (0.0f < sm.xtf) ? fr_bar * P.tf_len : 0.0f;
+                tri_scatter_global(vol, dv, sm.px, sm.py, sm.pz, I_bar);
+                if (!sm.flat) {
+                    const float ndl_bar = 0.8f * Lraw_bar;
+                    const float rdv_bar = 0.3f * 32.0f * powf(sm.rdv, 31.0f) * Lraw_bar;
+                    const float q_bar = (0.0f < sm.q) ? rdv_bar : 0.0f;
+                    const f3 rf_bar = make_f3(-vd.x * q_bar, -vd.y * q_bar, -vd.z * q_bar);
+                    const float m_bar = ((0.0f < sm.m) ? ndl_bar : 0.0f) - 2.0f * dot3(sm.nrm, rf_bar);
+                    const float m2 = -2.0f * sm.m;
+                    const f3 n_bar = make_f3(m2 * rf_bar.x + m_bar * sm.ld.x, m2 * rf_bar.y + m_bar * sm.ld.y,
+                                             m2 * rf_bar.z + m_bar * sm.ld.z);
+                    const float nn = dot3(sm.nrm, n_bar);
+                    const float inv = 1.0f / sm.gnorm;
+                    const float gx = inv * (n_bar.x - sm.nrm.x * nn);
+                    const float gy = inv * (n_bar.y - sm.nrm.y * nn);
+                    const float gz = inv * (n_bar.z - sm.nrm.z * nn);
+                    tri_scatter_global(vol, dv, sm.px + delta, sm.py, sm.pz, gx);
+                    tri_scatter_global(vol, dv, sm.px - delta, sm.py, sm.pz, -gx);
+                    tri_scatter_global(vol, dv, sm.px, sm.py + delta, sm.pz, gy);
+                    tri_scatter_global(vol, dv, sm.px, sm.py - delta, sm.pz, -gy);
+                    tri_scatter_global(vol, dv, sm.px, sm.py, sm.pz + delta, gz);
+                    tri_scatter_global(vol, dv, sm.px, sm.py, sm.pz - delta, -gz);
+                }
+            }
+        }
+    }
+    if (P.d_tf) {
+        __syncthreads();
+        float *dtf = P.d_tf + view * P.dtf_vs * 4;
+        for (int k = threadIdx.x; k < 4 * P.R; k += 256) {
+            const float v = lds_dtf[k];
+            if (v != 0.0f) unsafeAtomicAdd(dtf + k, v);
+        }
+    }
+}
+
+template <typename VT>
+static MarchParams<VT> make_params(const MarchArgs &a) {
+    MarchParams<VT> P;
+    P.vol.p = static_cast<const VT *>(a.vol);
+    P.vol.sx = a.sx; P.vol.sy = a.sy; P.vol.sz = a.sz;
+    P.vol.VX = a.VX; P.vol.VY = a.VY; P.vol.VZ = a.VZ;
+    P.vol.scx = (float)((double)a.VX - 1.0 - 1e-4);
+    P.vol.scy = (float)((double)a.VY - 1.0 - 1e-4);
+    P.vol.scz = (float)((double)a.VZ - 1.0 - 1e-4);
+    P.vol_vs = a.vol_vs;
+    P.tf = reinterpret_cast<const float4 *>(a.tf); P.tf_vs = a.tf_vs / 4; P.R = a.R; P.tf_len = (float)(a.R - 1);
+    P.cam = a.cam; P.entry = a.entry; P.exit_ = a.exit_; P.rays = a.rays; P.nsamp = a.nsamp;
+    P.W = a.W; P.H = a.H; P.S = a.S; P.sr = a.sr; P.inv_sr = 1.0f / a.sr;
+    P.out = a.out; P.steps = a.steps;
+    P.grad_out = a.grad_out; P.out_fwd = a.out_fwd;
+    P.dvol.p = a.d_vol; P.dvol.sx = a.dsx; P.dvol.sy = a.dsy; P.dvol.sz = a.dsz; P.dvol_vs = a.dvol_vs;
+    P.d_tf = a.d_tf; P.dtf_vs = a.dtf_vs / 4;
+    return P;
+}
+
+static dim3 tile_grid(const MarchArgs &a) {
+    const int tiles = ((a.W + 7) / 8) * ((a.H + 7) / 8);
+    return dim3((tiles + 3) / 4, a.n_views);
+}
+
+template <typename VT>
+static int fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
+    const size_t lds = (size_t)a.R * sizeof(float4);
+    if (lds > 64 * 1024) return DR_EUNSUPPORTED;
+    MarchParams<VT> P = make_params<VT>(a);
+    if (a.mode == DR_MODE_DIFF)
+        hipLaunchKernelGGL((march_fwd_baseline_kernel<VT, DR_MODE_DIFF>), tile_grid(a), dim3(256), lds, stream, P);
+    else
+        hipLaunchKernelGGL((march_fwd_baseline_kernel<VT, DR_MODE_NONDIFF>), tile_grid(a), dim3(256), lds, stream, P);
+    return (int)hipGetLastError();
+}
+
+int launch_march_fwd_baseline(const MarchArgs &a, hipStream_t stream) {
+    return a.vol_dtype == DR_F16 ? fwd_dispatch<__half>(a, stream) : fwd_dispatch<float>(a, stream);
+}
+
+template <typename VT>
+static int bwd_dispatch(const MarchArgs &a, hipStream_t stream) {
+    const size_t lds = 2 * (size_t)a.R * sizeof(float4);
+    if (lds > 64 * 1024) return DR_EUNSUPPORTED;
+    MarchParams<VT> P = make_params<VT>(a);
+    hipLaunchKernelGGL((march_bwd_baseline_kernel<VT>), tile_grid(a), dim3(256), lds, stream, P);
+    return (int)hipGetLastError();
+}
+
+int launch_march_bwd_baseline(const MarchArgs &a, hipStream_t stream) {
+    return a.vol_dtype == DR_F16 ? bwd_dispatch<__half>(a, stream) : bwd_dispatch<float>(a, stream);
+}
+
+}  // namespace dr

@@ -1,0 +1,64 @@
+"""Multi-GPU helpers (one process per GPU, torch.distributed; backend "nccl" is RCCL on ROCm).
+
+The hot path shards by VIEW: every rank holds a full replica of the volume and the transfer function
+(512 MiB at 512^3 f32 -- small against 288 GB of HBM), renders its own views, and accumulates a local
+d_volume / d_tf over them. The only exchange step is one sum all-reduce of those two shared gradients
+(SURVEY section 8(e)); the forward path needs no collective at all. The reference has no counterpart.
+"""
+import torch
+
+__all__ = ["shard_views", "all_reduce_gradients"]
+
+
+def shard_views(n_views, rank=None, world_size=None):
+    """Indices of the views rank `rank` renders: v = rank (mod world_size), in ascending order."""
+    if rank is None or world_size is None:
+        import torch.distributed as dist
+        rank, world_size = dist.get_rank(), dist.get_world_size()
+    return list(range(rank, n_views, world_size))
+
+
+def all_reduce_gradients(grads, group=None, async_op=False):
+    """Sum-all-reduce the shared gradients in place (d_volume: one large message, so the ring is
+    bandwidth-bound on the xGMI links; d_tf: a few KiB, latency-bound). Large tensors go as they are --
+    they are already one contiguous bucket each; small ones are coalesced into a single message."""
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return []
+    handles = []
+    small = [g for g in grads if g is not None and g.numel() * g.element_size() < (1 << 20)]
+    large = [g for g in grads if g is not None and g.numel() * g.element_size() >= (1 << 20)]
+    for g in large:
+        t = g if g.is_contiguous() or _dense(g) else None
+        if t is None:
+            c = g.contiguous()
+            dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)
+            g.copy_(c)
+        else:
+            h = dist.all_reduce(_flat_view(t), op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+            if async_op:
+                handles.append(h)
+    if small:
+        flat = torch.cat([g.reshape(-1) for g in small])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        off = 0
+        for g in small:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+    return handles
+
+
+def _dense(t):
+    """True if t covers a contiguous block of memory exactly once (e.g. a permuted contiguous tensor)."""
+    sizes_strides = sorted(((st, sz) for sz, st in zip(t.shape, t.stride()) if sz > 1), key=lambda p: p[0])
+    expect = 1
+    for st, sz in sizes_strides:
+        if st != expect:
+            return False
+        expect *= sz
+    return True
+
+
+def _flat_view(t):
+    """1-D view over the storage block of a dense tensor (order is irrelevant for an elementwise sum)."""
+    return torch.as_strided(t, (t.numel(),), (1,))

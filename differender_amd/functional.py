@@ -1,0 +1,133 @@
+"""Tensor-level wrappers over the C ABI (include/differender_hip.h).
+
+Buffers are torch tensors on a ROCm device; the HIP library allocates nothing and runs on the
+current torch stream. Volume tensors live in the reference's field index space (VX, VY, VZ) =
+(W, D, H) of the user's (1, D, H, W) tensor (VR.py:481) and may have arbitrary strides, so the
+permuted view of VR.py:566,571 is consumed without a copy.
+"""
+import numpy as np
+import torch
+
+from . import _native as N
+
+__all__ = ["ray_setup", "march_fwd", "march_bwd", "new_jitter_seed"]
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_gpu(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"differender_amd: `{name}` must live on a ROCm GPU (got {t.device}); "
+                           "there is no CPU path")
+
+
+def _vol_args(vol, n_views):
+    """-> (ptr, dtype_tag, VX, VY, VZ, sx, sy, sz, view_stride)"""
+    if vol.dtype == torch.float32:
+        tag = N.DR_F32
+    elif vol.dtype == torch.float16:
+        tag = N.DR_F16
+    else:
+        raise TypeError(f"volume dtype must be float32 or float16, got {vol.dtype}")
+    if vol.ndim == 3:
+        vs, (VX, VY, VZ), (sx, sy, sz) = 0, vol.shape, vol.stride()
+    elif vol.ndim == 4:
+        if vol.shape[0] != n_views:
+            raise ValueError(f"batched volume has {vol.shape[0]} items, expected {n_views}")
+        vs, (VX, VY, VZ), (sx, sy, sz) = vol.stride(0), vol.shape[1:], vol.stride()[1:]
+    else:
+        raise ValueError("volume must be (VX,VY,VZ) or (views,VX,VY,VZ)")
+    return vol.data_ptr(), tag, VX, VY, VZ, sx, sy, sz, vs
+
+
+def _tf_args(tf, n_views):
+    if tf.dtype != torch.float32 or not tf.is_contiguous():
+        raise TypeError("tf must be a contiguous float32 tensor")
+    if tf.ndim == 2 and tf.shape[1] == 4:
+        return tf.data_ptr(), tf.shape[0], 0
+    if tf.ndim == 3 and tf.shape[2] == 4 and tf.shape[0] == n_views:
+        return tf.data_ptr(), tf.shape[1], tf.stride(0)
+    raise ValueError("tf must be (R,4) or (views,R,4)")
+
+
+def new_jitter_seed():
+    """Non-zero 32-bit seed drawn from torch's CPU generator (so torch.manual_seed controls jitter)."""
+    return int(torch.randint(1, 2 ** 31 - 1, (1,)).item())
+
+
+def ray_setup(cam, out_shape, vol_shape, sampling_rate, fov_deg=30.0, near=0.1, jitter_seed=0, view_base=0):
+    """compute_entry_exit (VR.py:221-259) for cam (views,3) -> entry, exit (views,W,H), rays (views,W,H,3),
+    n (views,W,H) int32."""
+    _require_gpu(cam, "look_from")
+    cam = cam.to(torch.float32).contiguous()
+    V = cam.shape[0]
+    W, H = int(out_shape[0]), int(out_shape[1])
+    dev = cam.device
+    entry = torch.empty((V, W, H), dtype=torch.float32, device=dev)
+    exit_ = torch.empty((V, W, H), dtype=torch.float32, device=dev)
+    rays = torch.empty((V, W, H, 3), dtype=torch.float32, device=dev)
+    n = torch.empty((V, W, H), dtype=torch.int32, device=dev)
+    VX, VY, VZ = (int(s) for s in vol_shape)
+    with torch.cuda.device(dev):
+        rc = N.lib().dr_ray_setup(cam.data_ptr(), V, W, H, VX, VY, VZ, float(np.radians(fov_deg)), float(near),
+                                  float(sampling_rate), int(jitter_seed) & 0xFFFFFFFF, int(view_base),
+                                  entry.data_ptr(), exit_.data_ptr(), rays.data_ptr(), n.data_ptr(), _stream())
+    N.check(rc, "dr_ray_setup")
+    return entry, exit_, rays, n
+
+
+def march_fwd(vol, tf, cam, entry, exit_, rays, n, max_samples, sampling_rate, mode=N.DR_MODE_DIFF,
+              variant=N.DR_VARIANT_AUTO, want_steps=True):
+    """raycast + get_final_image (VR.py:261-306,363-372) or the nondiff pair (VR.py:308-361).
+    Returns out (views,W,H,4) and steps (views,W,H) int32 (or None)."""
+    _require_gpu(vol, "volume")
+    V, W, H = n.shape
+    dev = vol.device
+    cam = cam.to(torch.float32).contiguous()
+    out = torch.empty((V, W, H, 4), dtype=torch.float32, device=dev)
+    steps = torch.empty((V, W, H), dtype=torch.int32, device=dev) if want_steps else None
+    vargs = _vol_args(vol, V)
+    targs = _tf_args(tf, V)
+    with torch.cuda.device(dev):
+        rc = N.lib().dr_march_fwd(*vargs, targs[0], targs[1], targs[2], cam.data_ptr(), entry.data_ptr(),
+                                  exit_.data_ptr(), rays.data_ptr(), n.data_ptr(), V, W, H, int(max_samples),
+                                  float(sampling_rate), int(mode), int(variant), out.data_ptr(),
+                                  steps.data_ptr() if want_steps else None, _stream())
+    N.check(rc, "dr_march_fwd")
+    return out, steps
+
+
+def march_bwd(vol, tf, cam, entry, exit_, rays, n, max_samples, sampling_rate, grad_out, out, want_vol=True,
+              want_tf=True, variant=N.DR_VARIANT_AUTO):
+    """Adjoint of the differentiable march w.r.t. vol and tf (replaces raycast.grad, VR.py:460-461,470-471).
+    Shared (un-batched) vol / tf receive one gradient accumulated over all views."""
+    _require_gpu(vol, "volume")
+    V, W, H = n.shape
+    cam = cam.to(torch.float32).contiguous()
+    grad_out = grad_out.to(torch.float32).contiguous()
+    out = out.contiguous()
+    vargs = _vol_args(vol, V)
+    targs = _tf_args(tf, V)
+    d_vol = d_tf = None
+    dv = (None, 0, 0, 0, 0)
+    if want_vol:
+        d_vol = torch.zeros_like(vol, dtype=torch.float32, memory_format=torch.preserve_format)
+        if vol.ndim == 3:
+            dv = (d_vol.data_ptr(), *d_vol.stride(), 0)
+        else:
+            dv = (d_vol.data_ptr(), *d_vol.stride()[1:], d_vol.stride(0))
+    dt = (None, 0)
+    if want_tf:
+        d_tf = torch.zeros_like(tf)
+        dt = (d_tf.data_ptr(), d_tf.stride(0) if tf.ndim == 3 else 0)
+    if not (want_vol or want_tf):
+        return None, None
+    with torch.cuda.device(vol.device):
+        rc = N.lib().dr_march_bwd(*vargs, targs[0], targs[1], targs[2], cam.data_ptr(), entry.data_ptr(),
+                                  exit_.data_ptr(), rays.data_ptr(), n.data_ptr(), V, W, H, int(max_samples),
+                                  float(sampling_rate), int(variant), grad_out.data_ptr(), out.data_ptr(),
+                                  *dv, *dt, _stream())
+    N.check(rc, "dr_march_bwd")
+    return d_vol, d_tf

@@ -1,0 +1,1 @@
+from .utils import get_tf, in_circles, get_rand_pos, tex_from_pts

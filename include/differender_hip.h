@@ -1,0 +1,100 @@
+/*
+ * differender_hip.h -- C ABI of the MI355X (gfx950) volume-raycaster hot path.
+ *
+ * The reference (nanovis/Differender) has no FFI: its device code is Taichi-JIT'd Python inside
+ * differender/volume_raycaster.py ("VR.py").  Each entry point below replaces one Taichi kernel (or
+ * kernel pair) that VR.py's RaycastFunction / Raycaster launch; the reference lines are cited per
+ * function.  INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - The library is stateless and re-entrant.  It allocates nothing; every buffer is owned by the
+ *    caller (PyTorch on the Python side).  All pointers are DEVICE pointers on the current device.
+ *  - Work is enqueued on `stream` (a hipStream_t passed as void*); no call synchronises.
+ *  - Return value: 0 on success, otherwise a hipError_t value (>0) or a DR_E* code (<0);
+ *    dr_error_string() renders both.
+ *  - Volume = the reference's field index space (i,j,k) of extent (VX,VY,VZ) (VR.py:481 calls it
+ *    (W,D,H) of the user's (1,D,H,W) tensor), addressed with ELEMENT strides (sx,sy,sz) so the
+ *    permuted view of VR.py:566,571 needs no copy.  vol_dtype: DR_F32 or DR_F16 (fp16 storage,
+ *    f32 arithmetic; an extension, the reference is f32-only).
+ *  - Image buffers are contiguous [view][W][H](C), exactly the (W,H,4) tensors VR.py:417,438 return.
+ *  - n_views > 1 runs that many independent views in one launch (replaces the Python loops of
+ *    VR.py:418-426,450-464).  *_view_stride are ELEMENT strides between views; 0 shares the buffer
+ *    between all views (a shared volume then receives ONE accumulated d_vol).
+ */
+#ifndef DIFFERENDER_HIP_H
+#define DIFFERENDER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DR_ABI_VERSION 1
+
+enum { DR_F32 = 0, DR_F16 = 1 };
+enum { DR_MODE_DIFF = 0, DR_MODE_NONDIFF = 1 };
+/* kernel variant selector: AUTO picks the fastest validated kernel for the problem; BASELINE forces
+ * the plain one-lane-per-ray kernels kept for differential testing. */
+enum { DR_VARIANT_AUTO = 0, DR_VARIANT_BASELINE = 1 };
+
+enum {
+    DR_EINVAL = -1,      /* bad argument (null pointer, non-positive extent, unknown enum) */
+    DR_EUNSUPPORTED = -2 /* valid request this build cannot serve (e.g. TF too large for LDS) */
+};
+
+int dr_abi_version(void);
+const char *dr_error_string(int code);
+
+/* Ray generation + box clipping + sample count + jitter.
+ * Replaces VolumeRaycaster.compute_entry_exit (VR.py:221-259) incl. get_ray_direction (VR.py:127-151)
+ * and get_entry_exit_points (VR.py:28-53).
+ *   cam     [n_views][3] camera positions (look_from); the camera looks at the origin (VR.py:233)
+ *   fov_rad, near_plane: doubles, as VolumeRaycaster.__init__ holds them (VR.py:77-78)
+ *   jitter_seed: 0 = no jitter; otherwise tmin += U[0,1)*len/n with U from a counter-based hash of
+ *                (seed, view_base+view, pixel) -- replaces ti.random (VR.py:255) so that forward and
+ *                backward see the same offsets
+ *   entry, exit_ [n_views][W][H] f32; rays [n_views][W][H][3] f32; nsamp [n_views][W][H] i32 */
+int dr_ray_setup(const float *cam, int n_views, int W, int H, int VX, int VY, int VZ,
+                 double fov_rad, double near_plane, float sampling_rate,
+                 uint32_t jitter_seed, uint32_t view_base,
+                 float *entry, float *exit_, float *rays, int32_t *nsamp, void *stream);
+
+/* Forward march: trilinear sampling, 1-D TF lookup, Phong shading, front-to-back compositing with
+ * early termination at A >= 0.99.
+ *   mode DR_MODE_DIFF    replaces clear_framebuffer + raycast + get_final_image
+ *                        (VR.py:374-382, 261-306, 363-372); marches min(n, max_samples) samples
+ *   mode DR_MODE_NONDIFF replaces raycast_nondiff + get_final_image_nondiff (VR.py:308-361)
+ *   tf      [n_views or 1][R][4] f32
+ *   out_rgba [n_views][W][H][4] f32 (overwritten)
+ *   steps   [n_views][W][H] i32, nullable: samples that passed the termination test
+ *           (= valid_sample_step_count - 1, VR.py:303,381) */
+int dr_march_fwd(const void *vol, int vol_dtype, int VX, int VY, int VZ,
+                 int64_t sx, int64_t sy, int64_t sz, int64_t vol_view_stride,
+                 const float *tf, int R, int64_t tf_view_stride,
+                 const float *cam, const float *entry, const float *exit_, const float *rays,
+                 const int32_t *nsamp, int n_views, int W, int H, int max_samples,
+                 float sampling_rate, int mode, int variant,
+                 float *out_rgba, int32_t *steps, void *stream);
+
+/* Backward of the DR_MODE_DIFF march w.r.t. the volume and the transfer function: the hand-derived,
+ * tape-free equivalent of get_final_image.grad + raycast.grad (Taichi autodiff, VR.py:460-461,470-471).
+ *   grad_out [n_views][W][H][4]  upstream gradient of out_rgba
+ *   out_rgba [n_views][W][H][4]  the forward result for the same inputs (saved by the caller)
+ *   d_vol    f32, element strides (dsx,dsy,dsz), nullable; ACCUMULATED into (caller zeroes)
+ *   d_tf     [n_views or 1][R][4] f32, nullable; ACCUMULATED into (caller zeroes)
+ * Gradients w.r.t. camera and sampling rate are not defined (the reference returns None, VR.py:465). */
+int dr_march_bwd(const void *vol, int vol_dtype, int VX, int VY, int VZ,
+                 int64_t sx, int64_t sy, int64_t sz, int64_t vol_view_stride,
+                 const float *tf, int R, int64_t tf_view_stride,
+                 const float *cam, const float *entry, const float *exit_, const float *rays,
+                 const int32_t *nsamp, int n_views, int W, int H, int max_samples,
+                 float sampling_rate, int variant,
+                 const float *grad_out, const float *out_rgba,
+                 float *d_vol, int64_t dsx, int64_t dsy, int64_t dsz, int64_t dvol_view_stride,
+                 float *d_tf, int64_t dtf_view_stride, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFERENDER_HIP_H */

@@ -1,0 +1,73 @@
+"""N > 1 path on CPU: two gloo ranks shard the views, accumulate local gradients (computed with the
+oracle here, since there is no GPU) and all-reduce them; the result must equal the single-process sum."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, n_views, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from differender_amd.distributed import shard_views, all_reduce_gradients
+    from oracle import oracle as O
+    vol = O.synth_volume(20); tf = O.bench_tf(16, 0.03); tf[:, 3] = np.linspace(0.01, 0.06, 16)
+    dv = torch.zeros(20, 20, 20).permute(2, 0, 1)  # dense but not contiguous, as the product's d_vol is
+    dt = torch.zeros(16, 4)
+    mine = shard_views(n_views)
+    for v in mine:
+        cam = O.in_circles(0.4 * v)
+        e, x, r, n = O.ray_setup(cam, 16, 16, vol.shape)
+        g = np.random.RandomState(v).randn(16, 16, 4).astype(np.float32)
+        a, b = O.march_bwd(vol, tf, cam, e, x, r, n, 4096, 1.0, g)
+        dv += torch.from_numpy(a); dt += torch.from_numpy(b)
+    all_reduce_gradients([dv, dt])
+    if rank == 0:
+        q.put((mine, dv.contiguous().numpy(), dt.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_view_sharding_is_a_partition():
+    from differender_amd.distributed import shard_views
+    for n, w in [(8, 2), (5, 2), (7, 4), (1, 2)]:
+        parts = [shard_views(n, r, w) for r in range(w)]
+        assert sorted(sum(parts, [])) == list(range(n))
+
+
+def test_two_rank_gradient_allreduce_matches_single_process(oracle):
+    n_views = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_views, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    mine, dv, dt = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert mine == [0, 2]
+    O = oracle
+    vol = O.synth_volume(20); tf = O.bench_tf(16, 0.03); tf[:, 3] = np.linspace(0.01, 0.06, 16)
+    dv_ref = np.zeros_like(vol); dt_ref = np.zeros_like(tf)
+    for v in range(n_views):
+        cam = O.in_circles(0.4 * v)
+        e, x, r, n = O.ray_setup(cam, 16, 16, vol.shape)
+        g = np.random.RandomState(v).randn(16, 16, 4).astype(np.float32)
+        a, b = O.march_bwd(vol, tf, cam, e, x, r, n, 4096, 1.0, g)
+        dv_ref += a; dt_ref += b
+    assert np.abs(dv - dv_ref).max() <= 1e-5 * np.abs(dv_ref).max()
+    assert np.abs(dt - dt_ref).max() <= 1e-5 * np.abs(dt_ref).max()

@@ -1,0 +1,283 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Tolerances (BASELINE.json north_star): forward RGBA within 1e-5, gradients within 1e-4 -- the latter
+relative to the largest gradient magnitude of the tensor (f32 scatter-add of ~1e2..1e3 contributions per
+element). Ray-setup buffers are compared bit-for-bit and then shared between oracle and device march
+so that a flipped floor() cannot mask a march bug."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL = 1e-5
+GRAD_TOL = 1e-4
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+
+
+def scene(O, N=48, R=64, tf="bench", alpha=0.01, cam_i=0.3):
+    vol = O.synth_volume(N)
+    tfa = O.bench_tf(R, alpha) if tf == "bench" else O.peaks_tf(R)
+    return vol, tfa, O.in_circles(cam_i)
+
+
+def gpu_setup(F, cam, WH, vshape, sr=1.0, seed=0, view_base=0):
+    cam_t = T(np.atleast_2d(cam).astype(np.float32))
+    return F.ray_setup(cam_t, WH, vshape, sr, 30.0, 0.1, seed, view_base)
+
+
+def grad_close(a, b, tol=GRAD_TOL):
+    scale = max(float(np.abs(b).max()), 1e-12)
+    err = float(np.abs(a - b).max()) / scale
+    return err <= tol, err
+
+
+@pytest.fixture(scope="module")
+def F(hiplib):
+    assert torch.cuda.is_available(), "gpu tests need a ROCm device"
+    from differender_amd import functional
+    return functional
+
+
+@pytest.mark.parametrize("WH,vshape,sr,cam_i", [((64, 64), (48, 48, 48), 1.0, 0.3), ((40, 72), (32, 48, 40), 2.0, 1.9),
+                                               ((33, 21), (16, 16, 16), 0.7, 4.0)])
+def test_ray_setup_bit_exact(oracle, F, WH, vshape, sr, cam_i):
+    cam = oracle.in_circles(cam_i)
+    e0, x0, r0, n0 = oracle.ray_setup(cam, *WH, vshape, sr=sr)
+    e, x, r, n = gpu_setup(F, cam, WH, vshape, sr)
+    assert np.array_equal(n[0].cpu().numpy(), n0)
+    hit = n0 > 0
+    assert np.array_equal(e[0].cpu().numpy()[hit], e0[hit])
+    assert np.array_equal(x[0].cpu().numpy()[hit], x0[hit])
+    assert np.array_equal(r[0].cpu().numpy(), r0)
+
+
+def test_ray_setup_jitter_bit_exact(oracle, F):
+    cam = oracle.in_circles(2.2)
+    e0, x0, r0, n0 = oracle.ray_setup(cam, 48, 48, (40, 40, 40), jitter_seed=12345, view=3)
+    e, x, r, n = gpu_setup(F, cam, (48, 48), (40, 40, 40), seed=12345, view_base=3)
+    hit = n0 > 0
+    assert np.array_equal(n[0].cpu().numpy(), n0)
+    assert np.array_equal(e[0].cpu().numpy()[hit], e0[hit])
+
+
+def _fwd_both(O, F, vol, tf, cam, WH, S=1 << 20, sr=1.0, mode=0, seed=0):
+    e0, x0, r0, n0 = O.ray_setup(cam, *WH, vol.shape, sr=sr, jitter_seed=seed)
+    ref, steps_ref = O.march_fwd(vol, tf, cam, e0, x0, r0, n0, S, sr, mode)
+    e, x, r, n = gpu_setup(F, cam, WH, vol.shape, sr, seed)
+    out, steps = F.march_fwd(T(vol), T(tf), T(cam[None]), e, x, r, n, S, sr, mode)
+    return ref, steps_ref, out[0].cpu().numpy(), steps[0].cpu().numpy(), (e0, x0, r0, n0), (e, x, r, n)
+
+
+@pytest.mark.parametrize("sr", [1.0, 2.0])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_forward_parity(oracle, F, sr, mode):
+    vol, tf, cam = scene(oracle, alpha=0.02)
+    ref, sref, out, steps, _, _ = _fwd_both(oracle, F, vol, tf, cam, (64, 64), sr=sr, mode=mode)
+    assert np.array_equal(steps, sref)
+    assert np.abs(out - ref).max() <= FWD_TOL
+
+
+def test_forward_parity_early_termination(oracle, F):
+    vol, tf, cam = scene(oracle, tf="peaks", R=128, cam_i=1.1)
+    tf[:, 3] *= 2.0
+    ref, sref, out, steps, (e0, x0, r0, n0), _ = _fwd_both(oracle, F, vol, tf, cam, (64, 64))
+    assert (sref < n0)[n0 > 40].mean() > 0.3, "scene must exercise early termination"
+    # a ray whose alpha lands within rounding of 0.99 may legitimately take one sample more or fewer
+    diff = np.abs(out - ref).max(-1)
+    same = steps == sref
+    assert same.mean() > 0.995
+    assert diff[same].max() <= FWD_TOL
+    assert diff.max() <= 2e-3
+
+
+def test_forward_max_samples_and_rect(oracle, F):
+    vol = oracle.synth_volume((24, 40, 32))
+    tf = oracle.bench_tf(32, 0.01)
+    cam = oracle.in_circles(5.0)
+    ref, sref, out, steps, _, _ = _fwd_both(oracle, F, vol, tf, cam, (40, 24), S=17)
+    assert steps.max() == 17 and np.array_equal(steps, sref)
+    assert np.abs(out - ref).max() <= FWD_TOL
+
+
+def test_forward_jittered(oracle, F):
+    vol, tf, cam = scene(oracle)
+    ref, sref, out, steps, _, _ = _fwd_both(oracle, F, vol, tf, cam, (48, 48), seed=99)
+    assert np.abs(out - ref).max() <= FWD_TOL
+    ref0, _, _, _, _, _ = _fwd_both(oracle, F, vol, tf, cam, (48, 48), seed=0)
+    assert np.abs(ref - ref0).max() > 1e-6  # jitter changes the image
+
+
+def test_forward_flat_volume_ambient_only(oracle, F):
+    R, k = 11, 4
+    vol = np.full((8, 8, 8), k / (R - 1), np.float32)
+    tf = np.zeros((R, 4), np.float32); tf[k] = [0.9, 0.5, 0.25, 0.3]
+    cam = np.array([0.0, 0.3, 3.0], np.float32)
+    ref, sref, out, steps, _, _ = _fwd_both(oracle, F, vol, tf, cam, (16, 16))
+    assert np.isfinite(out).all() and np.abs(out - ref).max() <= FWD_TOL
+
+
+def test_forward_strided_and_f16_volume(oracle, F):
+    vol, tf, cam = scene(oracle, N=32)
+    e, x, r, n = gpu_setup(F, cam, (32, 32), vol.shape)
+    base, _ = F.march_fwd(T(vol), T(tf), T(cam[None]), e, x, r, n, 4096, 1.0)
+    # user layout (1,D,H,W): field index (i,j,k) = (W,D,H) -> memory order (D,H,W) (VR.py:566,571)
+    user = T(vol).permute(1, 2, 0).contiguous()  # (D,H,W)
+    view = user.permute(2, 0, 1)  # (W,D,H) view, x fastest in memory
+    assert not view.is_contiguous()
+    out, _ = F.march_fwd(view, T(tf), T(cam[None]), e, x, r, n, 4096, 1.0)
+    assert torch.equal(out, base)
+    # fp16 storage: compare with the oracle run on the rounded volume
+    vol16 = vol.astype(np.float16)
+    e0, x0, r0, n0 = oracle.ray_setup(cam, 32, 32, vol.shape)
+    ref, _ = oracle.march_fwd(vol16.astype(np.float32), tf, cam, e0, x0, r0, n0, 4096, 1.0, 0)
+    out16, _ = F.march_fwd(T(vol16), T(tf), T(cam[None]), e, x, r, n, 4096, 1.0)
+    assert np.abs(out16[0].cpu().numpy() - ref).max() <= FWD_TOL
+
+
+def _bwd_both(O, F, vol, tf, cam, WH, sr=1.0, S=1 << 20, seed=5, want=(True, True)):
+    e0, x0, r0, n0 = O.ray_setup(cam, *WH, vol.shape, sr=sr)
+    rng = np.random.RandomState(seed)
+    g = rng.randn(*WH, 4).astype(np.float32)
+    dv0, dt0 = O.march_bwd(vol, tf, cam, e0, x0, r0, n0, S, sr, g, *want)
+    e, x, r, n = gpu_setup(F, cam, WH, vol.shape, sr)
+    vt, tt, ct = T(vol), T(tf), T(cam[None])
+    out, _ = F.march_fwd(vt, tt, ct, e, x, r, n, S, sr)
+    dv, dt = F.march_bwd(vt, tt, ct, e, x, r, n, S, sr, T(g[None]), out, *want)
+    return dv0, dt0, (None if dv is None else dv.cpu().numpy()), (None if dt is None else dt.cpu().numpy())
+
+
+@pytest.mark.parametrize("sr", [1.0, 2.0])
+def test_backward_parity(oracle, F, sr):
+    vol, tf, cam = scene(oracle, N=40, R=32, alpha=0.03)
+    tf[:, 3] = np.linspace(0.01, 0.08, 32)  # non-constant alpha so dV sees the TF slope
+    dv0, dt0, dv, dt = _bwd_both(oracle, F, vol, tf, cam, (48, 48), sr=sr)
+    ok, err = grad_close(dt, dt0); assert ok, f"d_tf rel err {err}"
+    ok, err = grad_close(dv, dv0); assert ok, f"d_vol rel err {err}"
+
+
+def test_backward_parity_early_termination(oracle, F):
+    vol, tf, cam = scene(oracle, N=40, tf="peaks", R=64, cam_i=1.1)
+    tf[:, 3] *= 2.0
+    dv0, dt0, dv, dt = _bwd_both(oracle, F, vol, tf, cam, (48, 48))
+    ok, err = grad_close(dt, dt0, 5e-4); assert ok, f"d_tf rel err {err}"
+    ok, err = grad_close(dv, dv0, 5e-4); assert ok, f"d_vol rel err {err}"
+
+
+def test_backward_selective_outputs(oracle, F):
+    vol, tf, cam = scene(oracle, N=24, R=16, alpha=0.03)
+    dv0, dt0, dv, dt = _bwd_both(oracle, F, vol, tf, cam, (24, 24), want=(False, True))
+    assert dv is None and grad_close(dt, dt0)[0]
+    dv0, dt0, dv, dt = _bwd_both(oracle, F, vol, tf, cam, (24, 24), want=(True, False))
+    assert dt is None and grad_close(dv, dv0)[0]
+
+
+def test_backward_flat_volume_has_no_nan(oracle, F):
+    vol = np.full((12, 12, 12), 0.4, np.float32)
+    tf = oracle.bench_tf(16, 0.05)
+    cam = oracle.in_circles(0.2)
+    dv0, dt0, dv, dt = _bwd_both(oracle, F, vol, tf, cam, (16, 16))
+    assert np.isfinite(dv).all() and np.isfinite(dt).all()
+    assert grad_close(dv, dv0)[0] and grad_close(dt, dt0)[0]
+
+
+def test_batched_views_shared_volume(oracle, F):
+    """n_views > 1 in one launch; shared volume/tf accumulate one gradient (replaces VR.py:418-426,450-464)."""
+    vol, tf, _ = scene(oracle, N=32, R=32, alpha=0.03)
+    cams = np.stack([oracle.in_circles(0.5 * v) for v in range(3)])
+    WH = (32, 32)
+    rng = np.random.RandomState(1)
+    g = rng.randn(3, *WH, 4).astype(np.float32)
+    dv_ref = np.zeros_like(vol); dt_ref = np.zeros_like(tf); refs = []
+    for v in range(3):
+        e0, x0, r0, n0 = oracle.ray_setup(cams[v], *WH, vol.shape)
+        ref, _ = oracle.march_fwd(vol, tf, cams[v], e0, x0, r0, n0, 4096, 1.0, 0)
+        a, b = oracle.march_bwd(vol, tf, cams[v], e0, x0, r0, n0, 4096, 1.0, g[v])
+        dv_ref += a; dt_ref += b; refs.append(ref)
+    ct = T(cams)
+    e, x, r, n = F.ray_setup(ct, WH, vol.shape, 1.0)
+    out, _ = F.march_fwd(T(vol), T(tf), ct, e, x, r, n, 4096, 1.0)
+    assert np.abs(out.cpu().numpy() - np.stack(refs)).max() <= FWD_TOL
+    dv, dt = F.march_bwd(T(vol), T(tf), ct, e, x, r, n, 4096, 1.0, T(g), out)
+    assert dv.shape == vol.shape and dt.shape == tf.shape
+    assert grad_close(dv.cpu().numpy(), dv_ref)[0] and grad_close(dt.cpu().numpy(), dt_ref)[0]
+    # per-view volumes/tfs: per-view gradients
+    volb = T(np.stack([vol, vol * 0.9, vol * 0.8])); tfb = T(np.stack([tf, tf, tf]))
+    outb, _ = F.march_fwd(volb, tfb, ct, e, x, r, n, 4096, 1.0)
+    dvb, dtb = F.march_bwd(volb, tfb, ct, e, x, r, n, 4096, 1.0, T(g), outb)
+    assert dvb.shape == (3, *vol.shape) and dtb.shape == (3, *tf.shape)
+    e0, x0, r0, n0 = oracle.ray_setup(cams[1], *WH, vol.shape)
+    a, b = oracle.march_bwd(vol * np.float32(0.9), tf, cams[1], e0, x0, r0, n0, 4096, 1.0, g[1])
+    assert grad_close(dvb[1].cpu().numpy(), a)[0] and grad_close(dtb[1].cpu().numpy(), b)[0]
+
+
+def test_raycaster_module_matches_oracle_layout(oracle, F):
+    """End-to-end through Raycaster/RaycastFunction: (1,D,H,W) in, (4,H,W) out with the H flip (VR.py:543-548),
+    autograd gradients in the user's layout."""
+    from differender_amd.volume_raycaster import Raycaster
+    D, H, Wv = 20, 24, 28
+    vol_f = oracle.synth_volume((Wv, D, H))  # field layout (W,D,H)
+    tf_f = oracle.bench_tf(16, 0.03); tf_f[:, 3] = np.linspace(0.01, 0.06, 16)
+    cam = oracle.in_circles(0.9)
+    out_shape = (32, 40)  # (w, h)
+    rc = Raycaster((D, H, Wv), out_shape, 16, jitter=False, max_samples=4096)
+    vol_u = T(vol_f).permute(1, 2, 0).contiguous()[None].requires_grad_(True)  # (1,D,H,W)
+    tf_u = T(tf_f).t().contiguous().requires_grad_(True)  # (4,R)
+    img = rc(vol_u, tf_u, T(cam))
+    assert img.shape == (4, out_shape[1], out_shape[0]) and img.is_contiguous()
+    ref, _, (e0, x0, r0, n0) = oracle.render(vol_f, tf_f, cam, out_shape, S=4096)
+    ref_img = np.ascontiguousarray(np.flip(ref, 1).transpose(2, 1, 0))
+    assert np.abs(img.detach().cpu().numpy() - ref_img).max() <= FWD_TOL
+    rng = np.random.RandomState(2)
+    g_img = rng.randn(*img.shape).astype(np.float32)
+    (img * T(g_img)).sum().backward()
+    g_field = np.ascontiguousarray(np.flip(g_img.transpose(2, 1, 0), 1))  # back to (W,H,4)
+    dv0, dt0 = oracle.march_bwd(vol_f, tf_f, cam, e0, x0, r0, n0, 4096, 1.0, g_field)
+    assert vol_u.grad.shape == vol_u.shape and tf_u.grad.shape == tf_u.shape
+    assert grad_close(vol_u.grad[0].permute(2, 0, 1).cpu().numpy(), dv0)[0]
+    assert grad_close(tf_u.grad.t().cpu().numpy(), dt0)[0]
+    # nondiff render: default rate 4x, never jittered, clamped
+    nd = rc.raycast_nondiff(vol_u.detach(), tf_u.detach(), T(cam))
+    refn, _, _ = oracle.render(vol_f, tf_f, cam, out_shape, sr=4.0, mode=1)
+    assert np.abs(nd.cpu().numpy() - np.flip(refn, 1).transpose(2, 1, 0)).max() <= FWD_TOL
+    # batched look_from with shared volume/tf: (BS,4,H,W), one accumulated gradient
+    vol_u.grad = None; tf_u.grad = None
+    cams = np.stack([oracle.in_circles(0.9), oracle.in_circles(2.0)])
+    imgb = rc(vol_u, tf_u, T(cams))
+    assert imgb.shape == (2, 4, out_shape[1], out_shape[0])
+    assert np.abs(imgb[0].detach().cpu().numpy() - ref_img).max() <= FWD_TOL
+    imgb.sum().backward()
+    assert vol_u.grad.shape == vol_u.shape and torch.isfinite(vol_u.grad).all()
+
+
+def test_optimisation_loop_reduces_loss(oracle, F):
+    """Counterpart of examples/test_opt_tf.py:63-88 on synthetic data: the loss must go down."""
+    from differender_amd.volume_raycaster import Raycaster
+    N = 32
+    vol_gt = T(oracle.synth_volume(N)).permute(1, 2, 0).contiguous()[None]
+    tf = T(oracle.peaks_tf(32)).t().contiguous()
+    rc = Raycaster((N, N, N), (48, 48), 32, jitter=True, max_samples=1024)
+    torch.manual_seed(0)
+    vol = (vol_gt + 0.15 * torch.randn_like(vol_gt)).clamp(0, 1).requires_grad_(True)
+    opt = torch.optim.Adam([vol], lr=2e-2)
+    cams = T(np.stack([oracle.in_circles(0.7 * v) for v in range(4)]))
+    with torch.no_grad():
+        gt = rc.raycast_nondiff(vol_gt, tf, cams, sampling_rate=2.0)
+    losses = []
+    for it in range(12):
+        opt.zero_grad()
+        res = rc(vol, tf, cams)
+        loss = torch.nn.functional.mse_loss(res, gt)
+        loss.backward()
+        opt.step()
+        with torch.no_grad():
+            vol.clamp_(0.0, 1.0)
+        losses.append(float(loss))
+    assert losses[-1] < 0.7 * losses[0], losses

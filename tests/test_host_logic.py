@@ -1,0 +1,68 @@
+"""Host-side logic that needs no GPU: batching/layout rules of Raycaster (VR.py:551-571), utils."""
+import math
+
+import pytest
+import torch
+
+
+@pytest.fixture(scope="module")
+def rc(hiplib):
+    from differender_amd.volume_raycaster import Raycaster
+    return Raycaster((6, 8, 10), (16, 24), 12, max_samples=64)  # volume (D,H,W) = (6,8,10)
+
+
+def test_ctor_matches_reference_attributes(rc):
+    assert rc.volume_shape == (10, 6, 8)  # (W, D, H), VR.py:481
+    assert rc.vr.resolution == (16, 24) and rc.vr.max_samples == 64
+    assert "Max Samples = 64" in repr(rc)
+
+
+def test_determine_batch_unbatched(rc):
+    vol = torch.rand(1, 6, 8, 10); tf = torch.rand(4, 12); lf = torch.rand(3)
+    b, bs, v, t, l = rc._determine_batch(vol, tf, lf)
+    assert (b, bs) == (False, 0)
+    assert v.shape == (10, 6, 8) and t.shape == (12, 4) and l.shape == (3,)
+    assert torch.equal(v, vol.squeeze(0).permute(2, 0, 1)) and torch.equal(t, tf.permute(1, 0))
+    assert v.data_ptr() == vol.data_ptr()  # a view, not the .contiguous() copy of VR.py:571
+
+
+def test_determine_batch_mixed(rc):
+    vol = torch.rand(1, 6, 8, 10); tf = torch.rand(4, 12); lf = torch.rand(5, 3)
+    b, bs, v, t, l = rc._determine_batch(vol, tf, lf)
+    assert b and bs == 5 and v.shape == (10, 6, 8) and t.shape == (12, 4) and l.shape == (5, 3)
+    volb = torch.rand(5, 1, 6, 8, 10); tfb = torch.rand(5, 4, 12)
+    b, bs, v, t, l = rc._determine_batch(volb, tfb, lf[0])
+    assert b and bs == 5 and v.shape == (5, 10, 6, 8) and t.shape == (5, 12, 4) and l.shape == (5, 3)
+    assert torch.equal(v[2], volb[2, 0].permute(2, 0, 1))
+    with pytest.raises(ValueError):
+        rc._determine_batch(torch.rand(6, 8, 10), tf, lf)
+
+
+def test_no_cpu_fallback(rc):
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        rc(torch.rand(1, 6, 8, 10), torch.rand(4, 12), torch.tensor([2.5, 0.7, 0.0]))
+
+
+def test_alias_package_imports():
+    from differender.volume_raycaster import Raycaster, RaycastFunction, VolumeRaycaster  # noqa: F401
+    from differender.utils import get_tf, in_circles, get_rand_pos
+    tf = get_tf("tf1", 128)
+    assert tf.shape == (4, 128) and float(tf.min()) >= 0 and float(tf.max()) <= 1
+    # control point (0.3601 -> a=0.3904) .. (0.4475 -> 0.3917): plateau value inside
+    assert abs(float(tf[3, int(round(0.40 * 127))]) - 0.391) < 2e-3
+    assert get_tf("gray", 16)[3, 0] == pytest.approx(0.02) and get_tf("black", 16).max() == pytest.approx(1e-2)
+    with pytest.raises(Exception):
+        get_tf("nope", 8)
+    c = in_circles(0.5)
+    assert c.tolist() == pytest.approx([2.5 * math.cos(0.5), 0.7, 2.5 * math.sin(0.5)])
+    p = get_rand_pos(7)
+    assert p.shape == (7, 3) and torch.allclose(p.norm(dim=1), torch.full((7,), 2.7), atol=1e-5)
+
+
+def test_tex_from_pts_is_piecewise_linear():
+    from differender_amd.utils import tex_from_pts
+    pts = torch.tensor([[0.0, 0, 0, 0, 0.0], [0.5, 1, 0, 0, 1.0], [1.0, 0, 1, 0, 0.0]])
+    t = tex_from_pts(pts, 5)
+    assert t.shape == (4, 5)
+    assert t[0].tolist() == pytest.approx([0, 0.5, 1, 0.5, 0]) and t[3].tolist() == pytest.approx([0, 0.5, 1, 0.5, 0])
+    assert t[1].tolist() == pytest.approx([0, 0, 0, 0.5, 1])
