@@ -204,7 +204,8 @@ def run_cpu_baseline(vol, tf, args, sr, want_vol, want_tf):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         pass
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    cores = min(cores, 16)  # a 1-GPU box's CPU share (the host exposes all its cores to every box)
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     vol_h = vol.cpu().numpy()
     tf_h = tf.cpu().numpy()
     cam = np.array(in_circles(0.0), np.float32)

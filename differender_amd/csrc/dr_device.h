@@ -9,14 +9,16 @@ namespace dr {
 
 struct f3 { float x, y, z; };
 __device__ __forceinline__ f3 make_f3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
-__device__ __forceinline__ float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+// Arithmetic convention D2: a*b+c in dot/mix/position/compositing is ONE rounding, spelled as fmaf;
+// every kernel translation unit is compiled with -ffp-contract=off so nothing else is contracted.
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
 // taichi Vector.normalized(): invlen = 1/(norm + 0); invlen * v
 __device__ __forceinline__ f3 normalized3(f3 a) {
     float inv = 1.0f / (sqrtf(dot3(a, a)) + 0.0f);
     return make_f3(inv * a.x, inv * a.y, inv * a.z);
 }
 // taichi_glsl mix
-__device__ __forceinline__ float mixf(float x, float y, float a) { return x * (1.0f - a) + y * a; }
+__device__ __forceinline__ float mixf(float x, float y, float a) { return fmaf(y, a, x * (1.0f - a)); }
 
 // jitter RNG (replaces ti.random, VR.py:255): counter-based integer hash of (seed, view, pixel)
 __device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
@@ -28,6 +30,18 @@ __device__ __forceinline__ float jitter_u(uint32_t seed, uint32_t view, uint32_t
     h = hash_u32(h ^ (view * 0x85EBCA6BU + 0xC2B2AE35U));
     h = hash_u32(h ^ pix);
     return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+
+// pow(x, 32) for x >= 0 (VR.py:296, shininess 32) by five squarings: <= 16 ulp from powf, i.e. < 3e-7
+// absolute on the specular term, and costs 5 multiplies instead of a log/exp pair.
+__device__ __forceinline__ float pow32(float x) {
+    float x2 = x * x, x4 = x2 * x2, x8 = x4 * x4, x16 = x8 * x8;
+    return x16 * x16;
+}
+// x^31 = x^16 * x^8 * x^4 * x^2 * x (derivative of the specular term)
+__device__ __forceinline__ float pow31(float x) {
+    float x2 = x * x, x4 = x2 * x2, x8 = x4 * x4, x16 = x8 * x8;
+    return ((x16 * x8) * (x4 * x2)) * x;
 }
 
 // VR.py:7-21 low_high_frac
@@ -58,9 +72,9 @@ struct Cell {
 // VR.py:163-172: clamp to [0,1], scale, split, clamp the high index
 template <typename VT>
 __device__ __forceinline__ void tri_cell(const VolView<VT> &v, float px, float py, float pz, Cell &c) {
-    float qx = fminf(1.0f, fmaxf(0.0f, 0.5f * px + 0.5f)) * v.scx;
-    float qy = fminf(1.0f, fmaxf(0.0f, 0.5f * py + 0.5f)) * v.scy;
-    float qz = fminf(1.0f, fmaxf(0.0f, 0.5f * pz + 0.5f)) * v.scz;
+    float qx = fminf(1.0f, fmaxf(0.0f, fmaf(0.5f, px, 0.5f))) * v.scx;
+    float qy = fminf(1.0f, fmaxf(0.0f, fmaf(0.5f, py, 0.5f))) * v.scy;
+    float qz = fminf(1.0f, fmaxf(0.0f, fmaf(0.5f, pz, 0.5f))) * v.scz;
     low_high_frac(qx, c.x0, c.fx);
     low_high_frac(qy, c.y0, c.fy);
     low_high_frac(qz, c.z0, c.fz);
@@ -132,7 +146,7 @@ __device__ __forceinline__ void sample_pos(const RayGeom &rg, float cx, float cy
                                            float &pz) {
     float f = (float)s / (float)(rg.n - 1);
     float t = mixf(rg.t0, rg.exit_, f);
-    px = cx + t * rg.vx; py = cy + t * rg.vy; pz = cz + t * rg.vz;
+    px = fmaf(t, rg.vx, cx); py = fmaf(t, rg.vy, cy); pz = fmaf(t, rg.vz, cz);
 }
 
 // VR.py:205-219 + 284-285. tf is a [R][4] table (LDS or global).
@@ -172,12 +186,12 @@ __device__ __forceinline__ void shade(const VolView<VT> &v, f3 light_pos, f3 vd,
         sm.m = dot3(sm.nrm, sm.ld);
         sm.ndl = fmaxf(sm.m, 0.0f);
         float two_m = 2.0f * sm.m;
-        sm.rf = make_f3(sm.ld.x - two_m * sm.nrm.x, sm.ld.y - two_m * sm.nrm.y, sm.ld.z - two_m * sm.nrm.z);
-        sm.q = dot3(sm.rf, make_f3(-vd.x, -vd.y, -vd.z));
+        sm.rf = make_f3(fmaf(-two_m, sm.nrm.x, sm.ld.x), fmaf(-two_m, sm.nrm.y, sm.ld.y), fmaf(-two_m, sm.nrm.z, sm.ld.z));
+        sm.q = -dot3(sm.rf, vd);  // r.dot(-vd): negation is exact
         sm.rdv = fmaxf(sm.q, 0.0f);
     }
-    sm.spec = 0.3f * powf(sm.rdv, 32.0f);
-    sm.Lraw = 0.8f * sm.ndl + sm.spec + 0.4f;
+    sm.spec = 0.3f * pow32(sm.rdv);
+    sm.Lraw = fmaf(0.8f, sm.ndl, sm.spec) + 0.4f;
     sm.L = clampL ? fminf(1.0f, sm.Lraw) : sm.Lraw;
 }
 

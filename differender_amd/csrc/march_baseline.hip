@@ -69,10 +69,10 @@ __global__ __launch_bounds__(256) void march_fwd_baseline_kernel(MarchParams<VT>
         if (MODE == DR_MODE_NONDIFF && !(sm.a > 1e-3f)) continue;
         shade(vol, light, vd, MODE == DR_MODE_DIFF, sm);
         const float T = 1.0f - A;
-        C0 = T * (sm.L * sm.r * sm.op) + C0;
-        C1 = T * (sm.L * sm.g * sm.op) + C1;
-        C2 = T * (sm.L * sm.b * sm.op) + C2;
-        A = T * sm.op + A;
+        C0 = fmaf(T, sm.L * sm.r * sm.op, C0);
+        C1 = fmaf(T, sm.L * sm.g * sm.op, C1);
+        C2 = fmaf(T, sm.L * sm.b * sm.op, C2);
+        A = fmaf(T, sm.op, A);
     }
     if (MODE == DR_MODE_NONDIFF) {
         C0 = fminf(1.0f, C0); C1 = fminf(1.0f, C1); C2 = fminf(1.0f, C2); A = fminf(1.0f, A);
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void march_bwd_baseline_kernel(MarchParams<VT>
             classify(vol, lds_tf, P.R, P.tf_len, P.inv_sr, sm);
             shade(vol, light, vd, true, sm);
             const float T = 1.0f - A;
-            const float A_next = T * sm.op + A;
+            const float A_next = fmaf(T, sm.op, A);
             const bool last = (s == nmarch - 1) || !(A_next < 0.99f);
             const float rgbdot = go.x * sm.r + go.y * sm.g + go.z * sm.b;  // gC . rgb
             const float qs = sm.L * rgbdot + go.w;
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void march_bwd_baseline_kernel(MarchParams<VT>
                 tri_scatter_global(vol, dv, sm.px, sm.py, sm.pz, I_bar);
                 if (!sm.flat) {
                     const float ndl_bar = 0.8f * Lraw_bar;
-                    const float rdv_bar = 0.3f * 32.0f * powf(sm.rdv, 31.0f) * Lraw_bar;
+                    const float rdv_bar = 0.3f * 32.0f * pow31(sm.rdv) * Lraw_bar;
                     const float q_bar = (0.0f < sm.q) ? rdv_bar : 0.0f;
                     const f3 rf_bar = make_f3(-vd.x * q_bar, -vd.y * q_bar, -vd.z * q_bar);
                     const float m_bar = ((0.0f < sm.m) ? ndl_bar : 0.0f) - 2.0f * dot3(sm.nrm, rf_bar);

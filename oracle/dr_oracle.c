@@ -16,6 +16,7 @@
 #define R_POW powf
 #define R_FMAX fmaxf
 #define R_FMIN fminf
+#define R_FMA fmaf
 #include "dr_oracle_impl.inc"
 #undef REAL
 #undef SUF
@@ -24,6 +25,7 @@
 #undef R_POW
 #undef R_FMAX
 #undef R_FMIN
+#undef R_FMA
 
 #define REAL double
 #define SUF(x) x##_f64
@@ -32,6 +34,7 @@
 #define R_POW pow
 #define R_FMAX fmax
 #define R_FMIN fmin
+#define R_FMA fma
 #include "dr_oracle_impl.inc"
 
 int dro_abi_version(void) { return 1; }

@@ -87,7 +87,7 @@ def test_forward_parity(oracle, F, sr, mode):
 
 def test_forward_parity_early_termination(oracle, F):
     vol, tf, cam = scene(oracle, tf="peaks", R=128, cam_i=1.1)
-    tf[:, 3] *= 2.0
+    tf[:, 3] = np.linspace(0.0, 0.4, 128)
     ref, sref, out, steps, (e0, x0, r0, n0), _ = _fwd_both(oracle, F, vol, tf, cam, (64, 64))
     assert (sref < n0)[n0 > 40].mean() > 0.3, "scene must exercise early termination"
     # a ray whose alpha lands within rounding of 0.99 may legitimately take one sample more or fewer
@@ -165,7 +165,7 @@ def test_backward_parity(oracle, F, sr):
 
 def test_backward_parity_early_termination(oracle, F):
     vol, tf, cam = scene(oracle, N=40, tf="peaks", R=64, cam_i=1.1)
-    tf[:, 3] *= 2.0
+    tf[:, 3] = np.linspace(0.0, 0.4, 64)
     dv0, dt0, dv, dt = _bwd_both(oracle, F, vol, tf, cam, (48, 48))
     ok, err = grad_close(dt, dt0, 5e-4); assert ok, f"d_tf rel err {err}"
     ok, err = grad_close(dv, dv0, 5e-4); assert ok, f"d_vol rel err {err}"
@@ -279,5 +279,5 @@ def test_optimisation_loop_reduces_loss(oracle, F):
         opt.step()
         with torch.no_grad():
             vol.clamp_(0.0, 1.0)
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     assert losses[-1] < 0.7 * losses[0], losses
