@@ -104,6 +104,8 @@ def main():
     sr = 1.0
     total_steps = torch.zeros((), dtype=torch.int64, device=dev)
     ev = {"fwd": [], "bwd": []}
+    # scratch of the brick-centric kernels (coarse tape); allocated once, reused by every step
+    ws = F.alloc_workspace(1, (IMG, IMG), (N, N, N), R, dev) if args.variant == 0 else None
 
     def step(k, timed):
         v = k * world + rank
@@ -112,7 +114,7 @@ def main():
         if timed:
             a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a0.record()
-        out, steps = F.march_fwd(vol, tf, cam, e, x, r, n, S, sr, variant=args.variant)
+        out, steps = F.march_fwd(vol, tf, cam, e, x, r, n, S, sr, variant=args.variant, workspace=ws)
         if timed:
             a1.record(); ev["fwd"].append((a0, a1))
         if want_tf:
@@ -121,7 +123,7 @@ def main():
                 b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 b0.record()
             dv, dt = F.march_bwd(vol, tf, cam, e, x, r, n, S, sr, grad_out, out, want_vol=want_vol, want_tf=True,
-                                 variant=args.variant)
+                                 variant=args.variant, workspace=ws)
             if timed:
                 b1.record(); ev["bwd"].append((b0, b1))
             if world > 1:
@@ -189,6 +191,7 @@ def main():
                        "passes_per_voxel_step": passes, "kernel_variant": args.variant},
             "voxel_steps_per_step": int(vsteps / max(args.steps, 1)),
             "roofline": dominant, "roofline_fwd": roof_fwd, "roofline_bwd": roof_bwd,
+            "rays_marched_individually": (int(F.workspace_stats(ws)[0]) if ws is not None else None),
             "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(line))

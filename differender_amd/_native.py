@@ -13,17 +13,18 @@ DR_MODE_DIFF, DR_MODE_NONDIFF = 0, 1
 DR_VARIANT_AUTO, DR_VARIANT_BASELINE = 0, 1
 
 _c = ctypes
-_P, _I, _L, _F, _D, _U = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_double, _c.c_uint32
+_P, _I, _L, _F, _D, _U, _Z = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_double, _c.c_uint32, _c.c_size_t
 
 # name -> (restype, argtypes); must list every symbol the header declares (tests/test_abi.py checks)
 SIGNATURES = {
     "dr_abi_version": (_I, []),
     "dr_error_string": (_c.c_char_p, [_I]),
     "dr_ray_setup": (_I, [_P, _I, _I, _I, _I, _I, _I, _D, _D, _F, _U, _U, _P, _P, _P, _P, _P]),
+    "dr_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I, _I]),
     "dr_march_fwd": (_I, [_P, _I, _I, _I, _I, _L, _L, _L, _L, _P, _I, _L, _P, _P, _P, _P, _P,
-                          _I, _I, _I, _I, _F, _I, _I, _P, _P, _P]),
+                          _I, _I, _I, _I, _F, _D, _D, _I, _I, _P, _P, _P, _Z, _P]),
     "dr_march_bwd": (_I, [_P, _I, _I, _I, _I, _L, _L, _L, _L, _P, _I, _L, _P, _P, _P, _P, _P,
-                          _I, _I, _I, _I, _F, _I, _P, _P, _P, _L, _L, _L, _L, _P, _L, _P]),
+                          _I, _I, _I, _I, _F, _D, _D, _I, _P, _P, _P, _L, _L, _L, _L, _P, _L, _P, _Z, _P]),
 }
 
 _lib = None
@@ -42,7 +43,7 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.dr_abi_version() != 1:
+        if handle.dr_abi_version() != 2:
             raise ImportError("libdifferender_hip.so ABI version mismatch; rebuild it")
         _lib = handle
     return _lib

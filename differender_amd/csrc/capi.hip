@@ -22,6 +22,12 @@ const char *dr_error_string(int code) {
     return "differender_hip: unknown error";
 }
 
+size_t dr_workspace_bytes(int n_views, int W, int H, int VX, int VY, int VZ, int R) {
+    if (n_views <= 0 || W <= 0 || H <= 0 || VX < 2 || VY < 2 || VZ < 2 || R < 1) return 0;
+    if (!brick_path_supported(VX, VY, VZ, R)) return 0;
+    return brick_workspace_bytes(n_views, W, H, VX, VY, VZ);
+}
+
 int dr_ray_setup(const float *cam, int n_views, int W, int H, int VX, int VY, int VZ, double fov_rad,
                  double near_plane, float sampling_rate, uint32_t jitter_seed, uint32_t view_base, float *entry,
                  float *exit_, float *rays, int32_t *nsamp, void *stream) {
@@ -53,8 +59,8 @@ static int fill_common(MarchArgs &a, const void *vol, int vol_dtype, int VX, int
 int dr_march_fwd(const void *vol, int vol_dtype, int VX, int VY, int VZ, int64_t sx, int64_t sy, int64_t sz,
                  int64_t vol_view_stride, const float *tf, int R, int64_t tf_view_stride, const float *cam,
                  const float *entry, const float *exit_, const float *rays, const int32_t *nsamp, int n_views, int W,
-                 int H, int max_samples, float sampling_rate, int mode, int variant, float *out_rgba, int32_t *steps,
-                 void *stream) {
+                 int H, int max_samples, float sampling_rate, double fov_rad, double near_plane, int mode, int variant,
+                 float *out_rgba, int32_t *steps, void *workspace, size_t workspace_bytes, void *stream) {
     MarchArgs a;
     int rc = fill_common(a, vol, vol_dtype, VX, VY, VZ, sx, sy, sz, vol_view_stride, tf, R, tf_view_stride, cam,
                          entry, exit_, rays, nsamp, n_views, W, H, max_samples, sampling_rate);
@@ -63,15 +69,21 @@ int dr_march_fwd(const void *vol, int vol_dtype, int VX, int VY, int VZ, int64_t
     if (mode != DR_MODE_DIFF && mode != DR_MODE_NONDIFF) return DR_EINVAL;
     if (variant != DR_VARIANT_AUTO && variant != DR_VARIANT_BASELINE) return DR_EINVAL;
     a.mode = mode; a.out = out_rgba; a.steps = steps;
+    a.fov_rad = fov_rad; a.near_plane = near_plane; a.workspace = workspace; a.workspace_bytes = workspace_bytes;
+    if (variant == DR_VARIANT_AUTO && workspace && brick_path_supported(VX, VY, VZ, R)) {
+        if (workspace_bytes < brick_workspace_bytes(n_views, W, H, VX, VY, VZ)) return DR_EINVAL;
+        return launch_march_fwd_brick(a, (hipStream_t)stream);
+    }
     return launch_march_fwd_baseline(a, (hipStream_t)stream);
 }
 
 int dr_march_bwd(const void *vol, int vol_dtype, int VX, int VY, int VZ, int64_t sx, int64_t sy, int64_t sz,
                  int64_t vol_view_stride, const float *tf, int R, int64_t tf_view_stride, const float *cam,
                  const float *entry, const float *exit_, const float *rays, const int32_t *nsamp, int n_views, int W,
-                 int H, int max_samples, float sampling_rate, int variant, const float *grad_out,
-                 const float *out_rgba, float *d_vol, int64_t dsx, int64_t dsy, int64_t dsz,
-                 int64_t dvol_view_stride, float *d_tf, int64_t dtf_view_stride, void *stream) {
+                 int H, int max_samples, float sampling_rate, double fov_rad, double near_plane, int variant,
+                 const float *grad_out, const float *out_rgba, float *d_vol, int64_t dsx, int64_t dsy, int64_t dsz,
+                 int64_t dvol_view_stride, float *d_tf, int64_t dtf_view_stride, void *workspace,
+                 size_t workspace_bytes, void *stream) {
     MarchArgs a;
     int rc = fill_common(a, vol, vol_dtype, VX, VY, VZ, sx, sy, sz, vol_view_stride, tf, R, tf_view_stride, cam,
                          entry, exit_, rays, nsamp, n_views, W, H, max_samples, sampling_rate);
@@ -84,6 +96,11 @@ int dr_march_bwd(const void *vol, int vol_dtype, int VX, int VY, int VZ, int64_t
     a.grad_out = grad_out; a.out_fwd = out_rgba;
     a.d_vol = d_vol; a.dsx = dsx; a.dsy = dsy; a.dsz = dsz; a.dvol_vs = dvol_view_stride;
     a.d_tf = d_tf; a.dtf_vs = dtf_view_stride;
+    a.fov_rad = fov_rad; a.near_plane = near_plane; a.workspace = workspace; a.workspace_bytes = workspace_bytes;
+    if (variant == DR_VARIANT_AUTO && workspace && brick_path_supported(VX, VY, VZ, R)) {
+        if (workspace_bytes < brick_workspace_bytes(n_views, W, H, VX, VY, VZ)) return DR_EINVAL;
+        return launch_march_bwd_brick(a, (hipStream_t)stream);
+    }
     return launch_march_bwd_baseline(a, (hipStream_t)stream);
 }
 

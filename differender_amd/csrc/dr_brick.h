@@ -1,0 +1,67 @@
+// dr_brick.h -- geometry shared by the brick-centric march kernels (march_brick.hip).
+//
+// The volume's cells (one cell = the unit cube between 8 voxels, indexed by the low voxel) are grouped
+// into bricks of BRK^3 cells. A sample belongs to the brick that holds the cell of its centre tap; the
+// six normal taps sit 1e-3 world units away (VR.py:193), which is < 1 voxel whenever max(dim)-1 < 2000,
+// so they touch at most the neighbouring cell: the LDS box of a brick is BRK+3 voxels wide
+// (one voxel below, two above).
+//
+// Layer of a brick = Manhattan distance (in bricks) from the brick that holds the camera. Along any ray
+// the per-axis coordinates move monotonically away from the camera, so the bricks a ray visits have
+// strictly increasing layers: per-(ray, layer) partial composites can be combined front to back without
+// knowing which brick produced them.
+#pragma once
+#include "dr_device.h"
+
+namespace dr {
+
+constexpr int BRK = 16;                    // cells per brick edge
+constexpr int BOX = BRK + 3;               // voxels per LDS box edge
+constexpr int BOX_SY = BOX;                // LDS strides (z fastest); 19 and 361 are odd -> lanes that walk
+constexpr int BOX_SX = BOX * BOX;          // along any axis spread over the 32 LDS banks
+constexpr int BOX_N = BOX * BOX * BOX;     // 6859 floats = 27.4 KB
+constexpr int ECHUNK = 512;                // ray segments listed per round
+constexpr float BRICK_EPS = 2e-4f;         // world-space slack of the conservative ray/brick tests
+
+struct BrickGrid {
+    int NBx, NBy, NBz, NL;  // bricks per axis, number of layers (NBx+NBy+NBz-2)
+};
+
+__host__ __device__ inline BrickGrid make_brick_grid(int VX, int VY, int VZ) {
+    BrickGrid g;
+    g.NBx = (VX - 1 + BRK - 1) / BRK; g.NBy = (VY - 1 + BRK - 1) / BRK; g.NBz = (VZ - 1 + BRK - 1) / BRK;
+    g.NL = g.NBx + g.NBy + g.NBz - 2;
+    return g;
+}
+
+// The canonical per-axis coordinate of VR.py:163-168 (must stay bit-identical everywhere it is used:
+// it decides which brick owns a sample).
+__device__ __forceinline__ void axis_coord(float pos, float sc, int &cell, float &fr) {
+    float q = fminf(1.0f, fmaxf(0.0f, fmaf(0.5f, pos, 0.5f))) * sc;
+    float low = floorf(q);
+    fr = q - low;
+    cell = (int)low;
+}
+
+// brick coordinate of the camera along one axis (unclamped linear map, may be negative or >= NB)
+__device__ __forceinline__ int cam_brick(float cam, float sc) {
+    return (int)floorf(fmaf(0.5f, cam, 0.5f) * sc * (1.0f / BRK));
+}
+__device__ __forceinline__ int axis_layer_min(int cb, int NB) { return cb < 0 ? -cb : (cb > NB - 1 ? cb - (NB - 1) : 0); }
+
+// A ray is "regular" when the brick pipeline may handle it; the others (degenerate single-sample rays,
+// camera inside the box) are marched whole by the per-ray pass. Must be evaluated identically in every pass.
+__device__ __forceinline__ bool ray_is_regular(int n, float entry) { return n >= 2 && entry >= 0.0f; }
+
+// trilinear tap from the LDS box; identical arithmetic to tri_sample (x -> y -> z lerps)
+__device__ __forceinline__ float tri_lds(const float *box, int base, float fx, float fy, float fz) {
+    float a = mixf(box[base], box[base + BOX_SX], fx);
+    float b = mixf(box[base + BOX_SY], box[base + BOX_SX + BOX_SY], fx);
+    float zl = mixf(a, b, fy);
+    a = mixf(box[base + 1], box[base + BOX_SX + 1], fx);
+    b = mixf(box[base + BOX_SY + 1], box[base + BOX_SX + BOX_SY + 1], fx);
+    float zh = mixf(a, b, fy);
+    return mixf(zl, zh, fz);
+}
+
+}  // namespace dr

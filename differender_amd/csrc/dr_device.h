@@ -149,11 +149,8 @@ __device__ __forceinline__ void sample_pos(const RayGeom &rg, float cx, float cy
     px = fmaf(t, rg.vx, cx); py = fmaf(t, rg.vy, cy); pz = fmaf(t, rg.vz, cz);
 }
 
-// VR.py:205-219 + 284-285. tf is a [R][4] table (LDS or global).
-template <typename VT>
-__device__ __forceinline__ void classify(const VolView<VT> &v, const float4 *tf, int R, float tf_len, float inv_sr,
-                                         Sample &sm) {
-    sm.I = tri_sample(v, sm.px, sm.py, sm.pz);
+// VR.py:205-219 + 284-285. tf is a [R][4] table (LDS or global). sm.I must be set.
+__device__ __forceinline__ void classify_from_I(const float4 *tf, int R, float tf_len, float inv_sr, Sample &sm) {
     sm.xtf = sm.I * tf_len;
     low_high_frac(sm.xtf, sm.lo, sm.fr);
     sm.lo = min(sm.lo, R - 1);  // defined-domain guard for I > 1 (reference reads out of bounds)
@@ -164,14 +161,17 @@ __device__ __forceinline__ void classify(const VolView<VT> &v, const float4 *tf,
     float base = 1.0f - sm.a;
     sm.op = 1.0f - ((inv_sr == 1.0f) ? base : powf(base, inv_sr));
 }
-
-// VR.py:191-203 normal, :287-299 Phong. clampL: the differentiable path clamps lighting (VR.py:298).
 template <typename VT>
-__device__ __forceinline__ void shade(const VolView<VT> &v, f3 light_pos, f3 vd, bool clampL, Sample &sm) {
-    const float delta = 1e-3f;
-    float dx = tri_sample(v, sm.px + delta, sm.py, sm.pz) - tri_sample(v, sm.px - delta, sm.py, sm.pz);
-    float dy = tri_sample(v, sm.px, sm.py + delta, sm.pz) - tri_sample(v, sm.px, sm.py - delta, sm.pz);
-    float dz = tri_sample(v, sm.px, sm.py, sm.pz + delta) - tri_sample(v, sm.px, sm.py, sm.pz - delta);
+__device__ __forceinline__ void classify(const VolView<VT> &v, const float4 *tf, int R, float tf_len, float inv_sr,
+                                         Sample &sm) {
+    sm.I = tri_sample(v, sm.px, sm.py, sm.pz);
+    classify_from_I(tf, R, tf_len, inv_sr, sm);
+}
+
+// VR.py:191-203 normal, :287-299 Phong, given the central differences (dx,dy,dz) of the six normal taps.
+// clampL: the differentiable path clamps lighting (VR.py:298).
+__device__ __forceinline__ void shade_from_grad(float dx, float dy, float dz, f3 light_pos, f3 vd, bool clampL,
+                                                Sample &sm) {
     sm.grad = make_f3(dx, dy, dz);
     sm.gnorm = sqrtf(dot3(sm.grad, sm.grad));
     sm.flat = !(sm.gnorm > 0.0f);
@@ -193,6 +193,59 @@ __device__ __forceinline__ void shade(const VolView<VT> &v, f3 light_pos, f3 vd,
     sm.spec = 0.3f * pow32(sm.rdv);
     sm.Lraw = fmaf(0.8f, sm.ndl, sm.spec) + 0.4f;
     sm.L = clampL ? fminf(1.0f, sm.Lraw) : sm.Lraw;
+}
+template <typename VT>
+__device__ __forceinline__ void shade(const VolView<VT> &v, f3 light_pos, f3 vd, bool clampL, Sample &sm) {
+    const float delta = 1e-3f;
+    float dx = tri_sample(v, sm.px + delta, sm.py, sm.pz) - tri_sample(v, sm.px - delta, sm.py, sm.pz);
+    float dy = tri_sample(v, sm.px, sm.py + delta, sm.pz) - tri_sample(v, sm.px, sm.py - delta, sm.pz);
+    float dz = tri_sample(v, sm.px, sm.py, sm.pz + delta) - tri_sample(v, sm.px, sm.py, sm.pz - delta);
+    shade_from_grad(dx, dy, dz, light_pos, vd, clampL, sm);
+}
+
+// Adjoint of one composited sample: everything downstream of the taps.
+// Inputs: the shaded sample, T = 1 - A_before, suffix = gC.(C_final - C_after) + gA.(A_final - A_after)
+// (0 for the last live sample), upstream gradient go. Outputs the adjoints of the TF sample (r,g,b,a),
+// of the intensity tap (I_bar, needs tf slope) and of the central differences (gx,gy,gz).
+struct SampleAdj {
+    float r_bar, g_bar, b_bar, a_bar;  // d/d(tf colour, tf alpha) of this sample
+    float gx, gy, gz;                   // d/d(dx,dy,dz); 0 when the normal is flat
+};
+__device__ __forceinline__ void sample_adjoint(const Sample &sm, f3 vd, float T, float suffix, bool last, float4 go,
+                                               float inv_sr, SampleAdj &ad) {
+    const float rgbdot = go.x * sm.r + go.y * sm.g + go.z * sm.b;  // gC . rgb
+    const float qs = sm.L * rgbdot + go.w;
+    const float op_bar = T * qs - (last ? 0.0f : suffix / (1.0f - sm.op));
+    const float Lop = sm.L * sm.op * T;
+    ad.r_bar = Lop * go.x; ad.g_bar = Lop * go.y; ad.b_bar = Lop * go.z;
+    const float L_bar = sm.op * T * rgbdot;
+    const float Lraw_bar = (1.0f < sm.Lraw) ? 0.0f : L_bar;
+    const float base = 1.0f - sm.a;
+    ad.a_bar = op_bar * ((inv_sr == 1.0f) ? 1.0f : inv_sr * powf(base, inv_sr - 1.0f));
+    if (sm.flat) {
+        ad.gx = ad.gy = ad.gz = 0.0f;  // deviation D1: the reference injects NaN here
+        return;
+    }
+    const float ndl_bar = 0.8f * Lraw_bar;
+    const float rdv_bar = 0.3f * 32.0f * pow31(sm.rdv) * Lraw_bar;
+    const float q_bar = (0.0f < sm.q) ? rdv_bar : 0.0f;
+    const f3 rf_bar = make_f3(-vd.x * q_bar, -vd.y * q_bar, -vd.z * q_bar);
+    const float m_bar = ((0.0f < sm.m) ? ndl_bar : 0.0f) - 2.0f * dot3(sm.nrm, rf_bar);
+    const float m2 = -2.0f * sm.m;
+    const f3 n_bar = make_f3(m2 * rf_bar.x + m_bar * sm.ld.x, m2 * rf_bar.y + m_bar * sm.ld.y,
+                             m2 * rf_bar.z + m_bar * sm.ld.z);
+    const float nn = dot3(sm.nrm, n_bar);
+    const float inv = 1.0f / sm.gnorm;
+    ad.gx = inv * (n_bar.x - sm.nrm.x * nn);
+    ad.gy = inv * (n_bar.y - sm.nrm.y * nn);
+    ad.gz = inv * (n_bar.z - sm.nrm.z * nn);
+}
+// adjoint of the intensity tap given the TF texels around it
+__device__ __forceinline__ float intensity_adjoint(const Sample &sm, float4 t0, float4 t1, const SampleAdj &ad,
+                                                   float tf_len) {
+    const float fr_bar = (t1.x - t0.x) * ad.r_bar + (t1.y - t0.y) * ad.g_bar + (t1.z - t0.z) * ad.b_bar +
+                         (t1.w - t0.w) * ad.a_bar;
+    return (0.0f < sm.xtf) ? fr_bar * tf_len : 0.0f;
 }
 
 }  // namespace dr

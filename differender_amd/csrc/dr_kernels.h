@@ -16,6 +16,10 @@ struct MarchArgs {
     const float *grad_out; const float *out_fwd;
     float *d_vol; int64_t dsx, dsy, dsz, dvol_vs;
     float *d_tf; int64_t dtf_vs;
+    // brick path
+    double fov_rad, near_plane;
+    void *workspace; size_t workspace_bytes;
+    const uint8_t *only_flagged;  // baseline backward: restrict to rays with a non-zero flag (may be null)
 };
 
 hipError_t launch_ray_setup(const float *cam, int n_views, int W, int H, int VX, int VY, int VZ, double fov_rad,
@@ -25,5 +29,11 @@ hipError_t launch_ray_setup(const float *cam, int n_views, int W, int H, int VX,
 // Plain one-lane-per-ray kernels (DR_VARIANT_BASELINE): direct global gathers, global float atomics.
 int launch_march_fwd_baseline(const MarchArgs &a, hipStream_t stream);
 int launch_march_bwd_baseline(const MarchArgs &a, hipStream_t stream);
+
+// Brick-centric kernels (DR_VARIANT_AUTO): LDS-staged bricks, per-(ray,layer) partial composites.
+bool brick_path_supported(int VX, int VY, int VZ, int R);
+size_t brick_workspace_bytes(int n_views, int W, int H, int VX, int VY, int VZ);
+int launch_march_fwd_brick(const MarchArgs &a, hipStream_t stream);
+int launch_march_bwd_brick(const MarchArgs &a, hipStream_t stream);
 
 }  // namespace dr

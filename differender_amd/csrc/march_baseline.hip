@@ -5,8 +5,8 @@
 //
 // Forward   : VR.py:261-306 (raycast) + 363-372 (get_final_image); nondiff: VR.py:308-361.
 // Backward  : tape-free equivalent of raycast.grad/get_final_image.grad (VR.py:460-461,470-471).
-//   With T_s = 1 - A_{s-1}, q_s = gC.(L_s rgb_s) + gA and P_s = sum_{k<=s} T_k op_k q_k the adjoint of
-//   the sample opacity is  d/d op_s = T_s q_s - (Total - P_s) / (1 - op_s),  Total = gC.C_final + gA.A_final,
+//   With T_s = 1 - A_{s-1} and q_s = gC.(L_s rgb_s) + gA the adjoint of the sample opacity is
+//   d/d op_s = T_s q_s - [gC.(C_final - C_s) + gA.(A_final - A_s)] / (1 - op_s)   (C_s, A_s = composite up to s),
 //   which needs only a forward-order walk and the saved forward output (no per-sample tape).
 #include "dr_device.h"
 #include "dr_kernels.h"
@@ -24,6 +24,7 @@ struct MarchParams {
     const float *grad_out, *out_fwd;
     GradView dvol; int64_t dvol_vs;
     float *d_tf; int64_t dtf_vs;
+    const uint8_t *only_flagged;
 };
 
 __device__ __forceinline__ bool tile_pixel(int W, int H, int &i, int &j) {
@@ -94,7 +95,8 @@ __global__ __launch_bounds__(256) void march_bwd_baseline_kernel(MarchParams<VT>
     __syncthreads();
 
     int i, j;
-    const bool active = tile_pixel(P.W, P.H, i, j);
+    bool active = tile_pixel(P.W, P.H, i, j);
+    if (active && P.only_flagged) active = P.only_flagged[((size_t)view * P.W + i) * P.H + j] != 0;
     if (active) {
         const size_t p = ((size_t)view * P.W + i) * P.H + j;
         VolView<VT> vol = P.vol;
@@ -115,10 +117,9 @@ __global__ __launch_bounds__(256) void march_bwd_baseline_kernel(MarchParams<VT>
 
         const float4 go = reinterpret_cast<const float4 *>(P.grad_out)[p];
         const float4 of = reinterpret_cast<const float4 *>(P.out_fwd)[p];
-        const float total = (go.x * of.x + go.y * of.y + go.z * of.z) + go.w * of.w;
         const float delta = 1e-3f;
 
-        float A = 0.f, Pfx = 0.f;
+        float C0 = 0.f, C1 = 0.f, C2 = 0.f, A = 0.f;
         for (int s = 0; s < nmarch; ++s) {
             if (!(A < 0.99f)) break;
             Sample sm;
@@ -126,55 +127,34 @@ __global__ __launch_bounds__(256) void march_bwd_baseline_kernel(MarchParams<VT>
             classify(vol, lds_tf, P.R, P.tf_len, P.inv_sr, sm);
             shade(vol, light, vd, true, sm);
             const float T = 1.0f - A;
-            const float A_next = fmaf(T, sm.op, A);
-            const bool last = (s == nmarch - 1) || !(A_next < 0.99f);
-            const float rgbdot = go.x * sm.r + go.y * sm.g + go.z * sm.b;  // gC . rgb
-            const float qs = sm.L * rgbdot + go.w;
-            Pfx += T * sm.op * qs;
-            const float suffix = last ? 0.0f : (total - Pfx) / (1.0f - sm.op);
-            const float op_bar = T * qs - suffix;
-            const float Lop = sm.L * sm.op * T;
-            const float r_bar = Lop * go.x, g_bar = Lop * go.y, b_bar = Lop * go.z;
-            const float L_bar = sm.op * T * rgbdot;
-            const float Lraw_bar = (1.0f < sm.Lraw) ? 0.0f : L_bar;
-            const float base = 1.0f - sm.a;
-            const float a_bar = op_bar * ((P.inv_sr == 1.0f) ? 1.0f : P.inv_sr * powf(base, P.inv_sr - 1.0f));
-            A = A_next;
+            C0 = fmaf(T, sm.L * sm.r * sm.op, C0);
+            C1 = fmaf(T, sm.L * sm.g * sm.op, C1);
+            C2 = fmaf(T, sm.L * sm.b * sm.op, C2);
+            A = fmaf(T, sm.op, A);
+            const bool last = (s == nmarch - 1) || !(A < 0.99f);
+            // what the samples after s contribute to the loss: gC.(C_final - C_s) + gA.(A_final - A_s)
+            const float suffix = (go.x * (of.x - C0) + go.y * (of.y - C1) + go.z * (of.z - C2)) + go.w * (of.w - A);
+            SampleAdj ad;
+            sample_adjoint(sm, vd, T, suffix, last, go, P.inv_sr, ad);
 
             if (want_tf) {
                 const float w0 = 1.0f - sm.fr, w1 = sm.fr;
                 float *d0 = lds_dtf + 4 * sm.lo, *d1 = lds_dtf + 4 * sm.hi;
-                atomicAdd(d0 + 0, w0 * r_bar); atomicAdd(d0 + 1, w0 * g_bar);
-                atomicAdd(d0 + 2, w0 * b_bar); atomicAdd(d0 + 3, w0 * a_bar);
-                atomicAdd(d1 + 0, w1 * r_bar); atomicAdd(d1 + 1, w1 * g_bar);
-                atomicAdd(d1 + 2, w1 * b_bar); atomicAdd(d1 + 3, w1 * a_bar);
+                atomicAdd(d0 + 0, w0 * ad.r_bar); atomicAdd(d0 + 1, w0 * ad.g_bar);
+                atomicAdd(d0 + 2, w0 * ad.b_bar); atomicAdd(d0 + 3, w0 * ad.a_bar);
+                atomicAdd(d1 + 0, w1 * ad.r_bar); atomicAdd(d1 + 1, w1 * ad.g_bar);
+                atomicAdd(d1 + 2, w1 * ad.b_bar); atomicAdd(d1 + 3, w1 * ad.a_bar);
             }
             if (want_vol) {
-                const float4 t0 = lds_tf[sm.lo], t1 = lds_tf[sm.hi];
-                const float fr_bar =
-                    (t1.x - t0.x) * r_bar + (t1.y - t0.y) * g_bar + (t1.z - t0.z) * b_bar + (t1.w - t0.w) * a_bar;
-                const float I_bar = (0.0f < sm.xtf) ? fr_bar * P.tf_len : 0.0f;
+                const float I_bar = intensity_adjoint(sm, lds_tf[sm.lo], lds_tf[sm.hi], ad, P.tf_len);
                 tri_scatter_global(vol, dv, sm.px, sm.py, sm.pz, I_bar);
                 if (!sm.flat) {
-                    const float ndl_bar = 0.8f * Lraw_bar;
-                    const float rdv_bar = 0.3f * 32.0f * pow31(sm.rdv) * Lraw_bar;
-                    const float q_bar = (0.0f < sm.q) ? rdv_bar : 0.0f;
-                    const f3 rf_bar = make_f3(-vd.x * q_bar, -vd.y * q_bar, -vd.z * q_bar);
-                    const float m_bar = ((0.0f < sm.m) ? ndl_bar : 0.0f) - 2.0f * dot3(sm.nrm, rf_bar);
-                    const float m2 = -2.0f * sm.m;
-                    const f3 n_bar = make_f3(m2 * rf_bar.x + m_bar * sm.ld.x, m2 * rf_bar.y + m_bar * sm.ld.y,
-                                             m2 * rf_bar.z + m_bar * sm.ld.z);
-                    const float nn = dot3(sm.nrm, n_bar);
-                    const float inv = 1.0f / sm.gnorm;
-                    const float gx = inv * (n_bar.x - sm.nrm.x * nn);
-                    const float gy = inv * (n_bar.y - sm.nrm.y * nn);
-                    const float gz = inv * (n_bar.z - sm.nrm.z * nn);
-                    tri_scatter_global(vol, dv, sm.px + delta, sm.py, sm.pz, gx);
-                    tri_scatter_global(vol, dv, sm.px - delta, sm.py, sm.pz, -gx);
-                    tri_scatter_global(vol, dv, sm.px, sm.py + delta, sm.pz, gy);
-                    tri_scatter_global(vol, dv, sm.px, sm.py - delta, sm.pz, -gy);
-                    tri_scatter_global(vol, dv, sm.px, sm.py, sm.pz + delta, gz);
-                    tri_scatter_global(vol, dv, sm.px, sm.py, sm.pz - delta, -gz);
+                    tri_scatter_global(vol, dv, sm.px + delta, sm.py, sm.pz, ad.gx);
+                    tri_scatter_global(vol, dv, sm.px - delta, sm.py, sm.pz, -ad.gx);
+                    tri_scatter_global(vol, dv, sm.px, sm.py + delta, sm.pz, ad.gy);
+                    tri_scatter_global(vol, dv, sm.px, sm.py - delta, sm.pz, -ad.gy);
+                    tri_scatter_global(vol, dv, sm.px, sm.py, sm.pz + delta, ad.gz);
+                    tri_scatter_global(vol, dv, sm.px, sm.py, sm.pz - delta, -ad.gz);
                 }
             }
         }
@@ -206,6 +186,7 @@ static MarchParams<VT> make_params(const MarchArgs &a) {
     P.grad_out = a.grad_out; P.out_fwd = a.out_fwd;
     P.dvol.p = a.d_vol; P.dvol.sx = a.dsx; P.dvol.sy = a.dsy; P.dvol.sz = a.dsz; P.dvol_vs = a.dvol_vs;
     P.d_tf = a.d_tf; P.dtf_vs = a.dtf_vs / 4;
+    P.only_flagged = a.only_flagged;
     return P;
 }
 

@@ -1,0 +1,668 @@
+// march_brick.hip -- brick-centric march kernels for gfx950 (DR_VARIANT_AUTO fast path).
+//
+// Why: one marched sample needs 56 voxel fetches (7 trilinear taps, VR.py:153-203). Served as global
+// gathers they cost >= 25 cycles per wave-load on a CU (measured, tools/microbench); from LDS they cost
+// 2-6. So the volume is processed brick by brick: a workgroup stages one 16^3-cell brick (+apron, 19^3
+// voxels, 27 KB) in LDS with coalesced reads and marches every ray segment that crosses it.
+//
+//   F1 brick_fwd_kernel   per (brick, view): LDS box + TF; list the ray segments inside the brick, sort
+//                         them by length (so the 64 lanes of a wave run segments of equal length), march
+//                         them from LDS, write one partial RGBA + sample count per (ray, layer).
+//   F2 ray_compose_kernel per ray: composite the partials front to back ("over" is associative); the one
+//                         segment in which alpha crosses 0.99 is re-marched sample by sample so early
+//                         termination stays exact (VR.py:267); irregular rays are marched whole.
+//                         Leaves the prefix (C,A) before every segment in the workspace for the backward.
+//   B1 brick_bwd_kernel   per (brick, view): recompute the segment from the stored prefix, scatter-add
+//                         d_volume into an LDS box and d_tf into an LDS table, flush each once with
+//                         global float atomics (one coalesced flush per brick instead of 56 atomics/sample).
+//   B2                    irregular rays: the baseline backward restricted to flagged rays.
+//
+// Reference functions replaced: raycast / raycast_nondiff / get_final_image[_nondiff] (VR.py:261-372) and
+// their Taichi-autodiff twins (VR.py:460-461,470-471).
+#include "dr_brick.h"
+#include "dr_kernels.h"
+#include "../../include/differender_hip.h"
+
+namespace dr {
+
+template <typename VT>
+struct BrickParams {
+    VolView<VT> vol; int64_t vol_vs;
+    const float4 *tf; int64_t tf_vs; int R; float tf_len;
+    const float *cam, *entry, *exit_, *rays; const int32_t *nsamp;
+    int W, H, S; float sr, inv_sr;
+    float near_, near_w, near_h;
+    BrickGrid g;
+    float4 *seg_rgba;    // [view][NL][NP]: F1 partial composite, then (F2) prefix before the segment
+    int32_t *seg_cnt;    // [view][NL][NP]: samples of the ray inside the brick of that layer
+    uint8_t *rayflag;    // [view][NP]: 1 = irregular ray (marched whole by F2 / B2)
+    int32_t *ws_steps;   // [view][NP]: live samples per ray (F2 -> B1)
+    unsigned int *stats; // [0] rays repaired by the count check
+    float *out; int32_t *steps;
+    const float *grad_out, *out_fwd;
+    GradView dvol; int64_t dvol_vs;
+    float *d_tf; int64_t dtf_vs;
+};
+
+struct BrickCtx {
+    int bx, by, bz, layer;
+    int ox, oy, oz;               // voxel index of LDS box element 0 along each axis (16*b - 1)
+    float lo[3], hi[3];           // world AABB of the brick's cells, with slack
+    int i0, i1, j0, j1;           // candidate pixel rectangle (inclusive); empty if i0 > i1
+};
+
+__device__ __forceinline__ f3 cross3b(f3 a, f3 b) {
+    return make_f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+
+// Brick geometry + its projected pixel rectangle (pinhole model of VR.py:127-151).
+template <typename VT>
+__device__ __forceinline__ void brick_setup(const BrickParams<VT> &P, int b, f3 cam, BrickCtx &c) {
+    const BrickGrid &g = P.g;
+    c.bz = b % g.NBz; c.by = (b / g.NBz) % g.NBy; c.bx = b / (g.NBz * g.NBy);
+    c.ox = c.bx * BRK - 1; c.oy = c.by * BRK - 1; c.oz = c.bz * BRK - 1;
+    const int cbx = cam_brick(cam.x, P.vol.scx), cby = cam_brick(cam.y, P.vol.scy), cbz = cam_brick(cam.z, P.vol.scz);
+    const int lmin = axis_layer_min(cbx, g.NBx) + axis_layer_min(cby, g.NBy) + axis_layer_min(cbz, g.NBz);
+    c.layer = abs(c.bx - cbx) + abs(c.by - cby) + abs(c.bz - cbz) - lmin;
+    const int bb[3] = {c.bx, c.by, c.bz};
+    const int nb[3] = {g.NBx, g.NBy, g.NBz};
+    const float sc[3] = {P.vol.scx, P.vol.scy, P.vol.scz};
+    for (int k = 0; k < 3; ++k) {
+        // cell range [16b, 16b+16) in scaled coordinates q = (0.5 x + 0.5) sc  ->  x = 2 q / sc - 1
+        float lo = 2.0f * (float)(bb[k] * BRK) / sc[k] - 1.0f;
+        float hi = 2.0f * (float)(bb[k] * BRK + BRK) / sc[k] - 1.0f;
+        if (bb[k] == 0) lo = -1.0f;          // positions are clamped into the edge cells
+        if (bb[k] == nb[k] - 1) hi = 1.0f;
+        c.lo[k] = lo - BRICK_EPS; c.hi[k] = hi + BRICK_EPS;
+    }
+    const f3 vdir = normalized3(make_f3(-cam.x, -cam.y, -cam.z));
+    const f3 right = normalized3(cross3b(vdir, make_f3(0.f, 1.f, 0.f)));
+    const f3 up = normalized3(cross3b(right, vdir));
+    float pxmin = 1e30f, pxmax = -1e30f, pymin = 1e30f, pymax = -1e30f;
+    bool behind = false;
+    for (int k = 0; k < 8; ++k) {
+        const f3 d = make_f3(((k & 1) ? c.hi[0] : c.lo[0]) - cam.x, ((k & 2) ? c.hi[1] : c.lo[1]) - cam.y,
+                             ((k & 4) ? c.hi[2] : c.lo[2]) - cam.z);
+        const float depth = dot3(d, vdir);
+        if (!(depth > 1e-3f)) { behind = true; continue; }
+        const float u = dot3(d, right) / depth * (P.near_ / P.near_w);
+        const float v = dot3(d, up) / depth * (P.near_ / P.near_h);
+        const float px = (u + 0.5f) * (float)P.W - 0.5f, py = (v + 0.5f) * (float)P.H - 0.5f;
+        pxmin = fminf(pxmin, px); pxmax = fmaxf(pxmax, px); pymin = fminf(pymin, py); pymax = fmaxf(pymax, py);
+    }
+    if (behind) { c.i0 = 0; c.i1 = P.W - 1; c.j0 = 0; c.j1 = P.H - 1; return; }
+    pxmin = fmaxf(pxmin, -2.0f); pymin = fmaxf(pymin, -2.0f);
+    pxmax = fminf(pxmax, (float)P.W + 2.0f); pymax = fminf(pymax, (float)P.H + 2.0f);
+    c.i0 = max(0, (int)floorf(pxmin) - 1); c.i1 = min(P.W - 1, (int)ceilf(pxmax) + 1);
+    c.j0 = max(0, (int)floorf(pymin) - 1); c.j1 = min(P.H - 1, (int)ceilf(pymax) + 1);
+}
+
+// Conservative sample-index range [s0, s1) of ray p inside the brick (exact membership is decided per
+// sample from its cell). Returns false when the ray cannot touch the brick.
+__device__ __forceinline__ bool segment_range(const BrickCtx &c, f3 cam, f3 vd, float t0, float exit_, int n,
+                                              int nmarch, int &s0, int &s1) {
+    const float o[3] = {cam.x, cam.y, cam.z}, d[3] = {vd.x, vd.y, vd.z};
+    float ta = -1e30f, tb = 1e30f;
+    for (int k = 0; k < 3; ++k) {
+        if (fabsf(d[k]) < 1e-12f) {
+            if (o[k] < c.lo[k] || o[k] > c.hi[k]) return false;
+        } else {
+            const float inv = 1.0f / d[k];
+            const float t1 = (c.lo[k] - o[k]) * inv, t2 = (c.hi[k] - o[k]) * inv;
+            ta = fmaxf(ta, fminf(t1, t2)); tb = fminf(tb, fmaxf(t1, t2));
+        }
+    }
+    if (!(ta <= tb)) return false;
+    const float scale = (float)(n - 1) / (exit_ - t0);
+    float sa = floorf((ta - t0) * scale) - 1.0f, sb = ceilf((tb - t0) * scale) + 2.0f;
+    sa = fminf(fmaxf(sa, 0.0f), (float)nmarch); sb = fminf(fmaxf(sb, 0.0f), (float)nmarch);
+    s0 = (int)sa; s1 = (int)sb;
+    return s1 > s0;
+}
+
+struct LdsLayout {
+    float4 *tf; float *box; float *dbox; float *dtf;
+    int *e_pix, *e_s0, *e_cnt; unsigned short *order; int *hist; int *misc;
+};
+__host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t brick_lds_bytes(int R, bool bwd_vol, bool bwd_tf) {
+    size_t s = (size_t)R * 16 + align16(BOX_N * 4);
+    if (bwd_vol) s += align16(BOX_N * 4);
+    if (bwd_tf) s += (size_t)R * 16;
+    s += 3 * ECHUNK * 4 + ECHUNK * 2 + 128 * 4 + 16;
+    return s;
+}
+__device__ __forceinline__ LdsLayout carve(unsigned char *smem, int R, bool bwd_vol, bool bwd_tf) {
+    LdsLayout L;
+    size_t o = 0;
+    L.tf = reinterpret_cast<float4 *>(smem + o); o += (size_t)R * 16;
+    L.box = reinterpret_cast<float *>(smem + o); o += align16(BOX_N * 4);
+    L.dbox = nullptr; L.dtf = nullptr;
+    if (bwd_vol) { L.dbox = reinterpret_cast<float *>(smem + o); o += align16(BOX_N * 4); }
+    if (bwd_tf) { L.dtf = reinterpret_cast<float *>(smem + o); o += (size_t)R * 16; }
+    L.e_pix = reinterpret_cast<int *>(smem + o); o += ECHUNK * 4;
+    L.e_s0 = reinterpret_cast<int *>(smem + o); o += ECHUNK * 4;
+    L.e_cnt = reinterpret_cast<int *>(smem + o); o += ECHUNK * 4;
+    L.order = reinterpret_cast<unsigned short *>(smem + o); o += ECHUNK * 2;
+    L.hist = reinterpret_cast<int *>(smem + o); o += 128 * 4;
+    L.misc = reinterpret_cast<int *>(smem + o);
+    return L;
+}
+
+// Stage TF and the brick's voxel box in LDS. Global reads walk the axis with the smallest stride.
+template <typename VT>
+__device__ __forceinline__ void load_tf_and_box(const BrickParams<VT> &P, const VolView<VT> &vol, const BrickCtx &c,
+                                                const float4 *tfg, LdsLayout &L) {
+    for (int k = threadIdx.x; k < P.R; k += 256) L.tf[k] = tfg[k];
+    const int fast = (vol.sx <= vol.sy && vol.sx <= vol.sz) ? 0 : ((vol.sy <= vol.sz) ? 1 : 2);
+    for (int idx = threadIdx.x; idx < BOX_N; idx += 256) {
+        const int a = idx % BOX, b = (idx / BOX) % BOX, d = idx / (BOX * BOX);
+        int lx, ly, lz;
+        if (fast == 0) { lx = a; ly = b; lz = d; } else if (fast == 1) { ly = a; lx = b; lz = d; } else { lz = a; ly = b; lx = d; }
+        const int gx = c.ox + lx, gy = c.oy + ly, gz = c.oz + lz;
+        float v = 0.0f;
+        if (gx >= 0 && gx < vol.VX && gy >= 0 && gy < vol.VY && gz >= 0 && gz < vol.VZ)
+            v = ld_voxel(vol.p + gx * vol.sx + gy * vol.sy + gz * vol.sz);
+        L.box[lx * BOX_SX + ly * BOX_SY + lz] = v;
+    }
+}
+
+// One round of segment listing: candidates [cbase, cbase+ECHUNK) of the pixel rectangle -> sorted entry list.
+// SKIPFLAG: backward skips irregular rays (flagged by F2) and clips to the live sample count.
+template <typename VT, bool BWD>
+__device__ __forceinline__ int build_entries(const BrickParams<VT> &P, const BrickCtx &c, f3 cam, int view, int cbase,
+                                             int ncand, int mode, LdsLayout &L) {
+    const int NP = P.W * P.H;
+    if (threadIdx.x < 128) L.hist[threadIdx.x] = 0;
+    if (threadIdx.x == 0) L.misc[0] = 0;
+    __syncthreads();
+    const int nj = c.j1 - c.j0 + 1;
+    const int cend = min(ncand, cbase + ECHUNK);
+    for (int cc = cbase + threadIdx.x; cc < cend; cc += 256) {
+        const int i = c.i0 + cc / nj, j = c.j0 + cc % nj;
+        const int pl = i * P.H + j;
+        const size_t p = (size_t)view * NP + pl;
+        const int n = P.nsamp[p];
+        const float entry = P.entry[p];
+        if (!ray_is_regular(n, entry)) continue;
+        int nmarch = (mode == DR_MODE_DIFF && n > P.S) ? P.S : n;
+        if (BWD) {
+            if (P.rayflag[p]) continue;
+            nmarch = min(nmarch, P.ws_steps[p]);
+        }
+        const float exit_ = P.exit_[p];
+        const f3 vd = make_f3(P.rays[3 * p], P.rays[3 * p + 1], P.rays[3 * p + 2]);
+        const float t0 = entry + 0.5f * (exit_ - entry) / (float)n;
+        int s0, s1;
+        if (!segment_range(c, cam, vd, t0, exit_, n, nmarch, s0, s1)) continue;
+        const int slot = atomicAdd(&L.misc[0], 1);
+        L.e_pix[slot] = pl; L.e_s0[slot] = s0; L.e_cnt[slot] = s1 - s0;
+        atomicAdd(&L.hist[min(s1 - s0, 127)], 1);
+    }
+    __syncthreads();
+    const int nE = L.misc[0];
+    // descending counting sort by segment length
+    int start = 0;
+    if (threadIdx.x < 128) {
+        for (int k = threadIdx.x + 1; k < 128; ++k) start += L.hist[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) L.hist[threadIdx.x] = start;
+    __syncthreads();
+    for (int e = threadIdx.x; e < nE; e += 256) {
+        const int pos = atomicAdd(&L.hist[min(L.e_cnt[e], 127)], 1);
+        L.order[pos] = (unsigned short)e;
+    }
+    __syncthreads();
+    return nE;
+}
+
+struct TapCoords {
+    int lx, ly, lz;       // local (box) cell of the centre tap
+    float fx, fy, fz;
+    int lxp, lxm, lyp, lym, lzp, lzm;  // local cells of the +-delta taps along each axis
+    float fxp, fxm, fyp, fym, fzp, fzm;
+};
+
+// All seven taps of one sample from the LDS box: intensity and central differences.
+__device__ __forceinline__ void sample_taps_lds(const float *box, const TapCoords &t, float &I, float &dx, float &dy,
+                                                float &dz) {
+    const int by = t.ly * BOX_SY, bz = t.lz, bx = t.lx * BOX_SX;
+    I = tri_lds(box, bx + by + bz, t.fx, t.fy, t.fz);
+    dx = tri_lds(box, t.lxp * BOX_SX + by + bz, t.fxp, t.fy, t.fz) - tri_lds(box, t.lxm * BOX_SX + by + bz, t.fxm, t.fy, t.fz);
+    dy = tri_lds(box, bx + t.lyp * BOX_SY + bz, t.fx, t.fyp, t.fz) - tri_lds(box, bx + t.lym * BOX_SY + bz, t.fx, t.fym, t.fz);
+    dz = tri_lds(box, bx + by + t.lzp, t.fx, t.fy, t.fzp) - tri_lds(box, bx + by + t.lzm, t.fx, t.fy, t.fzm);
+}
+
+// Position of sample s and its tap coordinates; returns whether the sample's cell lies in this brick.
+template <typename VT>
+__device__ __forceinline__ bool sample_coords(const VolView<VT> &vol, const BrickCtx &c, const RayGeom &rg, f3 cam,
+                                              int s, Sample &sm, TapCoords &t) {
+    sample_pos(rg, cam.x, cam.y, cam.z, s, sm.px, sm.py, sm.pz);
+    int x0, y0, z0;
+    axis_coord(sm.px, vol.scx, x0, t.fx);
+    axis_coord(sm.py, vol.scy, y0, t.fy);
+    axis_coord(sm.pz, vol.scz, z0, t.fz);
+    if ((x0 >> 4) != c.bx || (y0 >> 4) != c.by || (z0 >> 4) != c.bz) return false;
+    const float delta = 1e-3f;
+    int k;
+    t.lx = x0 - c.ox; t.ly = y0 - c.oy; t.lz = z0 - c.oz;
+    axis_coord(sm.px + delta, vol.scx, k, t.fxp); t.lxp = k - c.ox;
+    axis_coord(sm.px - delta, vol.scx, k, t.fxm); t.lxm = k - c.ox;
+    axis_coord(sm.py + delta, vol.scy, k, t.fyp); t.lyp = k - c.oy;
+    axis_coord(sm.py - delta, vol.scy, k, t.fym); t.lym = k - c.oy;
+    axis_coord(sm.pz + delta, vol.scz, k, t.fzp); t.lzp = k - c.oz;
+    axis_coord(sm.pz - delta, vol.scz, k, t.fzm); t.lzm = k - c.oz;
+    return true;
+}
+
+__device__ __forceinline__ void load_ray(const float *entry, const float *exit_, const float *rays, const int32_t *nsamp,
+                                         size_t p, RayGeom &rg) {
+    rg.n = nsamp[p]; rg.entry = entry[p]; rg.exit_ = exit_[p];
+    rg.vx = rays[3 * p]; rg.vy = rays[3 * p + 1]; rg.vz = rays[3 * p + 2];
+    rg.t0 = rg.entry + 0.5f * (rg.exit_ - rg.entry) / (float)rg.n;
+}
+
+// ------------------------------------------------------------------------------------------------ F1
+template <typename VT, int MODE>
+__global__ __launch_bounds__(256) void brick_fwd_kernel(BrickParams<VT> P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int view = blockIdx.y;
+    const f3 cam = make_f3(P.cam[3 * view], P.cam[3 * view + 1], P.cam[3 * view + 2]);
+    BrickCtx c;
+    brick_setup(P, blockIdx.x, cam, c);
+    if (c.i0 > c.i1 || c.j0 > c.j1) return;  // uniform: the brick projects outside the image
+
+    LdsLayout L = carve(smem, P.R, false, false);
+    VolView<VT> vol = P.vol;
+    vol.p += view * P.vol_vs;
+    load_tf_and_box(P, vol, c, P.tf + view * P.tf_vs, L);
+    const f3 light = make_f3(cam.x + 0.0f, cam.y + 1.0f, cam.z + 0.0f);
+    const int NP = P.W * P.H;
+    const size_t seg_base = ((size_t)view * P.g.NL + c.layer) * NP;
+    const int ncand = (c.i1 - c.i0 + 1) * (c.j1 - c.j0 + 1);
+
+    for (int cbase = 0; cbase < ncand; cbase += ECHUNK) {
+        const int nE = build_entries<VT, false>(P, c, cam, view, cbase, ncand, MODE, L);  // syncs inside
+        for (int e = threadIdx.x; e < nE; e += 256) {
+            const int ei = L.order[e];
+            const int pl = L.e_pix[ei], s0 = L.e_s0[ei], cnt = L.e_cnt[ei];
+            RayGeom rg;
+            load_ray(P.entry, P.exit_, P.rays, P.nsamp, (size_t)view * NP + pl, rg);
+            const f3 vd = make_f3(rg.vx, rg.vy, rg.vz);
+            float C0 = 0.f, C1 = 0.f, C2 = 0.f, A = 0.f;
+            int valid = 0;
+            for (int s = s0; s < s0 + cnt; ++s) {
+                Sample sm; TapCoords t;
+                if (!sample_coords(vol, c, rg, cam, s, sm, t)) continue;
+                ++valid;
+                float dx, dy, dz;
+                sample_taps_lds(L.box, t, sm.I, dx, dy, dz);
+                classify_from_I(L.tf, P.R, P.tf_len, P.inv_sr, sm);
+                if (MODE == DR_MODE_NONDIFF && !(sm.a > 1e-3f)) continue;
+                shade_from_grad(dx, dy, dz, light, vd, MODE == DR_MODE_DIFF, sm);
+                const float T = 1.0f - A;
+                C0 = fmaf(T, sm.L * sm.r * sm.op, C0);
+                C1 = fmaf(T, sm.L * sm.g * sm.op, C1);
+                C2 = fmaf(T, sm.L * sm.b * sm.op, C2);
+                A = fmaf(T, sm.op, A);
+            }
+            if (valid > 0) {
+                P.seg_rgba[seg_base + pl] = make_float4(C0, C1, C2, A);
+                P.seg_cnt[seg_base + pl] = valid;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ F2
+template <typename VT, int MODE>
+__global__ __launch_bounds__(256) void ray_compose_kernel(BrickParams<VT> P) {
+    extern __shared__ __attribute__((aligned(16))) float4 lds_tf[];
+    const int view = blockIdx.y;
+    const float4 *tfg = P.tf + view * P.tf_vs;
+    for (int k = threadIdx.x; k < P.R; k += 256) lds_tf[k] = tfg[k];
+    __syncthreads();
+    const int NP = P.W * P.H;
+    const int pl = blockIdx.x * 256 + threadIdx.x;
+    if (pl >= NP) return;
+    const size_t p = (size_t)view * NP + pl;
+    RayGeom rg;
+    load_ray(P.entry, P.exit_, P.rays, P.nsamp, p, rg);
+    float C0 = 0.f, C1 = 0.f, C2 = 0.f, A = 0.f;
+    int steps = 0;
+    uint8_t flag = 0;
+    if (rg.n > 0) {
+        VolView<VT> vol = P.vol;
+        vol.p += view * P.vol_vs;
+        const f3 cam = make_f3(P.cam[3 * view], P.cam[3 * view + 1], P.cam[3 * view + 2]);
+        const f3 light = make_f3(cam.x + 0.0f, cam.y + 1.0f, cam.z + 0.0f);
+        const f3 vd = make_f3(rg.vx, rg.vy, rg.vz);
+        const int nmarch = (MODE == DR_MODE_DIFF && rg.n > P.S) ? P.S : rg.n;
+        const size_t seg0 = (size_t)view * P.g.NL * NP + pl;
+        bool regular = ray_is_regular(rg.n, rg.entry);
+        if (regular) {
+            // safety net: the segments must account for every sample, else march this ray whole
+            int total = 0;
+            for (int l = 0; l < P.g.NL; ++l) total += P.seg_cnt[seg0 + (size_t)l * NP];
+            if (total != nmarch) { regular = false; atomicAdd(&P.stats[0], 1u); }
+        }
+        int s_from = 0, s_to = 0;  // samples to march one by one with early termination
+        if (!regular) {
+            flag = 1; s_to = nmarch;
+        } else {
+            int sacc = 0;
+            steps = nmarch;
+            for (int l = 0; l < P.g.NL; ++l) {
+                const size_t si = seg0 + (size_t)l * NP;
+                const int cnt = P.seg_cnt[si];
+                if (cnt == 0) continue;
+                const float4 sg = P.seg_rgba[si];
+                if (MODE == DR_MODE_DIFF) P.seg_rgba[si] = make_float4(C0, C1, C2, A);  // prefix for the backward
+                const float T = 1.0f - A;
+                const float A_after = fmaf(T, sg.w, A);
+                if (!(A_after < 0.99f)) {  // alpha crosses 0.99 inside this segment
+                    s_from = sacc; s_to = sacc + cnt;
+                    break;
+                }
+                C0 = fmaf(T, sg.x, C0); C1 = fmaf(T, sg.y, C1); C2 = fmaf(T, sg.z, C2);
+                A = A_after;
+                sacc += cnt;
+            }
+        }
+        if (s_to > s_from) {
+            steps = s_from;
+            for (int s = s_from; s < s_to; ++s) {
+                if (!(A < 0.99f)) break;
+                Sample sm;
+                sample_pos(rg, cam.x, cam.y, cam.z, s, sm.px, sm.py, sm.pz);
+                classify(vol, lds_tf, P.R, P.tf_len, P.inv_sr, sm);
+                ++steps;
+                if (MODE == DR_MODE_NONDIFF && !(sm.a > 1e-3f)) continue;
+                shade(vol, light, vd, MODE == DR_MODE_DIFF, sm);
+                const float T = 1.0f - A;
+                C0 = fmaf(T, sm.L * sm.r * sm.op, C0);
+                C1 = fmaf(T, sm.L * sm.g * sm.op, C1);
+                C2 = fmaf(T, sm.L * sm.b * sm.op, C2);
+                A = fmaf(T, sm.op, A);
+            }
+            // a regular ray that crossed 0.99 exactly on the last sample of its segment keeps marching
+            // nothing further: later segments are ignored (their first sample would see A >= 0.99).
+            if (!flag && A < 0.99f) {
+                // the partial composite crossed 0.99 but the exact recurrence did not (rounding): fall
+                // back to marching the rest of the ray sample by sample.
+                for (int s = s_to; s < nmarch; ++s) {
+                    if (!(A < 0.99f)) break;
+                    Sample sm;
+                    sample_pos(rg, cam.x, cam.y, cam.z, s, sm.px, sm.py, sm.pz);
+                    classify(vol, lds_tf, P.R, P.tf_len, P.inv_sr, sm);
+                    ++steps;
+                    if (MODE == DR_MODE_NONDIFF && !(sm.a > 1e-3f)) continue;
+                    shade(vol, light, vd, MODE == DR_MODE_DIFF, sm);
+                    const float T = 1.0f - A;
+                    C0 = fmaf(T, sm.L * sm.r * sm.op, C0);
+                    C1 = fmaf(T, sm.L * sm.g * sm.op, C1);
+                    C2 = fmaf(T, sm.L * sm.b * sm.op, C2);
+                    A = fmaf(T, sm.op, A);
+                }
+                flag = 1;  // its stored prefixes beyond s_to are stale: let B2 handle the whole ray
+            }
+        }
+    }
+    if (MODE == DR_MODE_NONDIFF) {
+        C0 = fminf(1.0f, C0); C1 = fminf(1.0f, C1); C2 = fminf(1.0f, C2); A = fminf(1.0f, A);
+    }
+    reinterpret_cast<float4 *>(P.out)[p] = make_float4(C0, C1, C2, A);
+    if (P.steps) P.steps[p] = steps;
+    P.ws_steps[p] = steps;
+    P.rayflag[p] = flag;
+}
+
+// ------------------------------------------------------------------------------------------------ B1
+__device__ __forceinline__ void tri_scatter_lds(float *dbox, int base, float fx, float fy, float fz, float adj) {
+    const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;
+    atomicAdd(dbox + base, gx * gy * gz * adj);
+    atomicAdd(dbox + base + BOX_SX, fx * gy * gz * adj);
+    atomicAdd(dbox + base + BOX_SY, gx * fy * gz * adj);
+    atomicAdd(dbox + base + BOX_SX + BOX_SY, fx * fy * gz * adj);
+    atomicAdd(dbox + base + 1, gx * gy * fz * adj);
+    atomicAdd(dbox + base + BOX_SX + 1, fx * gy * fz * adj);
+    atomicAdd(dbox + base + BOX_SY + 1, gx * fy * fz * adj);
+    atomicAdd(dbox + base + BOX_SX + BOX_SY + 1, fx * fy * fz * adj);
+}
+
+template <typename VT, bool WANT_VOL, bool WANT_TF>
+__global__ __launch_bounds__(256) void brick_bwd_kernel(BrickParams<VT> P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int view = blockIdx.y;
+    const f3 cam = make_f3(P.cam[3 * view], P.cam[3 * view + 1], P.cam[3 * view + 2]);
+    BrickCtx c;
+    brick_setup(P, blockIdx.x, cam, c);
+    if (c.i0 > c.i1 || c.j0 > c.j1) return;
+
+    LdsLayout L = carve(smem, P.R, WANT_VOL, WANT_TF);
+    VolView<VT> vol = P.vol;
+    vol.p += view * P.vol_vs;
+    load_tf_and_box(P, vol, c, P.tf + view * P.tf_vs, L);
+    if (WANT_VOL) for (int k = threadIdx.x; k < BOX_N; k += 256) L.dbox[k] = 0.0f;
+    if (WANT_TF) for (int k = threadIdx.x; k < 4 * P.R; k += 256) L.dtf[k] = 0.0f;
+    const f3 light = make_f3(cam.x + 0.0f, cam.y + 1.0f, cam.z + 0.0f);
+    const int NP = P.W * P.H;
+    const size_t seg_base = ((size_t)view * P.g.NL + c.layer) * NP;
+    const int ncand = (c.i1 - c.i0 + 1) * (c.j1 - c.j0 + 1);
+    bool any = false;
+
+    for (int cbase = 0; cbase < ncand; cbase += ECHUNK) {
+        const int nE = build_entries<VT, true>(P, c, cam, view, cbase, ncand, DR_MODE_DIFF, L);
+        any = any || nE > 0;
+        for (int e = threadIdx.x; e < nE; e += 256) {
+            const int ei = L.order[e];
+            const int pl = L.e_pix[ei], s0 = L.e_s0[ei], cnt = L.e_cnt[ei];
+            const size_t p = (size_t)view * NP + pl;
+            if (P.seg_cnt[seg_base + pl] == 0) continue;  // no sample of this ray lies in this brick
+            RayGeom rg;
+            load_ray(P.entry, P.exit_, P.rays, P.nsamp, p, rg);
+            const f3 vd = make_f3(rg.vx, rg.vy, rg.vz);
+            const int live = P.ws_steps[p];
+            const float4 pre = P.seg_rgba[seg_base + pl];  // composite before this segment (written by F2)
+            const float4 go = reinterpret_cast<const float4 *>(P.grad_out)[p];
+            const float4 of = reinterpret_cast<const float4 *>(P.out_fwd)[p];
+            float C0 = pre.x, C1 = pre.y, C2 = pre.z, A = pre.w;
+            for (int s = s0; s < s0 + cnt; ++s) {
+                Sample sm; TapCoords t;
+                if (!sample_coords(vol, c, rg, cam, s, sm, t)) continue;
+                float dx, dy, dz;
+                sample_taps_lds(L.box, t, sm.I, dx, dy, dz);
+                classify_from_I(L.tf, P.R, P.tf_len, P.inv_sr, sm);
+                shade_from_grad(dx, dy, dz, light, vd, true, sm);
+                const float T = 1.0f - A;
+                C0 = fmaf(T, sm.L * sm.r * sm.op, C0);
+                C1 = fmaf(T, sm.L * sm.g * sm.op, C1);
+                C2 = fmaf(T, sm.L * sm.b * sm.op, C2);
+                A = fmaf(T, sm.op, A);
+                const bool last = (s == live - 1);
+                const float suffix = (go.x * (of.x - C0) + go.y * (of.y - C1) + go.z * (of.z - C2)) + go.w * (of.w - A);
+                SampleAdj ad;
+                sample_adjoint(sm, vd, T, suffix, last, go, P.inv_sr, ad);
+                if (WANT_TF) {
+                    const float w0 = 1.0f - sm.fr, w1 = sm.fr;
+                    float *d0 = L.dtf + 4 * sm.lo, *d1 = L.dtf + 4 * sm.hi;
+                    atomicAdd(d0 + 0, w0 * ad.r_bar); atomicAdd(d0 + 1, w0 * ad.g_bar);
+                    atomicAdd(d0 + 2, w0 * ad.b_bar); atomicAdd(d0 + 3, w0 * ad.a_bar);
+                    atomicAdd(d1 + 0, w1 * ad.r_bar); atomicAdd(d1 + 1, w1 * ad.g_bar);
+                    atomicAdd(d1 + 2, w1 * ad.b_bar); atomicAdd(d1 + 3, w1 * ad.a_bar);
+                }
+                if (WANT_VOL) {
+                    const float I_bar = intensity_adjoint(sm, L.tf[sm.lo], L.tf[sm.hi], ad, P.tf_len);
+                    const int by = t.ly * BOX_SY, bz = t.lz, bx = t.lx * BOX_SX;
+                    tri_scatter_lds(L.dbox, bx + by + bz, t.fx, t.fy, t.fz, I_bar);
+                    if (!sm.flat) {
+                        tri_scatter_lds(L.dbox, t.lxp * BOX_SX + by + bz, t.fxp, t.fy, t.fz, ad.gx);
+                        tri_scatter_lds(L.dbox, t.lxm * BOX_SX + by + bz, t.fxm, t.fy, t.fz, -ad.gx);
+                        tri_scatter_lds(L.dbox, bx + t.lyp * BOX_SY + bz, t.fx, t.fyp, t.fz, ad.gy);
+                        tri_scatter_lds(L.dbox, bx + t.lym * BOX_SY + bz, t.fx, t.fym, t.fz, -ad.gy);
+                        tri_scatter_lds(L.dbox, bx + by + t.lzp, t.fx, t.fy, t.fzp, ad.gz);
+                        tri_scatter_lds(L.dbox, bx + by + t.lzm, t.fx, t.fy, t.fzm, -ad.gz);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (!any) return;  // uniform
+    // flush: one pass of global float atomics per brick, walking the gradient's fastest axis
+    if (WANT_VOL) {
+        GradView dv = P.dvol;
+        dv.p += view * P.dvol_vs;
+        const int fast = (dv.sx <= dv.sy && dv.sx <= dv.sz) ? 0 : ((dv.sy <= dv.sz) ? 1 : 2);
+        for (int idx = threadIdx.x; idx < BOX_N; idx += 256) {
+            const int a = idx % BOX, b = (idx / BOX) % BOX, d = idx / (BOX * BOX);
+            int lx, ly, lz;
+            if (fast == 0) { lx = a; ly = b; lz = d; } else if (fast == 1) { ly = a; lx = b; lz = d; } else { lz = a; ly = b; lx = d; }
+            const float v = L.dbox[lx * BOX_SX + ly * BOX_SY + lz];
+            if (v != 0.0f) {
+                const int gx = c.ox + lx, gy = c.oy + ly, gz = c.oz + lz;  // in range whenever v != 0
+                unsafeAtomicAdd(dv.p + gx * dv.sx + gy * dv.sy + gz * dv.sz, v);
+            }
+        }
+    }
+    if (WANT_TF) {
+        float *dtf = P.d_tf + view * P.dtf_vs * 4;
+        for (int k = threadIdx.x; k < 4 * P.R; k += 256) {
+            const float v = L.dtf[k];
+            if (v != 0.0f) unsafeAtomicAdd(dtf + k, v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host
+struct Workspace {
+    float4 *seg_rgba; int32_t *seg_cnt; int32_t *ws_steps; uint8_t *rayflag; unsigned int *stats;
+    size_t cnt_bytes;
+};
+static size_t ws_layout(void *base, int n_views, int NP, int NL, Workspace *w) {
+    size_t o = 0;
+    const size_t nseg = (size_t)n_views * NL * NP;
+    unsigned char *b = static_cast<unsigned char *>(base);
+    if (w) w->stats = reinterpret_cast<unsigned int *>(b + o);
+    o += 256;
+    if (w) w->seg_rgba = reinterpret_cast<float4 *>(b + o);
+    o += nseg * 16;
+    if (w) { w->seg_cnt = reinterpret_cast<int32_t *>(b + o); w->cnt_bytes = nseg * 4; }
+    o += nseg * 4;
+    if (w) w->ws_steps = reinterpret_cast<int32_t *>(b + o);
+    o += align16((size_t)n_views * NP * 4);
+    if (w) w->rayflag = reinterpret_cast<uint8_t *>(b + o);
+    o += align16((size_t)n_views * NP);
+    return o;
+}
+
+bool brick_path_supported(int VX, int VY, int VZ, int R) {
+    const int m = VX > VY ? (VX > VZ ? VX : VZ) : (VY > VZ ? VY : VZ);
+    if (m - 1 >= 2000) return false;       // normal taps must stay within one voxel of the centre cell
+    if (brick_lds_bytes(R, true, true) > 160 * 1024) return false;
+    return true;
+}
+
+size_t brick_workspace_bytes(int n_views, int W, int H, int VX, int VY, int VZ) {
+    const BrickGrid g = make_brick_grid(VX, VY, VZ);
+    return ws_layout(nullptr, n_views, W * H, g.NL, nullptr);
+}
+
+template <typename VT>
+static BrickParams<VT> make_brick_params(const MarchArgs &a, const Workspace &w) {
+    BrickParams<VT> P;
+    P.vol.p = static_cast<const VT *>(a.vol);
+    P.vol.sx = a.sx; P.vol.sy = a.sy; P.vol.sz = a.sz;
+    P.vol.VX = a.VX; P.vol.VY = a.VY; P.vol.VZ = a.VZ;
+    P.vol.scx = (float)((double)a.VX - 1.0 - 1e-4);
+    P.vol.scy = (float)((double)a.VY - 1.0 - 1e-4);
+    P.vol.scz = (float)((double)a.VZ - 1.0 - 1e-4);
+    P.vol_vs = a.vol_vs;
+    P.tf = reinterpret_cast<const float4 *>(a.tf); P.tf_vs = a.tf_vs / 4; P.R = a.R; P.tf_len = (float)(a.R - 1);
+    P.cam = a.cam; P.entry = a.entry; P.exit_ = a.exit_; P.rays = a.rays; P.nsamp = a.nsamp;
+    P.W = a.W; P.H = a.H; P.S = a.S; P.sr = a.sr; P.inv_sr = 1.0f / a.sr;
+    const double near_h = 2.0 * tan(a.fov_rad) * a.near_plane;
+    P.near_ = (float)a.near_plane; P.near_h = (float)near_h; P.near_w = (float)(near_h * ((double)a.W / (double)a.H));
+    P.g = make_brick_grid(a.VX, a.VY, a.VZ);
+    P.seg_rgba = w.seg_rgba; P.seg_cnt = w.seg_cnt; P.rayflag = w.rayflag; P.stats = w.stats; P.ws_steps = w.ws_steps;
+    P.out = a.out; P.steps = a.steps;
+    P.grad_out = a.grad_out; P.out_fwd = a.out_fwd;
+    P.dvol.p = a.d_vol; P.dvol.sx = a.dsx; P.dvol.sy = a.dsy; P.dvol.sz = a.dsz; P.dvol_vs = a.dvol_vs;
+    P.d_tf = a.d_tf; P.dtf_vs = a.dtf_vs / 4;
+    return P;
+}
+
+template <typename K>
+static hipError_t allow_lds(K kernel, size_t bytes) {
+    if (bytes <= 64 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+template <typename VT>
+static int brick_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
+    const BrickGrid g = make_brick_grid(a.VX, a.VY, a.VZ);
+    const int NP = a.W * a.H;
+    Workspace w;
+    const size_t need = ws_layout(a.workspace, a.n_views, NP, g.NL, &w);
+    if (!a.workspace || a.workspace_bytes < need) return DR_EINVAL;
+    BrickParams<VT> P = make_brick_params<VT>(a, w);
+    hipError_t e = hipMemsetAsync(w.stats, 0, 256, stream);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(w.seg_cnt, 0, w.cnt_bytes, stream);
+    if (e != hipSuccess) return (int)e;
+    const size_t lds = brick_lds_bytes(a.R, false, false);
+    const dim3 grid1(g.NBx * g.NBy * g.NBz, a.n_views), grid2((NP + 255) / 256, a.n_views);
+    const size_t lds2 = (size_t)a.R * 16;
+    if (a.mode == DR_MODE_DIFF) {
+        if ((e = allow_lds(brick_fwd_kernel<VT, DR_MODE_DIFF>, lds)) != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((brick_fwd_kernel<VT, DR_MODE_DIFF>), grid1, dim3(256), lds, stream, P);
+        hipLaunchKernelGGL((ray_compose_kernel<VT, DR_MODE_DIFF>), grid2, dim3(256), lds2, stream, P);
+    } else {
+        if ((e = allow_lds(brick_fwd_kernel<VT, DR_MODE_NONDIFF>, lds)) != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((brick_fwd_kernel<VT, DR_MODE_NONDIFF>), grid1, dim3(256), lds, stream, P);
+        hipLaunchKernelGGL((ray_compose_kernel<VT, DR_MODE_NONDIFF>), grid2, dim3(256), lds2, stream, P);
+    }
+    return (int)hipGetLastError();
+}
+
+int launch_march_fwd_brick(const MarchArgs &a, hipStream_t stream) {
+    return a.vol_dtype == DR_F16 ? brick_fwd_dispatch<__half>(a, stream) : brick_fwd_dispatch<float>(a, stream);
+}
+
+template <typename VT>
+static int brick_bwd_dispatch(const MarchArgs &a, hipStream_t stream) {
+    const BrickGrid g = make_brick_grid(a.VX, a.VY, a.VZ);
+    const int NP = a.W * a.H;
+    Workspace w;
+    const size_t need = ws_layout(a.workspace, a.n_views, NP, g.NL, &w);
+    if (!a.workspace || a.workspace_bytes < need) return DR_EINVAL;
+    BrickParams<VT> P = make_brick_params<VT>(a, w);
+    const bool wv = a.d_vol != nullptr, wt = a.d_tf != nullptr;
+    const size_t lds = brick_lds_bytes(a.R, wv, wt);
+    const dim3 grid1(g.NBx * g.NBy * g.NBz, a.n_views);
+    hipError_t e;
+    if (wv && wt) {
+        if ((e = allow_lds(brick_bwd_kernel<VT, true, true>, lds)) != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((brick_bwd_kernel<VT, true, true>), grid1, dim3(256), lds, stream, P);
+    } else if (wv) {
+        if ((e = allow_lds(brick_bwd_kernel<VT, true, false>, lds)) != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((brick_bwd_kernel<VT, true, false>), grid1, dim3(256), lds, stream, P);
+    } else {
+        if ((e = allow_lds(brick_bwd_kernel<VT, false, true>, lds)) != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((brick_bwd_kernel<VT, false, true>), grid1, dim3(256), lds, stream, P);
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    // B2: irregular rays through the baseline backward, restricted to the rays F2 flagged
+    MarchArgs b = a;
+    b.only_flagged = w.rayflag;
+    return launch_march_bwd_baseline(b, stream);
+}
+
+int launch_march_bwd_brick(const MarchArgs &a, hipStream_t stream) {
+    return a.vol_dtype == DR_F16 ? brick_bwd_dispatch<__half>(a, stream) : brick_bwd_dispatch<float>(a, stream);
+}
+
+}  // namespace dr

@@ -10,7 +10,7 @@ import torch
 
 from . import _native as N
 
-__all__ = ["ray_setup", "march_fwd", "march_bwd", "new_jitter_seed"]
+__all__ = ["ray_setup", "march_fwd", "march_bwd", "new_jitter_seed", "alloc_workspace", "workspace_stats"]
 
 
 def _stream():
@@ -57,6 +57,30 @@ def new_jitter_seed():
     return int(torch.randint(1, 2 ** 31 - 1, (1,)).item())
 
 
+def alloc_workspace(n_views, out_shape, vol_shape, R, device):
+    """Scratch buffer of the fast (brick-centric) kernels for one forward(+backward) pair, or None when only
+    the baseline kernels can serve this problem (dr_workspace_bytes() == 0). The forward leaves its coarse
+    tape here; hand the same buffer to march_bwd."""
+    W, H = int(out_shape[0]), int(out_shape[1])
+    VX, VY, VZ = (int(s) for s in vol_shape)
+    nbytes = N.lib().dr_workspace_bytes(int(n_views), W, H, VX, VY, VZ, int(R))
+    if nbytes == 0:
+        return None
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def workspace_stats(workspace):
+    """Diagnostics the last forward left in the workspace header: [0] = rays whose segments failed the
+    sample-count check and were marched individually (expected 0)."""
+    return workspace[:32].view(torch.int32).cpu()
+
+
+def _ws_args(workspace):
+    if workspace is None:
+        return None, 0
+    return workspace.data_ptr(), workspace.numel()
+
+
 def ray_setup(cam, out_shape, vol_shape, sampling_rate, fov_deg=30.0, near=0.1, jitter_seed=0, view_base=0):
     """compute_entry_exit (VR.py:221-259) for cam (views,3) -> entry, exit (views,W,H), rays (views,W,H,3),
     n (views,W,H) int32."""
@@ -79,9 +103,11 @@ def ray_setup(cam, out_shape, vol_shape, sampling_rate, fov_deg=30.0, near=0.1, 
 
 
 def march_fwd(vol, tf, cam, entry, exit_, rays, n, max_samples, sampling_rate, mode=N.DR_MODE_DIFF,
-              variant=N.DR_VARIANT_AUTO, want_steps=True):
+              variant=N.DR_VARIANT_AUTO, want_steps=True, fov_deg=30.0, near=0.1, workspace="auto"):
     """raycast + get_final_image (VR.py:261-306,363-372) or the nondiff pair (VR.py:308-361).
-    Returns out (views,W,H,4) and steps (views,W,H) int32 (or None)."""
+    Returns out (views,W,H,4) and steps (views,W,H) int32 (or None).
+    workspace: a buffer from alloc_workspace() (keep it for march_bwd), "auto" to allocate a throw-away one,
+    or None to force the baseline kernels."""
     _require_gpu(vol, "volume")
     V, W, H = n.shape
     dev = vol.device
@@ -90,19 +116,23 @@ def march_fwd(vol, tf, cam, entry, exit_, rays, n, max_samples, sampling_rate, m
     steps = torch.empty((V, W, H), dtype=torch.int32, device=dev) if want_steps else None
     vargs = _vol_args(vol, V)
     targs = _tf_args(tf, V)
+    if isinstance(workspace, str):
+        workspace = alloc_workspace(V, (W, H), vargs[2:5], targs[1], dev) if variant == N.DR_VARIANT_AUTO else None
     with torch.cuda.device(dev):
         rc = N.lib().dr_march_fwd(*vargs, targs[0], targs[1], targs[2], cam.data_ptr(), entry.data_ptr(),
                                   exit_.data_ptr(), rays.data_ptr(), n.data_ptr(), V, W, H, int(max_samples),
-                                  float(sampling_rate), int(mode), int(variant), out.data_ptr(),
-                                  steps.data_ptr() if want_steps else None, _stream())
+                                  float(sampling_rate), float(np.radians(fov_deg)), float(near), int(mode),
+                                  int(variant), out.data_ptr(), steps.data_ptr() if want_steps else None,
+                                  *_ws_args(workspace), _stream())
     N.check(rc, "dr_march_fwd")
     return out, steps
 
 
 def march_bwd(vol, tf, cam, entry, exit_, rays, n, max_samples, sampling_rate, grad_out, out, want_vol=True,
-              want_tf=True, variant=N.DR_VARIANT_AUTO):
+              want_tf=True, variant=N.DR_VARIANT_AUTO, fov_deg=30.0, near=0.1, workspace=None):
     """Adjoint of the differentiable march w.r.t. vol and tf (replaces raycast.grad, VR.py:460-461,470-471).
-    Shared (un-batched) vol / tf receive one gradient accumulated over all views."""
+    Shared (un-batched) vol / tf receive one gradient accumulated over all views.
+    workspace: the buffer the matching march_fwd filled (fast path); None runs the baseline kernels."""
     _require_gpu(vol, "volume")
     V, W, H = n.shape
     cam = cam.to(torch.float32).contiguous()
@@ -127,7 +157,7 @@ def march_bwd(vol, tf, cam, entry, exit_, rays, n, max_samples, sampling_rate, g
     with torch.cuda.device(vol.device):
         rc = N.lib().dr_march_bwd(*vargs, targs[0], targs[1], targs[2], cam.data_ptr(), entry.data_ptr(),
                                   exit_.data_ptr(), rays.data_ptr(), n.data_ptr(), V, W, H, int(max_samples),
-                                  float(sampling_rate), int(variant), grad_out.data_ptr(), out.data_ptr(),
-                                  *dv, *dt, _stream())
+                                  float(sampling_rate), float(np.radians(fov_deg)), float(near), int(variant),
+                                  grad_out.data_ptr(), out.data_ptr(), *dv, *dt, *_ws_args(workspace), _stream())
     N.check(rc, "dr_march_bwd")
     return d_vol, d_tf

@@ -89,7 +89,7 @@ class VolumeRaycaster:
         self.ambient, self.diffuse, self.specular, self.shininess = 0.4, 0.8, 0.3, 32.0  # VR.py:91-94 (fixed in-kernel)
         for name in ("volume", "tf_tex", "cam_pos", "entry", "exit", "rays", "sample_step_nums",
                      "valid_sample_step_count", "output_rgba", "volume_grad", "tf_tex_grad", "output_rgba_grad",
-                     "tape_last"):
+                     "tape_last", "workspace"):
             setattr(self, "_" + name, None)
         self.volume = _Field(self, "volume", needs_grad=True)
         self.tf_tex = _Field(self, "tf_tex", needs_grad=True)
@@ -144,8 +144,11 @@ class VolumeRaycaster:
         self._entry, self._exit, self._rays, self._sample_step_nums = e[0], x[0], r[0], n[0]
 
     def _march(self, sampling_rate, mode):
+        self._workspace = F.alloc_workspace(1, self.resolution, self._volume.shape, self._tf_tex.shape[0],
+                                            self._volume.device)
         out, steps = F.march_fwd(self._volume, self._tf_tex, self._cam_pos, self._entry[None], self._exit[None],
-                                 self._rays[None], self._sample_step_nums[None], self.max_samples, sampling_rate, mode)
+                                 self._rays[None], self._sample_step_nums[None], self.max_samples, sampling_rate, mode,
+                                 fov_deg=self.fov_deg, near=self.near, workspace=self._workspace)
         self._tape_last = out[0]
         self._valid_sample_step_count = steps[0]
         self._sr = sampling_rate
@@ -169,7 +172,8 @@ class VolumeRaycaster:
     def _raycast_grad(self, sampling_rate):
         dv, dt = F.march_bwd(self._volume, self._tf_tex, self._cam_pos, self._entry[None], self._exit[None],
                              self._rays[None], self._sample_step_nums[None], self.max_samples, sampling_rate,
-                             self._output_rgba_grad[None], self._tape_last[None])
+                             self._output_rgba_grad[None], self._tape_last[None], fov_deg=self.fov_deg,
+                             near=self.near, workspace=self._workspace)
         self._volume_grad = dv if self._volume_grad is None else self._volume_grad + dv
         self._tf_tex_grad = dt if self._tf_tex_grad is None else self._tf_tex_grad + dt
 
@@ -192,8 +196,11 @@ class RaycastFunction(torch.autograd.Function):
         tf = tf.contiguous()
         seed = F.new_jitter_seed() if jitter else 0
         e, x, r, n = F.ray_setup(cam, vr.resolution, volume.shape[-3:], sampling_rate, vr.fov_deg, vr.near, seed)
-        out, steps = F.march_fwd(volume, tf, cam, e, x, r, n, vr.max_samples, sampling_rate, N.DR_MODE_DIFF)
+        ws = F.alloc_workspace(cam.shape[0], vr.resolution, volume.shape[-3:], tf.shape[-2], volume.device)
+        out, steps = F.march_fwd(volume, tf, cam, e, x, r, n, vr.max_samples, sampling_rate, N.DR_MODE_DIFF,
+                                 fov_deg=vr.fov_deg, near=vr.near, workspace=ws)
         ctx.save_for_backward(volume, tf, cam, e, x, r, n, out)
+        ctx.workspace = ws  # coarse tape of the forward (per-segment prefixes), consumed by backward
         ctx.vr, ctx.sampling_rate, ctx.batched, ctx.jitter_seed = vr, sampling_rate, is_batched, seed
         vr._valid_sample_step_count = steps if is_batched else steps[0]
         return out if is_batched else out[0]
@@ -205,7 +212,8 @@ class RaycastFunction(torch.autograd.Function):
         g = grad_output if ctx.batched else grad_output[None]
         want_vol, want_tf = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         dv, dt = F.march_bwd(volume, tf, cam, e, x, r, n, ctx.vr.max_samples, ctx.sampling_rate, g, out,
-                             want_vol=want_vol, want_tf=want_tf)
+                             want_vol=want_vol, want_tf=want_tf, fov_deg=ctx.vr.fov_deg, near=ctx.vr.near,
+                             workspace=ctx.workspace)
         # VR.py:463-464,474-475
         if dv is not None:
             dv = torch.nan_to_num(dv)
@@ -252,7 +260,7 @@ class Raycaster(torch.nn.Module):
             cam = lf_in.reshape(-1, 3).float()
             e, x, r, n = F.ray_setup(cam, self.vr.resolution, vol_in.shape[-3:], sr, self.vr.fov_deg, self.vr.near, 0)
             out, steps = F.march_fwd(vol_in, tf_in.float().contiguous(), cam, e, x, r, n, self.vr.max_samples, sr,
-                                     N.DR_MODE_NONDIFF)
+                                     N.DR_MODE_NONDIFF, fov_deg=self.vr.fov_deg, near=self.vr.near)
             self.vr._valid_sample_step_count = steps if batched else steps[0]
             if batched:  # (BS,W,H,4) -> flip H -> (BS,4,H,W), VR.py:513
                 return torch.flip(out, (2,)).permute(0, 3, 2, 1).contiguous()

@@ -24,13 +24,14 @@
 #ifndef DIFFERENDER_HIP_H
 #define DIFFERENDER_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define DR_ABI_VERSION 1
+#define DR_ABI_VERSION 2
 
 enum { DR_F32 = 0, DR_F16 = 1 };
 enum { DR_MODE_DIFF = 0, DR_MODE_NONDIFF = 1 };
@@ -60,6 +61,14 @@ int dr_ray_setup(const float *cam, int n_views, int W, int H, int VX, int VY, in
                  uint32_t jitter_seed, uint32_t view_base,
                  float *entry, float *exit_, float *rays, int32_t *nsamp, void *stream);
 
+/* Scratch memory the fast (brick-centric) march kernels need for n_views views, in bytes; 0 when this
+ * problem is only served by the baseline kernels (volume edge > 2000 voxels or a TF too large for LDS).
+ * The caller allocates it (device memory, 256-byte aligned), passes it to dr_march_fwd and, unchanged,
+ * to the dr_march_bwd of the same inputs: the forward leaves the per-segment composite prefixes and the
+ * per-ray live sample counts there (the "coarse tape", ~20 B per ray per brick layer). Replaces the
+ * reference's render_tape field (VR.py:82,102-103: 16 B per ray per SAMPLE, twice with its gradient). */
+size_t dr_workspace_bytes(int n_views, int W, int H, int VX, int VY, int VZ, int R);
+
 /* Forward march: trilinear sampling, 1-D TF lookup, Phong shading, front-to-back compositing with
  * early termination at A >= 0.99.
  *   mode DR_MODE_DIFF    replaces clear_framebuffer + raycast + get_final_image
@@ -68,14 +77,18 @@ int dr_ray_setup(const float *cam, int n_views, int W, int H, int VX, int VY, in
  *   tf      [n_views or 1][R][4] f32
  *   out_rgba [n_views][W][H][4] f32 (overwritten)
  *   steps   [n_views][W][H] i32, nullable: samples that passed the termination test
- *           (= valid_sample_step_count - 1, VR.py:303,381) */
+ *           (= valid_sample_step_count - 1, VR.py:303,381)
+ *   fov_rad, near_plane: the pinhole model the ray buffers were generated with (dr_ray_setup); the fast
+ *           path uses it to find the pixels a brick projects to. Rays that do not follow the model are
+ *           detected (sample-count check) and marched individually, so results stay correct.
+ *   workspace: dr_workspace_bytes() bytes, or NULL to force the baseline kernels. */
 int dr_march_fwd(const void *vol, int vol_dtype, int VX, int VY, int VZ,
                  int64_t sx, int64_t sy, int64_t sz, int64_t vol_view_stride,
                  const float *tf, int R, int64_t tf_view_stride,
                  const float *cam, const float *entry, const float *exit_, const float *rays,
                  const int32_t *nsamp, int n_views, int W, int H, int max_samples,
-                 float sampling_rate, int mode, int variant,
-                 float *out_rgba, int32_t *steps, void *stream);
+                 float sampling_rate, double fov_rad, double near_plane, int mode, int variant,
+                 float *out_rgba, int32_t *steps, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Backward of the DR_MODE_DIFF march w.r.t. the volume and the transfer function: the hand-derived,
  * tape-free equivalent of get_final_image.grad + raycast.grad (Taichi autodiff, VR.py:460-461,470-471).
@@ -83,16 +96,18 @@ int dr_march_fwd(const void *vol, int vol_dtype, int VX, int VY, int VZ,
  *   out_rgba [n_views][W][H][4]  the forward result for the same inputs (saved by the caller)
  *   d_vol    f32, element strides (dsx,dsy,dsz), nullable; ACCUMULATED into (caller zeroes)
  *   d_tf     [n_views or 1][R][4] f32, nullable; ACCUMULATED into (caller zeroes)
+ *   workspace: the buffer the forward call of the same inputs filled (fast path), or NULL (baseline).
  * Gradients w.r.t. camera and sampling rate are not defined (the reference returns None, VR.py:465). */
 int dr_march_bwd(const void *vol, int vol_dtype, int VX, int VY, int VZ,
                  int64_t sx, int64_t sy, int64_t sz, int64_t vol_view_stride,
                  const float *tf, int R, int64_t tf_view_stride,
                  const float *cam, const float *entry, const float *exit_, const float *rays,
                  const int32_t *nsamp, int n_views, int W, int H, int max_samples,
-                 float sampling_rate, int variant,
+                 float sampling_rate, double fov_rad, double near_plane, int variant,
                  const float *grad_out, const float *out_rgba,
                  float *d_vol, int64_t dsx, int64_t dsy, int64_t dsz, int64_t dvol_view_stride,
-                 float *d_tf, int64_t dtf_view_stride, void *stream);
+                 float *d_tf, int64_t dtf_view_stride,
+                 void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -39,11 +39,31 @@ def grad_close(a, b, tol=GRAD_TOL):
     return err <= tol, err
 
 
-@pytest.fixture(scope="module")
-def F(hiplib):
+class _Variant:
+    """differender_amd.functional with the kernel variant pinned (AUTO = brick-centric fast path with a
+    workspace shared between forward and backward; BASELINE = plain kernels, no workspace)."""
+
+    def __init__(self, functional, variant):
+        self._f, self.variant = functional, variant
+        self.ray_setup = functional.ray_setup
+        self._ws = None
+
+    def march_fwd(self, vol, tf, cam, e, x, r, n, S, sr, mode=0, **kw):
+        if self.variant == 0:
+            self._ws = self._f.alloc_workspace(n.shape[0], n.shape[1:], vol.shape[-3:], tf.shape[-2], vol.device)
+            assert self._ws is not None
+        return self._f.march_fwd(vol, tf, cam, e, x, r, n, S, sr, mode, variant=self.variant, workspace=self._ws, **kw)
+
+    def march_bwd(self, vol, tf, cam, e, x, r, n, S, sr, g, out, want_vol=True, want_tf=True):
+        return self._f.march_bwd(vol, tf, cam, e, x, r, n, S, sr, g, out, want_vol, want_tf, variant=self.variant,
+                                 workspace=self._ws)
+
+
+@pytest.fixture(scope="module", params=[0, 1], ids=["brick", "baseline"])
+def F(hiplib, request):
     assert torch.cuda.is_available(), "gpu tests need a ROCm device"
     from differender_amd import functional
-    return functional
+    return _Variant(functional, request.param)
 
 
 @pytest.mark.parametrize("WH,vshape,sr,cam_i", [((64, 64), (48, 48, 48), 1.0, 0.3), ((40, 72), (32, 48, 40), 2.0, 1.9),
