@@ -15,6 +15,11 @@
 //   B1 brick_bwd_kernel   per (brick, view): recompute the segment from the stored prefix, scatter-add
 //                         d_volume into an LDS box and d_tf into an LDS table, flush each once with
 //                         global float atomics (one coalesced flush per brick instead of 56 atomics/sample).
+//                         The LDS accumulators are 64-bit FIXED POINT: on gfx950 ds_add_f32 is serialised
+//                         (~193 cycles per wave-instruction whatever the addresses, measured in
+//                         tools/microbench/lds_atomic_bench) while ds_add_u64 takes 9-12. The scale comes from
+//                         max|grad_out| (a small reduction kernel) so 2^-28 of it is the resolution and
+//                         2^34 of it the headroom; integer adds also make the brick sums order-independent.
 //   B2                    irregular rays: the baseline backward restricted to flagged rays.
 //
 // Reference functions replaced: raycast / raycast_nondiff / get_final_image[_nondiff] (VR.py:261-372) and
@@ -37,7 +42,7 @@ struct BrickParams {
     int32_t *seg_cnt;    // [view][NL][NP]: samples of the ray inside the brick of that layer
     uint8_t *rayflag;    // [view][NP]: 1 = irregular ray (marched whole by F2 / B2)
     int32_t *ws_steps;   // [view][NP]: live samples per ray (F2 -> B1)
-    unsigned int *stats; // [0] rays repaired by the count check
+    unsigned int *stats; // [0] rays repaired by the count check, [1] bits of max|grad_out| (backward)
     float *out; int32_t *steps;
     const float *grad_out, *out_fwd;
     GradView dvol; int64_t dvol_vs;
@@ -121,14 +126,14 @@ __device__ __forceinline__ bool segment_range(const BrickCtx &c, f3 cam, f3 vd, 
 }
 
 struct LdsLayout {
-    float4 *tf; float *box; float *dbox; float *dtf;
+    float4 *tf; float *box; unsigned long long *dbox; unsigned long long *dtf;
     int *e_pix, *e_s0, *e_cnt; unsigned short *order; int *hist; int *misc;
 };
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 __host__ __device__ inline size_t brick_lds_bytes(int R, bool bwd_vol, bool bwd_tf) {
     size_t s = (size_t)R * 16 + align16(BOX_N * 4);
-    if (bwd_vol) s += align16(BOX_N * 4);
-    if (bwd_tf) s += (size_t)R * 16;
+    if (bwd_vol) s += align16(BOX_N * 8);
+    if (bwd_tf) s += (size_t)R * 32;
     s += 3 * ECHUNK * 4 + ECHUNK * 2 + 128 * 4 + 16;
     return s;
 }
@@ -138,8 +143,8 @@ __device__ __forceinline__ LdsLayout carve(unsigned char *smem, int R, bool bwd_
     L.tf = reinterpret_cast<float4 *>(smem + o); o += (size_t)R * 16;
     L.box = reinterpret_cast<float *>(smem + o); o += align16(BOX_N * 4);
     L.dbox = nullptr; L.dtf = nullptr;
-    if (bwd_vol) { L.dbox = reinterpret_cast<float *>(smem + o); o += align16(BOX_N * 4); }
-    if (bwd_tf) { L.dtf = reinterpret_cast<float *>(smem + o); o += (size_t)R * 16; }
+    if (bwd_vol) { L.dbox = reinterpret_cast<unsigned long long *>(smem + o); o += align16(BOX_N * 8); }
+    if (bwd_tf) { L.dtf = reinterpret_cast<unsigned long long *>(smem + o); o += (size_t)R * 32; }
     L.e_pix = reinterpret_cast<int *>(smem + o); o += ECHUNK * 4;
     L.e_s0 = reinterpret_cast<int *>(smem + o); o += ECHUNK * 4;
     L.e_cnt = reinterpret_cast<int *>(smem + o); o += ECHUNK * 4;
@@ -420,16 +425,63 @@ __global__ __launch_bounds__(256) void ray_compose_kernel(BrickParams<VT> P) {
 }
 
 // ------------------------------------------------------------------------------------------------ B1
-__device__ __forceinline__ void tri_scatter_lds(float *dbox, int base, float fx, float fy, float fz, float adj) {
+// ---- 64-bit fixed point for the LDS accumulators -------------------------------------------------------
+// value = x * 2^shift, stored as a two's-complement int64. fx_hi = 2^(shift-32) is passed around as a float.
+struct FixScale {
+    float hi;    // 2^(shift-32): x*hi has the high word in its integer part, the low word in its fraction
+    float lim;   // adjoints are clamped to +-lim = 2^20 * max|grad_out| (keeps every sum inside 63 bits)
+    double inv;  // 2^-shift
+};
+__device__ __forceinline__ FixScale make_fix_scale(unsigned int gmax_bits) {
+    float gmax = __uint_as_float(gmax_bits);
+    if (!(gmax > 0.0f) || !(gmax < 3.0e38f)) gmax = 1.0f;  // all-zero or non-finite upstream gradient
+    int e;
+    frexpf(gmax, &e);            // gmax < 2^e
+    const int shift = 28 - e;    // gmax * 2^shift < 2^28
+    FixScale f;
+    f.hi = ldexpf(1.0f, shift - 32);
+    f.lim = ldexpf(1.0f, e + 20);
+    f.inv = ldexp(1.0, -shift);
+    return f;
+}
+__device__ __forceinline__ float fix_clamp(float x, const FixScale &f) {
+    return fminf(fmaxf(x, -f.lim), f.lim);  // NaN -> -lim (finite), as nan_to_num would make it finite later
+}
+__device__ __forceinline__ void fix_add(unsigned long long *p, float x, const FixScale &f) {
+    const float t = x * f.hi;
+    const float hf = floorf(t);
+    const unsigned int lo = (unsigned int)((t - hf) * 4294967296.0f);  // fraction in [0,1): exact product
+    const unsigned long long v = ((unsigned long long)(unsigned int)(int)hf << 32) | lo;
+    atomicAdd(p, v);  // ds_add_u64
+}
+__device__ __forceinline__ float fix_to_float(unsigned long long v, const FixScale &f) {
+    return (float)((double)(long long)v * f.inv);
+}
+
+// adjoint of tri_lds into the fixed-point LDS box
+__device__ __forceinline__ void tri_scatter_lds(unsigned long long *dbox, int base, float fx, float fy, float fz,
+                                                float adj, const FixScale &f) {
     const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;
-    atomicAdd(dbox + base, gx * gy * gz * adj);
-    atomicAdd(dbox + base + BOX_SX, fx * gy * gz * adj);
-    atomicAdd(dbox + base + BOX_SY, gx * fy * gz * adj);
-    atomicAdd(dbox + base + BOX_SX + BOX_SY, fx * fy * gz * adj);
-    atomicAdd(dbox + base + 1, gx * gy * fz * adj);
-    atomicAdd(dbox + base + BOX_SX + 1, fx * gy * fz * adj);
-    atomicAdd(dbox + base + BOX_SY + 1, gx * fy * fz * adj);
-    atomicAdd(dbox + base + BOX_SX + BOX_SY + 1, fx * fy * fz * adj);
+    const float a00 = gx * gy * adj, a10 = fx * gy * adj, a01 = gx * fy * adj, a11 = fx * fy * adj;
+    fix_add(dbox + base, a00 * gz, f);
+    fix_add(dbox + base + BOX_SX, a10 * gz, f);
+    fix_add(dbox + base + BOX_SY, a01 * gz, f);
+    fix_add(dbox + base + BOX_SX + BOX_SY, a11 * gz, f);
+    fix_add(dbox + base + 1, a00 * fz, f);
+    fix_add(dbox + base + BOX_SX + 1, a10 * fz, f);
+    fix_add(dbox + base + BOX_SY + 1, a01 * fz, f);
+    fix_add(dbox + base + BOX_SX + BOX_SY + 1, a11 * fz, f);
+}
+
+// max |x| over a buffer -> bits of the (non-negative) float, combined with atomicMax on the integer view
+__global__ __launch_bounds__(256) void absmax_kernel(const float *x, size_t n, unsigned int *out_bits) {
+    float m = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float v = fabsf(x[i]);
+        m = (v > m) ? v : m;  // NaN never wins
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(out_bits, __float_as_uint(fminf(m, 3.0e38f)));
 }
 
 template <typename VT, bool WANT_VOL, bool WANT_TF>
@@ -445,8 +497,9 @@ __global__ __launch_bounds__(256) void brick_bwd_kernel(BrickParams<VT> P) {
     VolView<VT> vol = P.vol;
     vol.p += view * P.vol_vs;
     load_tf_and_box(P, vol, c, P.tf + view * P.tf_vs, L);
-    if (WANT_VOL) for (int k = threadIdx.x; k < BOX_N; k += 256) L.dbox[k] = 0.0f;
-    if (WANT_TF) for (int k = threadIdx.x; k < 4 * P.R; k += 256) L.dtf[k] = 0.0f;
+    if (WANT_VOL) for (int k = threadIdx.x; k < BOX_N; k += 256) L.dbox[k] = 0ull;
+    if (WANT_TF) for (int k = threadIdx.x; k < 4 * P.R; k += 256) L.dtf[k] = 0ull;
+    const FixScale fs = make_fix_scale(P.stats[1]);
     const f3 light = make_f3(cam.x + 0.0f, cam.y + 1.0f, cam.z + 0.0f);
     const int NP = P.W * P.H;
     const size_t seg_base = ((size_t)view * P.g.NL + c.layer) * NP;
@@ -469,6 +522,10 @@ __global__ __launch_bounds__(256) void brick_bwd_kernel(BrickParams<VT> P) {
             const float4 go = reinterpret_cast<const float4 *>(P.grad_out)[p];
             const float4 of = reinterpret_cast<const float4 *>(P.out_fwd)[p];
             float C0 = pre.x, C1 = pre.y, C2 = pre.z, A = pre.w;
+            // d_tf: consecutive samples of a ray mostly fall between the same two texels, so the eight
+            // texel contributions are summed in registers and only flushed when the texel pair changes
+            int tf_lo = -1, tf_hi = -1;
+            float t0r = 0.f, t0g = 0.f, t0b = 0.f, t0a = 0.f, t1r = 0.f, t1g = 0.f, t1b = 0.f, t1a = 0.f;
             for (int s = s0; s < s0 + cnt; ++s) {
                 Sample sm; TapCoords t;
                 if (!sample_coords(vol, c, rg, cam, s, sm, t)) continue;
@@ -486,26 +543,40 @@ __global__ __launch_bounds__(256) void brick_bwd_kernel(BrickParams<VT> P) {
                 SampleAdj ad;
                 sample_adjoint(sm, vd, T, suffix, last, go, P.inv_sr, ad);
                 if (WANT_TF) {
+                    if (sm.lo != tf_lo) {
+                        if (tf_lo >= 0) {
+                            fix_add(L.dtf + 4 * tf_lo + 0, fix_clamp(t0r, fs), fs); fix_add(L.dtf + 4 * tf_lo + 1, fix_clamp(t0g, fs), fs);
+                            fix_add(L.dtf + 4 * tf_lo + 2, fix_clamp(t0b, fs), fs); fix_add(L.dtf + 4 * tf_lo + 3, fix_clamp(t0a, fs), fs);
+                            fix_add(L.dtf + 4 * tf_hi + 0, fix_clamp(t1r, fs), fs); fix_add(L.dtf + 4 * tf_hi + 1, fix_clamp(t1g, fs), fs);
+                            fix_add(L.dtf + 4 * tf_hi + 2, fix_clamp(t1b, fs), fs); fix_add(L.dtf + 4 * tf_hi + 3, fix_clamp(t1a, fs), fs);
+                        }
+                        tf_lo = sm.lo; tf_hi = sm.hi;
+                        t0r = t0g = t0b = t0a = t1r = t1g = t1b = t1a = 0.f;
+                    }
                     const float w0 = 1.0f - sm.fr, w1 = sm.fr;
-                    float *d0 = L.dtf + 4 * sm.lo, *d1 = L.dtf + 4 * sm.hi;
-                    atomicAdd(d0 + 0, w0 * ad.r_bar); atomicAdd(d0 + 1, w0 * ad.g_bar);
-                    atomicAdd(d0 + 2, w0 * ad.b_bar); atomicAdd(d0 + 3, w0 * ad.a_bar);
-                    atomicAdd(d1 + 0, w1 * ad.r_bar); atomicAdd(d1 + 1, w1 * ad.g_bar);
-                    atomicAdd(d1 + 2, w1 * ad.b_bar); atomicAdd(d1 + 3, w1 * ad.a_bar);
+                    t0r = fmaf(w0, ad.r_bar, t0r); t0g = fmaf(w0, ad.g_bar, t0g); t0b = fmaf(w0, ad.b_bar, t0b); t0a = fmaf(w0, ad.a_bar, t0a);
+                    t1r = fmaf(w1, ad.r_bar, t1r); t1g = fmaf(w1, ad.g_bar, t1g); t1b = fmaf(w1, ad.b_bar, t1b); t1a = fmaf(w1, ad.a_bar, t1a);
                 }
                 if (WANT_VOL) {
-                    const float I_bar = intensity_adjoint(sm, L.tf[sm.lo], L.tf[sm.hi], ad, P.tf_len);
+                    const float I_bar = fix_clamp(intensity_adjoint(sm, L.tf[sm.lo], L.tf[sm.hi], ad, P.tf_len), fs);
                     const int by = t.ly * BOX_SY, bz = t.lz, bx = t.lx * BOX_SX;
-                    tri_scatter_lds(L.dbox, bx + by + bz, t.fx, t.fy, t.fz, I_bar);
+                    tri_scatter_lds(L.dbox, bx + by + bz, t.fx, t.fy, t.fz, I_bar, fs);
                     if (!sm.flat) {
-                        tri_scatter_lds(L.dbox, t.lxp * BOX_SX + by + bz, t.fxp, t.fy, t.fz, ad.gx);
-                        tri_scatter_lds(L.dbox, t.lxm * BOX_SX + by + bz, t.fxm, t.fy, t.fz, -ad.gx);
-                        tri_scatter_lds(L.dbox, bx + t.lyp * BOX_SY + bz, t.fx, t.fyp, t.fz, ad.gy);
-                        tri_scatter_lds(L.dbox, bx + t.lym * BOX_SY + bz, t.fx, t.fym, t.fz, -ad.gy);
-                        tri_scatter_lds(L.dbox, bx + by + t.lzp, t.fx, t.fy, t.fzp, ad.gz);
-                        tri_scatter_lds(L.dbox, bx + by + t.lzm, t.fx, t.fy, t.fzm, -ad.gz);
+                        const float gx = fix_clamp(ad.gx, fs), gy = fix_clamp(ad.gy, fs), gz = fix_clamp(ad.gz, fs);
+                        tri_scatter_lds(L.dbox, t.lxp * BOX_SX + by + bz, t.fxp, t.fy, t.fz, gx, fs);
+                        tri_scatter_lds(L.dbox, t.lxm * BOX_SX + by + bz, t.fxm, t.fy, t.fz, -gx, fs);
+                        tri_scatter_lds(L.dbox, bx + t.lyp * BOX_SY + bz, t.fx, t.fyp, t.fz, gy, fs);
+                        tri_scatter_lds(L.dbox, bx + t.lym * BOX_SY + bz, t.fx, t.fym, t.fz, -gy, fs);
+                        tri_scatter_lds(L.dbox, bx + by + t.lzp, t.fx, t.fy, t.fzp, gz, fs);
+                        tri_scatter_lds(L.dbox, bx + by + t.lzm, t.fx, t.fy, t.fzm, -gz, fs);
                     }
                 }
+            }
+            if (WANT_TF && tf_lo >= 0) {
+                fix_add(L.dtf + 4 * tf_lo + 0, fix_clamp(t0r, fs), fs); fix_add(L.dtf + 4 * tf_lo + 1, fix_clamp(t0g, fs), fs);
+                fix_add(L.dtf + 4 * tf_lo + 2, fix_clamp(t0b, fs), fs); fix_add(L.dtf + 4 * tf_lo + 3, fix_clamp(t0a, fs), fs);
+                fix_add(L.dtf + 4 * tf_hi + 0, fix_clamp(t1r, fs), fs); fix_add(L.dtf + 4 * tf_hi + 1, fix_clamp(t1g, fs), fs);
+                fix_add(L.dtf + 4 * tf_hi + 2, fix_clamp(t1b, fs), fs); fix_add(L.dtf + 4 * tf_hi + 3, fix_clamp(t1a, fs), fs);
             }
         }
         __syncthreads();
@@ -520,8 +591,9 @@ __global__ __launch_bounds__(256) void brick_bwd_kernel(BrickParams<VT> P) {
             const int a = idx % BOX, b = (idx / BOX) % BOX, d = idx / (BOX * BOX);
             int lx, ly, lz;
             if (fast == 0) { lx = a; ly = b; lz = d; } else if (fast == 1) { ly = a; lx = b; lz = d; } else { lz = a; ly = b; lx = d; }
-            const float v = L.dbox[lx * BOX_SX + ly * BOX_SY + lz];
-            if (v != 0.0f) {
+            const unsigned long long raw = L.dbox[lx * BOX_SX + ly * BOX_SY + lz];
+            if (raw != 0ull) {
+                const float v = fix_to_float(raw, fs);
                 const int gx = c.ox + lx, gy = c.oy + ly, gz = c.oz + lz;  // in range whenever v != 0
                 unsafeAtomicAdd(dv.p + gx * dv.sx + gy * dv.sy + gz * dv.sz, v);
             }
@@ -530,8 +602,8 @@ __global__ __launch_bounds__(256) void brick_bwd_kernel(BrickParams<VT> P) {
     if (WANT_TF) {
         float *dtf = P.d_tf + view * P.dtf_vs * 4;
         for (int k = threadIdx.x; k < 4 * P.R; k += 256) {
-            const float v = L.dtf[k];
-            if (v != 0.0f) unsafeAtomicAdd(dtf + k, v);
+            const unsigned long long raw = L.dtf[k];
+            if (raw != 0ull) unsafeAtomicAdd(dtf + k, fix_to_float(raw, fs));
         }
     }
 }
@@ -642,7 +714,11 @@ static int brick_bwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     const bool wv = a.d_vol != nullptr, wt = a.d_tf != nullptr;
     const size_t lds = brick_lds_bytes(a.R, wv, wt);
     const dim3 grid1(g.NBx * g.NBy * g.NBz, a.n_views);
-    hipError_t e;
+    hipError_t e = hipMemsetAsync(w.stats + 1, 0, 4, stream);
+    if (e != hipSuccess) return (int)e;
+    const size_t ng = (size_t)a.n_views * NP * 4;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)((ng + 256 * 16 - 1) / (256 * 16)) > 1024u ? 1024u : (unsigned)((ng + 256 * 16 - 1) / (256 * 16))),
+                       dim3(256), 0, stream, a.grad_out, ng, w.stats + 1);
     if (wv && wt) {
         if ((e = allow_lds(brick_bwd_kernel<VT, true, true>, lds)) != hipSuccess) return (int)e;
         hipLaunchKernelGGL((brick_bwd_kernel<VT, true, true>), grid1, dim3(256), lds, stream, P);
