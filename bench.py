@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--vol", type=int, default=512)
     ap.add_argument("--img", type=int, default=512)
     ap.add_argument("--tf-res", type=int, default=256)
-    ap.add_argument("--grads", default="vol+tf", choices=["vol+tf", "tf", "none"],
+    ap.add_argument("--grads", default="vol+tf", choices=["vol+tf", "tf", "vol", "none"],
                     help="vol+tf = C4 (default); tf = C3; none = forward only (C2-style)")
     ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 baseline kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -91,8 +91,9 @@ def main():
     from differender_amd.distributed import all_reduce_gradients
 
     N, IMG, R = args.vol, args.img, args.tf_res
-    want_vol = args.grads == "vol+tf"
+    want_vol = args.grads in ("vol+tf", "vol")
     want_tf = args.grads in ("vol+tf", "tf")
+    want_bwd = want_vol or want_tf
     # n_max <= 2*sqrt(3)*diag ~ 3.47*N*sqrt(3): alpha = 3/n_max keeps early termination from firing
     n_max = 2.0 * math.sqrt(3.0) * math.sqrt(3.0) * (N - 1)
     alpha = 3.0 / n_max
@@ -117,12 +118,12 @@ def main():
         out, steps = F.march_fwd(vol, tf, cam, e, x, r, n, S, sr, variant=args.variant, workspace=ws)
         if timed:
             a1.record(); ev["fwd"].append((a0, a1))
-        if want_tf:
+        if want_bwd:
             grad_out = (out - target) * (2.0 / out.numel())
             if timed:
                 b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 b0.record()
-            dv, dt = F.march_bwd(vol, tf, cam, e, x, r, n, S, sr, grad_out, out, want_vol=want_vol, want_tf=True,
+            dv, dt = F.march_bwd(vol, tf, cam, e, x, r, n, S, sr, grad_out, out, want_vol=want_vol, want_tf=want_tf,
                                  variant=args.variant, workspace=ws)
             if timed:
                 b1.record(); ev["bwd"].append((b0, b1))
@@ -151,7 +152,7 @@ def main():
         dist.all_reduce(total_steps, op=dist.ReduceOp.SUM)
     elapsed = float(el.item())
     vsteps = int(total_steps.item())
-    passes = 2 if want_tf else 1  # a voxel-step counted once per marched sample of the fwd(+bwd) pass
+    passes = 2 if want_bwd else 1  # a voxel-step counted once per marched sample of the fwd(+bwd) pass
 
     fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in ev["fwd"]]))
     bwd_ms = float(np.mean([a.elapsed_time(b) for a, b in ev["bwd"]])) if ev["bwd"] else 0.0
@@ -164,7 +165,7 @@ def main():
                 "bytes_per_voxel_step": bytes_per_step, "voxel_steps_per_launch": int(steps_per_launch)}
 
     roof_fwd = roof("march_fwd", fwd_ms, B_FWD)
-    roof_bwd = roof("march_bwd", bwd_ms, B_BWD_VOL if want_vol else B_BWD_TF) if want_tf else None
+    roof_bwd = roof("march_bwd", bwd_ms, B_BWD_VOL if want_vol else B_BWD_TF) if want_bwd else None
     dominant = roof_bwd if (roof_bwd and bwd_ms >= fwd_ms) else roof_fwd
 
     cpu_baseline = None
@@ -175,7 +176,7 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         workload = {"vol+tf": "C4: fwd+bwd w.r.t. volume and TF", "tf": "C3: fwd+bwd w.r.t. TF",
-                    "none": "forward only"}[args.grads]
+                    "vol": "fwd+bwd w.r.t. volume", "none": "forward only"}[args.grads]
         line = {
             "metric": "Mvoxel-steps/s fwd+bwd, 512^3 vol @ 512^2 img",
             "value": round(vsteps / elapsed / 1e6, 3),
@@ -217,14 +218,14 @@ def run_cpu_baseline(vol, tf, args, sr, want_vol, want_tf):
     e, x, r, n = O.ray_setup(cam, W, W, (N, N, N), sr)
     t0 = time.perf_counter()
     out, steps = O.march_fwd(vol_h, tf_h, cam, e, x, r, n, 1 << 20, sr, 0)
-    if want_tf:
+    if want_vol or want_tf:
         g = (2.0 / out.size) * (out - 0.5)
-        O.march_bwd(vol_h, tf_h, cam, e, x, r, n, 1 << 20, sr, g.astype(np.float32), want_vol, True)
+        O.march_bwd(vol_h, tf_h, cam, e, x, r, n, 1 << 20, sr, g.astype(np.float32), want_vol, want_tf)
     dt = time.perf_counter() - t0
     nst = int(steps.sum())
     return {"value": round(nst / dt / 1e6, 4), "unit": "Mvoxel-steps/s", "cores": cores, "kind": "port",
             "sample": f"same {N}^3 volume/TF, camera in_circles(0), {W}x{W} image "
-                      f"({nst} voxel-steps, fwd{'+bwd' if want_tf else ''}), C oracle with OpenMP, {dt:.1f} s"}
+                      f"({nst} voxel-steps, fwd{'+bwd' if (want_tf or want_vol) else ''}), C oracle with OpenMP, {dt:.1f} s"}
 
 
 if __name__ == "__main__":

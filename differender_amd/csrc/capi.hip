@@ -67,11 +67,12 @@ int dr_march_fwd(const void *vol, int vol_dtype, int VX, int VY, int VZ, int64_t
     if (rc) return rc;
     if (!out_rgba) return DR_EINVAL;
     if (mode != DR_MODE_DIFF && mode != DR_MODE_NONDIFF) return DR_EINVAL;
-    if (variant != DR_VARIANT_AUTO && variant != DR_VARIANT_BASELINE) return DR_EINVAL;
+    if (variant < DR_VARIANT_AUTO || variant > DR_VARIANT_BRICK_RAYSEG) return DR_EINVAL;
     a.mode = mode; a.out = out_rgba; a.steps = steps;
     a.fov_rad = fov_rad; a.near_plane = near_plane; a.workspace = workspace; a.workspace_bytes = workspace_bytes;
-    if (variant == DR_VARIANT_AUTO && workspace && brick_path_supported(VX, VY, VZ, R)) {
+    if (variant != DR_VARIANT_BASELINE && workspace && brick_path_supported(VX, VY, VZ, R)) {
         if (workspace_bytes < brick_workspace_bytes(n_views, W, H, VX, VY, VZ)) return DR_EINVAL;
+        if (variant == DR_VARIANT_AUTO && flat_path_supported(VX, VY, VZ, R)) return launch_march_fwd_flat(a, (hipStream_t)stream);
         return launch_march_fwd_brick(a, (hipStream_t)stream);
     }
     return launch_march_fwd_baseline(a, (hipStream_t)stream);
@@ -89,7 +90,7 @@ int dr_march_bwd(const void *vol, int vol_dtype, int VX, int VY, int VZ, int64_t
                          entry, exit_, rays, nsamp, n_views, W, H, max_samples, sampling_rate);
     if (rc) return rc;
     if (!grad_out || !out_rgba) return DR_EINVAL;
-    if (variant != DR_VARIANT_AUTO && variant != DR_VARIANT_BASELINE) return DR_EINVAL;
+    if (variant < DR_VARIANT_AUTO || variant > DR_VARIANT_BRICK_RAYSEG) return DR_EINVAL;
     if (dtf_view_stride % 4 != 0) return DR_EINVAL;
     if (!d_vol && !d_tf) return 0;  // nothing requested
     a.mode = DR_MODE_DIFF;
@@ -97,8 +98,9 @@ int dr_march_bwd(const void *vol, int vol_dtype, int VX, int VY, int VZ, int64_t
     a.d_vol = d_vol; a.dsx = dsx; a.dsy = dsy; a.dsz = dsz; a.dvol_vs = dvol_view_stride;
     a.d_tf = d_tf; a.dtf_vs = dtf_view_stride;
     a.fov_rad = fov_rad; a.near_plane = near_plane; a.workspace = workspace; a.workspace_bytes = workspace_bytes;
-    if (variant == DR_VARIANT_AUTO && workspace && brick_path_supported(VX, VY, VZ, R)) {
+    if (variant != DR_VARIANT_BASELINE && workspace && brick_path_supported(VX, VY, VZ, R)) {
         if (workspace_bytes < brick_workspace_bytes(n_views, W, H, VX, VY, VZ)) return DR_EINVAL;
+        if (variant == DR_VARIANT_AUTO && flat_path_supported(VX, VY, VZ, R)) return launch_march_bwd_flat(a, (hipStream_t)stream);
         return launch_march_bwd_brick(a, (hipStream_t)stream);
     }
     return launch_march_bwd_baseline(a, (hipStream_t)stream);

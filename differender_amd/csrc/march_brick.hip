@@ -24,249 +24,9 @@
 //
 // Reference functions replaced: raycast / raycast_nondiff / get_final_image[_nondiff] (VR.py:261-372) and
 // their Taichi-autodiff twins (VR.py:460-461,470-471).
-#include "dr_brick.h"
-#include "dr_kernels.h"
-#include "../../include/differender_hip.h"
+#include "dr_brick_common.h"
 
 namespace dr {
-
-template <typename VT>
-struct BrickParams {
-    VolView<VT> vol; int64_t vol_vs;
-    const float4 *tf; int64_t tf_vs; int R; float tf_len;
-    const float *cam, *entry, *exit_, *rays; const int32_t *nsamp;
-    int W, H, S; float sr, inv_sr;
-    float near_, near_w, near_h;
-    BrickGrid g;
-    float4 *seg_rgba;    // [view][NL][NP]: F1 partial composite, then (F2) prefix before the segment
-    int32_t *seg_cnt;    // [view][NL][NP]: samples of the ray inside the brick of that layer
-    uint8_t *rayflag;    // [view][NP]: 1 = irregular ray (marched whole by F2 / B2)
-    int32_t *ws_steps;   // [view][NP]: live samples per ray (F2 -> B1)
-    unsigned int *stats; // [0] rays repaired by the count check, [1] bits of max|grad_out| (backward)
-    float *out; int32_t *steps;
-    const float *grad_out, *out_fwd;
-    GradView dvol; int64_t dvol_vs;
-    float *d_tf; int64_t dtf_vs;
-};
-
-struct BrickCtx {
-    int bx, by, bz, layer;
-    int ox, oy, oz;               // voxel index of LDS box element 0 along each axis (16*b - 1)
-    float lo[3], hi[3];           // world AABB of the brick's cells, with slack
-    int i0, i1, j0, j1;           // candidate pixel rectangle (inclusive); empty if i0 > i1
-};
-
-__device__ __forceinline__ f3 cross3b(f3 a, f3 b) {
-    return make_f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
-}
-
-// Brick geometry + its projected pixel rectangle (pinhole model of VR.py:127-151).
-template <typename VT>
-__device__ __forceinline__ void brick_setup(const BrickParams<VT> &P, int b, f3 cam, BrickCtx &c) {
-    const BrickGrid &g = P.g;
-    c.bz = b % g.NBz; c.by = (b / g.NBz) % g.NBy; c.bx = b / (g.NBz * g.NBy);
-    c.ox = c.bx * BRK - 1; c.oy = c.by * BRK - 1; c.oz = c.bz * BRK - 1;
-    const int cbx = cam_brick(cam.x, P.vol.scx), cby = cam_brick(cam.y, P.vol.scy), cbz = cam_brick(cam.z, P.vol.scz);
-    const int lmin = axis_layer_min(cbx, g.NBx) + axis_layer_min(cby, g.NBy) + axis_layer_min(cbz, g.NBz);
-    c.layer = abs(c.bx - cbx) + abs(c.by - cby) + abs(c.bz - cbz) - lmin;
-    const int bb[3] = {c.bx, c.by, c.bz};
-    const int nb[3] = {g.NBx, g.NBy, g.NBz};
-    const float sc[3] = {P.vol.scx, P.vol.scy, P.vol.scz};
-    for (int k = 0; k < 3; ++k) {
-        // cell range [16b, 16b+16) in scaled coordinates q = (0.5 x + 0.5) sc  ->  x = 2 q / sc - 1
-        float lo = 2.0f * (float)(bb[k] * BRK) / sc[k] - 1.0f;
-        float hi = 2.0f * (float)(bb[k] * BRK + BRK) / sc[k] - 1.0f;
-        if (bb[k] == 0) lo = -1.0f;          // positions are clamped into the edge cells
-        if (bb[k] == nb[k] - 1) hi = 1.0f;
-        c.lo[k] = lo - BRICK_EPS; c.hi[k] = hi + BRICK_EPS;
-    }
-    const f3 vdir = normalized3(make_f3(-cam.x, -cam.y, -cam.z));
-    const f3 right = normalized3(cross3b(vdir, make_f3(0.f, 1.f, 0.f)));
-    const f3 up = normalized3(cross3b(right, vdir));
-    float pxmin = 1e30f, pxmax = -1e30f, pymin = 1e30f, pymax = -1e30f;
-    bool behind = false;
-    for (int k = 0; k < 8; ++k) {
-        const f3 d = make_f3(((k & 1) ? c.hi[0] : c.lo[0]) - cam.x, ((k & 2) ? c.hi[1] : c.lo[1]) - cam.y,
-                             ((k & 4) ? c.hi[2] : c.lo[2]) - cam.z);
-        const float depth = dot3(d, vdir);
-        if (!(depth > 1e-3f)) { behind = true; continue; }
-        const float u = dot3(d, right) / depth * (P.near_ / P.near_w);
-        const float v = dot3(d, up) / depth * (P.near_ / P.near_h);
-        const float px = (u + 0.5f) * (float)P.W - 0.5f, py = (v + 0.5f) * (float)P.H - 0.5f;
-        pxmin = fminf(pxmin, px); pxmax = fmaxf(pxmax, px); pymin = fminf(pymin, py); pymax = fmaxf(pymax, py);
-    }
-    if (behind) { c.i0 = 0; c.i1 = P.W - 1; c.j0 = 0; c.j1 = P.H - 1; return; }
-    pxmin = fmaxf(pxmin, -2.0f); pymin = fmaxf(pymin, -2.0f);
-    pxmax = fminf(pxmax, (float)P.W + 2.0f); pymax = fminf(pymax, (float)P.H + 2.0f);
-    c.i0 = max(0, (int)floorf(pxmin) - 1); c.i1 = min(P.W - 1, (int)ceilf(pxmax) + 1);
-    c.j0 = max(0, (int)floorf(pymin) - 1); c.j1 = min(P.H - 1, (int)ceilf(pymax) + 1);
-}
-
-// Conservative sample-index range [s0, s1) of ray p inside the brick (exact membership is decided per
-// sample from its cell). Returns false when the ray cannot touch the brick.
-__device__ __forceinline__ bool segment_range(const BrickCtx &c, f3 cam, f3 vd, float t0, float exit_, int n,
-                                              int nmarch, int &s0, int &s1) {
-    const float o[3] = {cam.x, cam.y, cam.z}, d[3] = {vd.x, vd.y, vd.z};
-    float ta = -1e30f, tb = 1e30f;
-    for (int k = 0; k < 3; ++k) {
-        if (fabsf(d[k]) < 1e-12f) {
-            if (o[k] < c.lo[k] || o[k] > c.hi[k]) return false;
-        } else {
-            const float inv = 1.0f / d[k];
-            const float t1 = (c.lo[k] - o[k]) * inv, t2 = (c.hi[k] - o[k]) * inv;
-            ta = fmaxf(ta, fminf(t1, t2)); tb = fminf(tb, fmaxf(t1, t2));
-        }
-    }
-    if (!(ta <= tb)) return false;
-    const float scale = (float)(n - 1) / (exit_ - t0);
-    float sa = floorf((ta - t0) * scale) - 1.0f, sb = ceilf((tb - t0) * scale) + 2.0f;
-    sa = fminf(fmaxf(sa, 0.0f), (float)nmarch); sb = fminf(fmaxf(sb, 0.0f), (float)nmarch);
-    s0 = (int)sa; s1 = (int)sb;
-    return s1 > s0;
-}
-
-struct LdsLayout {
-    float4 *tf; float *box; unsigned long long *dbox; unsigned long long *dtf;
-    int *e_pix, *e_s0, *e_cnt; unsigned short *order; int *hist; int *misc;
-};
-__host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
-__host__ __device__ inline size_t brick_lds_bytes(int R, bool bwd_vol, bool bwd_tf) {
-    size_t s = (size_t)R * 16 + align16(BOX_N * 4);
-    if (bwd_vol) s += align16(BOX_N * 8);
-    if (bwd_tf) s += (size_t)R * 32;
-    s += 3 * ECHUNK * 4 + ECHUNK * 2 + 128 * 4 + 16;
-    return s;
-}
-__device__ __forceinline__ LdsLayout carve(unsigned char *smem, int R, bool bwd_vol, bool bwd_tf) {
-    LdsLayout L;
-    size_t o = 0;
-    L.tf = reinterpret_cast<float4 *>(smem + o); o += (size_t)R * 16;
-    L.box = reinterpret_cast<float *>(smem + o); o += align16(BOX_N * 4);
-    L.dbox = nullptr; L.dtf = nullptr;
-    if (bwd_vol) { L.dbox = reinterpret_cast<unsigned long long *>(smem + o); o += align16(BOX_N * 8); }
-    if (bwd_tf) { L.dtf = reinterpret_cast<unsigned long long *>(smem + o); o += (size_t)R * 32; }
-    L.e_pix = reinterpret_cast<int *>(smem + o); o += ECHUNK * 4;
-    L.e_s0 = reinterpret_cast<int *>(smem + o); o += ECHUNK * 4;
-    L.e_cnt = reinterpret_cast<int *>(smem + o); o += ECHUNK * 4;
-    L.order = reinterpret_cast<unsigned short *>(smem + o); o += ECHUNK * 2;
-    L.hist = reinterpret_cast<int *>(smem + o); o += 128 * 4;
-    L.misc = reinterpret_cast<int *>(smem + o);
-    return L;
-}
-
-// Stage TF and the brick's voxel box in LDS. Global reads walk the axis with the smallest stride.
-template <typename VT>
-__device__ __forceinline__ void load_tf_and_box(const BrickParams<VT> &P, const VolView<VT> &vol, const BrickCtx &c,
-                                                const float4 *tfg, LdsLayout &L) {
-    for (int k = threadIdx.x; k < P.R; k += 256) L.tf[k] = tfg[k];
-    const int fast = (vol.sx <= vol.sy && vol.sx <= vol.sz) ? 0 : ((vol.sy <= vol.sz) ? 1 : 2);
-    for (int idx = threadIdx.x; idx < BOX_N; idx += 256) {
-        const int a = idx % BOX, b = (idx / BOX) % BOX, d = idx / (BOX * BOX);
-        int lx, ly, lz;
-        if (fast == 0) { lx = a; ly = b; lz = d; } else if (fast == 1) { ly = a; lx = b; lz = d; } else { lz = a; ly = b; lx = d; }
-        const int gx = c.ox + lx, gy = c.oy + ly, gz = c.oz + lz;
-        float v = 0.0f;
-        if (gx >= 0 && gx < vol.VX && gy >= 0 && gy < vol.VY && gz >= 0 && gz < vol.VZ)
-            v = ld_voxel(vol.p + gx * vol.sx + gy * vol.sy + gz * vol.sz);
-        L.box[lx * BOX_SX + ly * BOX_SY + lz] = v;
-    }
-}
-
-// One round of segment listing: candidates [cbase, cbase+ECHUNK) of the pixel rectangle -> sorted entry list.
-// SKIPFLAG: backward skips irregular rays (flagged by F2) and clips to the live sample count.
-template <typename VT, bool BWD>
-__device__ __forceinline__ int build_entries(const BrickParams<VT> &P, const BrickCtx &c, f3 cam, int view, int cbase,
-                                             int ncand, int mode, LdsLayout &L) {
-    const int NP = P.W * P.H;
-    if (threadIdx.x < 128) L.hist[threadIdx.x] = 0;
-    if (threadIdx.x == 0) L.misc[0] = 0;
-    __syncthreads();
-    const int nj = c.j1 - c.j0 + 1;
-    const int cend = min(ncand, cbase + ECHUNK);
-    for (int cc = cbase + threadIdx.x; cc < cend; cc += 256) {
-        const int i = c.i0 + cc / nj, j = c.j0 + cc % nj;
-        const int pl = i * P.H + j;
-        const size_t p = (size_t)view * NP + pl;
-        const int n = P.nsamp[p];
-        const float entry = P.entry[p];
-        if (!ray_is_regular(n, entry)) continue;
-        int nmarch = (mode == DR_MODE_DIFF && n > P.S) ? P.S : n;
-        if (BWD) {
-            if (P.rayflag[p]) continue;
-            nmarch = min(nmarch, P.ws_steps[p]);
-        }
-        const float exit_ = P.exit_[p];
-        const f3 vd = make_f3(P.rays[3 * p], P.rays[3 * p + 1], P.rays[3 * p + 2]);
-        const float t0 = entry + 0.5f * (exit_ - entry) / (float)n;
-        int s0, s1;
-        if (!segment_range(c, cam, vd, t0, exit_, n, nmarch, s0, s1)) continue;
-        const int slot = atomicAdd(&L.misc[0], 1);
-        L.e_pix[slot] = pl; L.e_s0[slot] = s0; L.e_cnt[slot] = s1 - s0;
-        atomicAdd(&L.hist[min(s1 - s0, 127)], 1);
-    }
-    __syncthreads();
-    const int nE = L.misc[0];
-    // descending counting sort by segment length
-    int start = 0;
-    if (threadIdx.x < 128) {
-        for (int k = threadIdx.x + 1; k < 128; ++k) start += L.hist[k];
-    }
-    __syncthreads();
-    if (threadIdx.x < 128) L.hist[threadIdx.x] = start;
-    __syncthreads();
-    for (int e = threadIdx.x; e < nE; e += 256) {
-        const int pos = atomicAdd(&L.hist[min(L.e_cnt[e], 127)], 1);
-        L.order[pos] = (unsigned short)e;
-    }
-    __syncthreads();
-    return nE;
-}
-
-struct TapCoords {
-    int lx, ly, lz;       // local (box) cell of the centre tap
-    float fx, fy, fz;
-    int lxp, lxm, lyp, lym, lzp, lzm;  // local cells of the +-delta taps along each axis
-    float fxp, fxm, fyp, fym, fzp, fzm;
-};
-
-// All seven taps of one sample from the LDS box: intensity and central differences.
-__device__ __forceinline__ void sample_taps_lds(const float *box, const TapCoords &t, float &I, float &dx, float &dy,
-                                                float &dz) {
-    const int by = t.ly * BOX_SY, bz = t.lz, bx = t.lx * BOX_SX;
-    I = tri_lds(box, bx + by + bz, t.fx, t.fy, t.fz);
-    dx = tri_lds(box, t.lxp * BOX_SX + by + bz, t.fxp, t.fy, t.fz) - tri_lds(box, t.lxm * BOX_SX + by + bz, t.fxm, t.fy, t.fz);
-    dy = tri_lds(box, bx + t.lyp * BOX_SY + bz, t.fx, t.fyp, t.fz) - tri_lds(box, bx + t.lym * BOX_SY + bz, t.fx, t.fym, t.fz);
-    dz = tri_lds(box, bx + by + t.lzp, t.fx, t.fy, t.fzp) - tri_lds(box, bx + by + t.lzm, t.fx, t.fy, t.fzm);
-}
-
-// Position of sample s and its tap coordinates; returns whether the sample's cell lies in this brick.
-template <typename VT>
-__device__ __forceinline__ bool sample_coords(const VolView<VT> &vol, const BrickCtx &c, const RayGeom &rg, f3 cam,
-                                              int s, Sample &sm, TapCoords &t) {
-    sample_pos(rg, cam.x, cam.y, cam.z, s, sm.px, sm.py, sm.pz);
-    int x0, y0, z0;
-    axis_coord(sm.px, vol.scx, x0, t.fx);
-    axis_coord(sm.py, vol.scy, y0, t.fy);
-    axis_coord(sm.pz, vol.scz, z0, t.fz);
-    if ((x0 >> 4) != c.bx || (y0 >> 4) != c.by || (z0 >> 4) != c.bz) return false;
-    const float delta = 1e-3f;
-    int k;
-    t.lx = x0 - c.ox; t.ly = y0 - c.oy; t.lz = z0 - c.oz;
-    axis_coord(sm.px + delta, vol.scx, k, t.fxp); t.lxp = k - c.ox;
-    axis_coord(sm.px - delta, vol.scx, k, t.fxm); t.lxm = k - c.ox;
-    axis_coord(sm.py + delta, vol.scy, k, t.fyp); t.lyp = k - c.oy;
-    axis_coord(sm.py - delta, vol.scy, k, t.fym); t.lym = k - c.oy;
-    axis_coord(sm.pz + delta, vol.scz, k, t.fzp); t.lzp = k - c.oz;
-    axis_coord(sm.pz - delta, vol.scz, k, t.fzm); t.lzm = k - c.oz;
-    return true;
-}
-
-__device__ __forceinline__ void load_ray(const float *entry, const float *exit_, const float *rays, const int32_t *nsamp,
-                                         size_t p, RayGeom &rg) {
-    rg.n = nsamp[p]; rg.entry = entry[p]; rg.exit_ = exit_[p];
-    rg.vx = rays[3 * p]; rg.vy = rays[3 * p + 1]; rg.vz = rays[3 * p + 2];
-    rg.t0 = rg.entry + 0.5f * (rg.exit_ - rg.entry) / (float)rg.n;
-}
 
 // ------------------------------------------------------------------------------------------------ F1
 template <typename VT, int MODE>
@@ -425,65 +185,6 @@ __global__ __launch_bounds__(256) void ray_compose_kernel(BrickParams<VT> P) {
 }
 
 // ------------------------------------------------------------------------------------------------ B1
-// ---- 64-bit fixed point for the LDS accumulators -------------------------------------------------------
-// value = x * 2^shift, stored as a two's-complement int64. fx_hi = 2^(shift-32) is passed around as a float.
-struct FixScale {
-    float hi;    // 2^(shift-32): x*hi has the high word in its integer part, the low word in its fraction
-    float lim;   // adjoints are clamped to +-lim = 2^20 * max|grad_out| (keeps every sum inside 63 bits)
-    double inv;  // 2^-shift
-};
-__device__ __forceinline__ FixScale make_fix_scale(unsigned int gmax_bits) {
-    float gmax = __uint_as_float(gmax_bits);
-    if (!(gmax > 0.0f) || !(gmax < 3.0e38f)) gmax = 1.0f;  // all-zero or non-finite upstream gradient
-    int e;
-    frexpf(gmax, &e);            // gmax < 2^e
-    const int shift = 28 - e;    // gmax * 2^shift < 2^28
-    FixScale f;
-    f.hi = ldexpf(1.0f, shift - 32);
-    f.lim = ldexpf(1.0f, e + 20);
-    f.inv = ldexp(1.0, -shift);
-    return f;
-}
-__device__ __forceinline__ float fix_clamp(float x, const FixScale &f) {
-    return fminf(fmaxf(x, -f.lim), f.lim);  // NaN -> -lim (finite), as nan_to_num would make it finite later
-}
-__device__ __forceinline__ void fix_add(unsigned long long *p, float x, const FixScale &f) {
-    const float t = x * f.hi;
-    const float hf = floorf(t);
-    const unsigned int lo = (unsigned int)((t - hf) * 4294967296.0f);  // fraction in [0,1): exact product
-    const unsigned long long v = ((unsigned long long)(unsigned int)(int)hf << 32) | lo;
-    atomicAdd(p, v);  // ds_add_u64
-}
-__device__ __forceinline__ float fix_to_float(unsigned long long v, const FixScale &f) {
-    return (float)((double)(long long)v * f.inv);
-}
-
-// adjoint of tri_lds into the fixed-point LDS box
-__device__ __forceinline__ void tri_scatter_lds(unsigned long long *dbox, int base, float fx, float fy, float fz,
-                                                float adj, const FixScale &f) {
-    const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;
-    const float a00 = gx * gy * adj, a10 = fx * gy * adj, a01 = gx * fy * adj, a11 = fx * fy * adj;
-    fix_add(dbox + base, a00 * gz, f);
-    fix_add(dbox + base + BOX_SX, a10 * gz, f);
-    fix_add(dbox + base + BOX_SY, a01 * gz, f);
-    fix_add(dbox + base + BOX_SX + BOX_SY, a11 * gz, f);
-    fix_add(dbox + base + 1, a00 * fz, f);
-    fix_add(dbox + base + BOX_SX + 1, a10 * fz, f);
-    fix_add(dbox + base + BOX_SY + 1, a01 * fz, f);
-    fix_add(dbox + base + BOX_SX + BOX_SY + 1, a11 * fz, f);
-}
-
-// max |x| over a buffer -> bits of the (non-negative) float, combined with atomicMax on the integer view
-__global__ __launch_bounds__(256) void absmax_kernel(const float *x, size_t n, unsigned int *out_bits) {
-    float m = 0.0f;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const float v = fabsf(x[i]);
-        m = (v > m) ? v : m;  // NaN never wins
-    }
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(out_bits, __float_as_uint(fminf(m, 3.0e38f)));
-}
-
 template <typename VT, bool WANT_VOL, bool WANT_TF>
 __global__ __launch_bounds__(256) void brick_bwd_kernel(BrickParams<VT> P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -609,27 +310,6 @@ __global__ __launch_bounds__(256) void brick_bwd_kernel(BrickParams<VT> P) {
 }
 
 // ------------------------------------------------------------------------------------------------ host
-struct Workspace {
-    float4 *seg_rgba; int32_t *seg_cnt; int32_t *ws_steps; uint8_t *rayflag; unsigned int *stats;
-    size_t cnt_bytes;
-};
-static size_t ws_layout(void *base, int n_views, int NP, int NL, Workspace *w) {
-    size_t o = 0;
-    const size_t nseg = (size_t)n_views * NL * NP;
-    unsigned char *b = static_cast<unsigned char *>(base);
-    if (w) w->stats = reinterpret_cast<unsigned int *>(b + o);
-    o += 256;
-    if (w) w->seg_rgba = reinterpret_cast<float4 *>(b + o);
-    o += nseg * 16;
-    if (w) { w->seg_cnt = reinterpret_cast<int32_t *>(b + o); w->cnt_bytes = nseg * 4; }
-    o += nseg * 4;
-    if (w) w->ws_steps = reinterpret_cast<int32_t *>(b + o);
-    o += align16((size_t)n_views * NP * 4);
-    if (w) w->rayflag = reinterpret_cast<uint8_t *>(b + o);
-    o += align16((size_t)n_views * NP);
-    return o;
-}
-
 bool brick_path_supported(int VX, int VY, int VZ, int R) {
     const int m = VX > VY ? (VX > VZ ? VX : VZ) : (VY > VZ ? VY : VZ);
     if (m - 1 >= 2000) return false;       // normal taps must stay within one voxel of the centre cell
@@ -640,36 +320,6 @@ bool brick_path_supported(int VX, int VY, int VZ, int R) {
 size_t brick_workspace_bytes(int n_views, int W, int H, int VX, int VY, int VZ) {
     const BrickGrid g = make_brick_grid(VX, VY, VZ);
     return ws_layout(nullptr, n_views, W * H, g.NL, nullptr);
-}
-
-template <typename VT>
-static BrickParams<VT> make_brick_params(const MarchArgs &a, const Workspace &w) {
-    BrickParams<VT> P;
-    P.vol.p = static_cast<const VT *>(a.vol);
-    P.vol.sx = a.sx; P.vol.sy = a.sy; P.vol.sz = a.sz;
-    P.vol.VX = a.VX; P.vol.VY = a.VY; P.vol.VZ = a.VZ;
-    P.vol.scx = (float)((double)a.VX - 1.0 - 1e-4);
-    P.vol.scy = (float)((double)a.VY - 1.0 - 1e-4);
-    P.vol.scz = (float)((double)a.VZ - 1.0 - 1e-4);
-    P.vol_vs = a.vol_vs;
-    P.tf = reinterpret_cast<const float4 *>(a.tf); P.tf_vs = a.tf_vs / 4; P.R = a.R; P.tf_len = (float)(a.R - 1);
-    P.cam = a.cam; P.entry = a.entry; P.exit_ = a.exit_; P.rays = a.rays; P.nsamp = a.nsamp;
-    P.W = a.W; P.H = a.H; P.S = a.S; P.sr = a.sr; P.inv_sr = 1.0f / a.sr;
-    const double near_h = 2.0 * tan(a.fov_rad) * a.near_plane;
-    P.near_ = (float)a.near_plane; P.near_h = (float)near_h; P.near_w = (float)(near_h * ((double)a.W / (double)a.H));
-    P.g = make_brick_grid(a.VX, a.VY, a.VZ);
-    P.seg_rgba = w.seg_rgba; P.seg_cnt = w.seg_cnt; P.rayflag = w.rayflag; P.stats = w.stats; P.ws_steps = w.ws_steps;
-    P.out = a.out; P.steps = a.steps;
-    P.grad_out = a.grad_out; P.out_fwd = a.out_fwd;
-    P.dvol.p = a.d_vol; P.dvol.sx = a.dsx; P.dvol.sy = a.dsy; P.dvol.sz = a.dsz; P.dvol_vs = a.dvol_vs;
-    P.d_tf = a.d_tf; P.dtf_vs = a.dtf_vs / 4;
-    return P;
-}
-
-template <typename K>
-static hipError_t allow_lds(K kernel, size_t bytes) {
-    if (bytes <= 64 * 1024) return hipSuccess;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
 template <typename VT>
@@ -685,18 +335,37 @@ static int brick_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     e = hipMemsetAsync(w.seg_cnt, 0, w.cnt_bytes, stream);
     if (e != hipSuccess) return (int)e;
     const size_t lds = brick_lds_bytes(a.R, false, false);
-    const dim3 grid1(g.NBx * g.NBy * g.NBz, a.n_views), grid2((NP + 255) / 256, a.n_views);
-    const size_t lds2 = (size_t)a.R * 16;
+    const dim3 grid1(g.NBx * g.NBy * g.NBz, a.n_views);
     if (a.mode == DR_MODE_DIFF) {
         if ((e = allow_lds(brick_fwd_kernel<VT, DR_MODE_DIFF>, lds)) != hipSuccess) return (int)e;
         hipLaunchKernelGGL((brick_fwd_kernel<VT, DR_MODE_DIFF>), grid1, dim3(256), lds, stream, P);
-        hipLaunchKernelGGL((ray_compose_kernel<VT, DR_MODE_DIFF>), grid2, dim3(256), lds2, stream, P);
     } else {
         if ((e = allow_lds(brick_fwd_kernel<VT, DR_MODE_NONDIFF>, lds)) != hipSuccess) return (int)e;
         hipLaunchKernelGGL((brick_fwd_kernel<VT, DR_MODE_NONDIFF>), grid1, dim3(256), lds, stream, P);
-        hipLaunchKernelGGL((ray_compose_kernel<VT, DR_MODE_NONDIFF>), grid2, dim3(256), lds2, stream, P);
     }
+    if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+    return launch_ray_compose(a, stream);
+}
+
+// F2 for any of the brick pipelines: the workspace must hold the F1 output of the same call.
+template <typename VT>
+static int ray_compose_dispatch(const MarchArgs &a, hipStream_t stream) {
+    const BrickGrid g = make_brick_grid(a.VX, a.VY, a.VZ);
+    const int NP = a.W * a.H;
+    Workspace w;
+    ws_layout(a.workspace, a.n_views, NP, g.NL, &w);
+    BrickParams<VT> P = make_brick_params<VT>(a, w);
+    const dim3 grid2((NP + 255) / 256, a.n_views);
+    const size_t lds2 = (size_t)a.R * 16;
+    if (a.mode == DR_MODE_DIFF)
+        hipLaunchKernelGGL((ray_compose_kernel<VT, DR_MODE_DIFF>), grid2, dim3(256), lds2, stream, P);
+    else
+        hipLaunchKernelGGL((ray_compose_kernel<VT, DR_MODE_NONDIFF>), grid2, dim3(256), lds2, stream, P);
     return (int)hipGetLastError();
+}
+
+int launch_ray_compose(const MarchArgs &a, hipStream_t stream) {
+    return a.vol_dtype == DR_F16 ? ray_compose_dispatch<__half>(a, stream) : ray_compose_dispatch<float>(a, stream);
 }
 
 int launch_march_fwd_brick(const MarchArgs &a, hipStream_t stream) {

@@ -1,0 +1,521 @@
+// march_flat.hip -- brick-centric march with ONE LANE PER SAMPLE (DR_VARIANT_AUTO fast path, gfx950).
+//
+// Same pipeline as march_brick.hip (LDS-staged 16^3-cell bricks, per-(ray,layer) partial composites, F2
+// per-ray composition, fixed-point LDS gradient boxes), but the work items of a brick are the SAMPLES of all
+// ray segments that cross it, laid out back to back ("flat" index): a wave takes 64 consecutive samples.
+//   * every lane is busy whatever the lengths of the individual segments (a brick holds only ~170 segments
+//     but ~7800 samples), so a 512-thread workgroup fills a CU even when the LDS footprint allows one
+//     workgroup per CU (backward: 27 KB voxel box + 55 KB 64-bit gradient box);
+//   * the 64 lanes of a load walk along one or two rays: ~19 distinct cells per instruction on odd LDS
+//     strides, i.e. conflict-free reads, and neighbouring lanes that share a cell are LDS broadcasts;
+//   * front-to-back compositing inside a segment becomes a segmented wave scan of the associative "over"
+//     operator (DPP/shuffle, no LDS traffic); the running composite of a segment that spans several
+//     64-sample chunks is carried in registers by the wave that owns it.
+// Reference functions replaced: VR.py:261-372 and the autodiff twins VR.py:460-461,470-471.
+#include "dr_brick_common.h"
+
+namespace dr {
+
+constexpr int FNT = 512;          // threads per workgroup
+constexpr int FNW = FNT / 64;     // waves per workgroup
+constexpr int FEC_FWD = 512;      // ray segments listed per round (forward)
+constexpr int FEC_BWD = 256;      // (backward: the entry table also holds prefix / gradient / output)
+
+struct FlatLds {
+    float4 *tf; float *box; unsigned long long *dbox; unsigned long long *dtf;
+    float4 *ray0;   // (t0, exit, (float)(n-1), unused)
+    float4 *ray1;   // (vx, vy, vz, bits(pixel index))
+    float4 *pre, *go, *of;  // backward: composite before the segment, upstream gradient, forward output
+    int *s_rel;     // first sample index of the segment minus its flat offset
+    int *offs;      // [EC+1] exclusive prefix of the segment lengths (flat index of each segment's first sample)
+    int *valid;     // in-brick samples of each segment (forward)
+    int *live;      // backward: live sample count of the ray
+    int *misc;
+};
+template <bool BWD>
+__host__ __device__ inline size_t flat_lds_bytes(int R, bool want_vol, bool want_tf) {
+    const int EC = BWD ? FEC_BWD : FEC_FWD;
+    size_t s = (size_t)R * 16 + align16(BOX_N * 4);
+    if (BWD && want_vol) s += align16(BOX_N * 8);
+    if (BWD && want_tf) s += (size_t)R * 32;
+    s += (size_t)EC * 32 + (BWD ? (size_t)EC * 48 : 0);
+    s += (size_t)EC * 4 + align16((EC + 1) * 4) + (size_t)EC * 4 + (BWD ? (size_t)EC * 4 : 0) + 64;  // + misc
+    return s;
+}
+template <bool BWD>
+__device__ __forceinline__ FlatLds flat_carve(unsigned char *smem, int R, bool want_vol, bool want_tf) {
+    const int EC = BWD ? FEC_BWD : FEC_FWD;
+    FlatLds L;
+    size_t o = 0;
+    L.tf = reinterpret_cast<float4 *>(smem + o); o += (size_t)R * 16;
+    L.box = reinterpret_cast<float *>(smem + o); o += align16(BOX_N * 4);
+    L.dbox = nullptr; L.dtf = nullptr; L.pre = L.go = L.of = nullptr; L.live = nullptr;
+    if (BWD && want_vol) { L.dbox = reinterpret_cast<unsigned long long *>(smem + o); o += align16(BOX_N * 8); }
+    if (BWD && want_tf) { L.dtf = reinterpret_cast<unsigned long long *>(smem + o); o += (size_t)R * 32; }
+    L.ray0 = reinterpret_cast<float4 *>(smem + o); o += (size_t)EC * 16;
+    L.ray1 = reinterpret_cast<float4 *>(smem + o); o += (size_t)EC * 16;
+    if (BWD) {
+        L.pre = reinterpret_cast<float4 *>(smem + o); o += (size_t)EC * 16;
+        L.go = reinterpret_cast<float4 *>(smem + o); o += (size_t)EC * 16;
+        L.of = reinterpret_cast<float4 *>(smem + o); o += (size_t)EC * 16;
+    }
+    L.s_rel = reinterpret_cast<int *>(smem + o); o += (size_t)EC * 4;
+    L.offs = reinterpret_cast<int *>(smem + o); o += align16((EC + 1) * 4);
+    L.valid = reinterpret_cast<int *>(smem + o); o += (size_t)EC * 4;
+    if (BWD) { L.live = reinterpret_cast<int *>(smem + o); o += (size_t)EC * 4; }
+    L.misc = reinterpret_cast<int *>(smem + o);  // 16 ints
+    return L;
+}
+
+template <typename VT>
+__device__ __forceinline__ void flat_load_tf_and_box(const BrickParams<VT> &P, const VolView<VT> &vol,
+                                                     const BrickCtx &c, const float4 *tfg, FlatLds &L) {
+    for (int k = threadIdx.x; k < P.R; k += FNT) L.tf[k] = tfg[k];
+    const int fast = (vol.sx <= vol.sy && vol.sx <= vol.sz) ? 0 : ((vol.sy <= vol.sz) ? 1 : 2);
+    for (int idx = threadIdx.x; idx < BOX_N; idx += FNT) {
+        const int a = idx % BOX, b = (idx / BOX) % BOX, d = idx / (BOX * BOX);
+        int lx, ly, lz;
+        if (fast == 0) { lx = a; ly = b; lz = d; } else if (fast == 1) { ly = a; lx = b; lz = d; } else { lz = a; ly = b; lx = d; }
+        const int gx = c.ox + lx, gy = c.oy + ly, gz = c.oz + lz;
+        float v = 0.0f;
+        if (gx >= 0 && gx < vol.VX && gy >= 0 && gy < vol.VY && gz >= 0 && gz < vol.VZ)
+            v = ld_voxel(vol.p + gx * vol.sx + gy * vol.sy + gz * vol.sz);
+        L.box[lx * BOX_SX + ly * BOX_SY + lz] = v;
+    }
+}
+
+// List the ray segments of candidates [cbase, cbase+EC) and their flat offsets. Returns (nE, M) via misc.
+template <typename VT, int MODE, bool BWD>
+__device__ __forceinline__ void flat_build_entries(const BrickParams<VT> &P, const BrickCtx &c, f3 cam, int view,
+                                                   int cbase, int ncand, size_t seg_base, FlatLds &L, int &nE, int &M) {
+    constexpr int EC = BWD ? FEC_BWD : FEC_FWD;
+    static_assert(EC <= FNT, "one candidate per thread and round");
+    const int NP = P.W * P.H;
+    const int nj = c.j1 - c.j0 + 1;
+    const int cc = cbase + threadIdx.x;
+    // each thread examines at most one candidate pixel; slots are handed out in candidate order
+    // (ballot compaction), so the flat sample order -- and with it every rounding -- is reproducible
+    bool has = false;
+    int pl = 0, s0 = 0, s1 = 0, live = 0;
+    float t0 = 0.f, exit_ = 0.f, nm1 = 0.f;
+    f3 vd = make_f3(0.f, 0.f, 0.f);
+    size_t p = 0;
+    if (threadIdx.x < EC && cc < ncand) {
+        const int i = c.i0 + cc / nj, j = c.j0 + cc % nj;
+        pl = i * P.H + j;
+        p = (size_t)view * NP + pl;
+        const int n = P.nsamp[p];
+        const float entry = P.entry[p];
+        bool ok = ray_is_regular(n, entry);
+        int nmarch = (MODE == DR_MODE_DIFF && n > P.S) ? P.S : n;
+        if (BWD && ok) {
+            ok = !P.rayflag[p] && P.seg_cnt[seg_base + pl] != 0;  // irregular ray / no sample in this brick
+            live = P.ws_steps[p];
+            nmarch = min(nmarch, live);
+        }
+        if (ok) {
+            exit_ = P.exit_[p];
+            vd = make_f3(P.rays[3 * p], P.rays[3 * p + 1], P.rays[3 * p + 2]);
+            t0 = entry + 0.5f * (exit_ - entry) / (float)n;
+            nm1 = (float)(n - 1);
+            has = segment_range(c, cam, vd, t0, exit_, n, nmarch, s0, s1);
+        }
+    }
+    const unsigned long long hm = __ballot(has);
+    const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
+    if (lane_ == 0) L.misc[4 + wave_] = __popcll(hm);
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < FNW; ++w) {
+        const int cw = L.misc[4 + w];
+        if (w < wave_) base += cw;
+        total += cw;
+    }
+    nE = total;
+    if (has) {
+        const int slot = base + __popcll(hm & ((1ull << lane_) - 1ull));
+        L.ray0[slot] = make_float4(t0, exit_, nm1, 0.0f);
+        L.ray1[slot] = make_float4(vd.x, vd.y, vd.z, __int_as_float(pl));
+        L.s_rel[slot] = s0;           // turned into s0 - offs below
+        L.offs[slot + 1] = s1 - s0;   // length; prefix-summed below
+        L.valid[slot] = 0;
+        if (BWD) {
+            L.pre[slot] = P.seg_rgba[seg_base + pl];
+            L.go[slot] = reinterpret_cast<const float4 *>(P.grad_out)[p];
+            L.of[slot] = reinterpret_cast<const float4 *>(P.out_fwd)[p];
+            L.live[slot] = live;
+        }
+    }
+    __syncthreads();
+    // exclusive prefix sum of the lengths by wave 0: each lane owns EC/64 consecutive entries
+    if (threadIdx.x < 64) {
+        constexpr int PER = EC / 64;
+        int loc[PER];
+        int sum = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int e = threadIdx.x * PER + k;
+            loc[k] = (e < nE) ? L.offs[e + 1] : 0;
+            sum += loc[k];
+        }
+        int incl = sum;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d);
+            if ((int)threadIdx.x >= d) incl += o;
+        }
+        int run = incl - sum;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int e = threadIdx.x * PER + k;
+            if (e < nE) { L.offs[e] = run; L.s_rel[e] -= run; }
+            run += loc[k];
+        }
+        if (threadIdx.x == 63) { L.offs[nE] = run; L.misc[1] = run; }
+    }
+    __syncthreads();
+    M = L.misc[1];
+}
+
+// first index e in [0, nE] with offs[e] >= target (offs is non-decreasing, offs[nE] = M)
+__device__ __forceinline__ int lower_bound_offs(const int *offs, int nE, int target) {
+    int lo = 0, hi = nE;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (offs[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+struct Over { float c0, c1, c2, a; };  // premultiplied composite element
+__device__ __forceinline__ Over over(const Over &front, const Over &back) {  // front-to-back "over"
+    const float T = 1.0f - front.a;
+    Over r;
+    r.c0 = fmaf(T, back.c0, front.c0); r.c1 = fmaf(T, back.c1, front.c1); r.c2 = fmaf(T, back.c2, front.c2);
+    r.a = fmaf(T, back.a, front.a);
+    return r;
+}
+// ---- cross-lane plumbing: DPP moves (no LDS traffic, a few cycles of latency) ---------------------------
+// ctrl: 0x111/0x112/0x114/0x118 = row_shr:1/2/4/8 (within a 16-lane row), 0x142 = row_bcast:15 (lane 15 of a
+// row to the next row), 0x143 = row_bcast:31 (lane 31 to the upper half). Lanes without a source keep `old`.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL>
+__device__ __forceinline__ Over dpp_over(const Over &v) {
+    Over r;
+    r.c0 = dpp_f<CTRL>(v.c0); r.c1 = dpp_f<CTRL>(v.c1); r.c2 = dpp_f<CTRL>(v.c2); r.a = dpp_f<CTRL>(v.a);
+    return r;
+}
+// Does the DPP source lane of step K exist and lie at or after lane `sl` (the first lane of this lane's segment)?
+template <int K>
+__device__ __forceinline__ bool scan_src_ok(int lane, int sl) {
+    if (K < 4) return (lane & 15) >= (1 << K) && lane - (1 << K) >= sl;
+    if (K == 4) return (lane & 16) && ((lane & ~15) - 1) >= sl;
+    return lane >= 32 && 31 >= sl;
+}
+// segmented inclusive scan of "over": segments are runs of lanes sharing sl
+__device__ __forceinline__ Over seg_scan_over(Over v, int lane, int sl) {
+    { const Over o = dpp_over<0x111>(v); if (scan_src_ok<0>(lane, sl)) v = over(o, v); }
+    { const Over o = dpp_over<0x112>(v); if (scan_src_ok<1>(lane, sl)) v = over(o, v); }
+    { const Over o = dpp_over<0x114>(v); if (scan_src_ok<2>(lane, sl)) v = over(o, v); }
+    { const Over o = dpp_over<0x118>(v); if (scan_src_ok<3>(lane, sl)) v = over(o, v); }
+    { const Over o = dpp_over<0x142>(v); if (scan_src_ok<4>(lane, sl)) v = over(o, v); }
+    { const Over o = dpp_over<0x143>(v); if (scan_src_ok<5>(lane, sl)) v = over(o, v); }
+    return v;
+}
+// segmented inclusive SUM of NV values (same segment convention)
+template <int NV>
+__device__ __forceinline__ void seg_scan_sum(float (&v)[NV], int lane, int sl) {
+#define DR_SUM_STEP(CTRL, K)                                             \
+    {                                                                    \
+        const bool ok = scan_src_ok<K>(lane, sl);                        \
+        _Pragma("unroll") for (int i = 0; i < NV; ++i) {                 \
+            const float o = dpp_f<CTRL>(v[i]);                           \
+            v[i] += ok ? o : 0.0f;                                       \
+        }                                                                \
+    }
+    DR_SUM_STEP(0x111, 0) DR_SUM_STEP(0x112, 1) DR_SUM_STEP(0x114, 2) DR_SUM_STEP(0x118, 3)
+    DR_SUM_STEP(0x142, 4) DR_SUM_STEP(0x143, 5)
+#undef DR_SUM_STEP
+}
+// inclusive max scan of an int (used to propagate run starts)
+__device__ __forceinline__ int scan_max(int v, int lane) {
+    { const int o = dpp_i<0x111>(v); if ((lane & 15) >= 1) v = max(v, o); }
+    { const int o = dpp_i<0x112>(v); if ((lane & 15) >= 2) v = max(v, o); }
+    { const int o = dpp_i<0x114>(v); if ((lane & 15) >= 4) v = max(v, o); }
+    { const int o = dpp_i<0x118>(v); if ((lane & 15) >= 8) v = max(v, o); }
+    { const int o = dpp_i<0x142>(v); if (lane & 16) v = max(v, o); }
+    { const int o = dpp_i<0x143>(v); if (lane >= 32) v = max(v, o); }
+    return v;
+}
+__device__ __forceinline__ Over readlane_over(const Over &v, int lane) {
+    Over r;
+    r.c0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.c0), lane));
+    r.c1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.c1), lane));
+    r.c2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.c2), lane));
+    r.a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.a), lane));
+    return r;
+}
+__device__ __forceinline__ Over shfl_up1_over(const Over &v) {
+    Over r;
+    r.c0 = __shfl_up(v.c0, 1); r.c1 = __shfl_up(v.c1, 1); r.c2 = __shfl_up(v.c2, 1); r.a = __shfl_up(v.a, 1);
+    return r;
+}
+
+template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF>
+__global__ __launch_bounds__(FNT) void brick_flat_kernel(BrickParams<VT> P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int EC = BWD ? FEC_BWD : FEC_FWD;
+    const int view = blockIdx.y;
+    const f3 cam = make_f3(P.cam[3 * view], P.cam[3 * view + 1], P.cam[3 * view + 2]);
+    BrickCtx c;
+    brick_setup(P, blockIdx.x, cam, c);
+    if (c.i0 > c.i1 || c.j0 > c.j1) return;  // uniform: the brick projects outside the image
+
+    FlatLds L = flat_carve<BWD>(smem, P.R, WANT_VOL, WANT_TF);
+    VolView<VT> vol = P.vol;
+    vol.p += view * P.vol_vs;
+    flat_load_tf_and_box(P, vol, c, P.tf + view * P.tf_vs, L);
+    FixScale fs;
+    if (BWD) {
+        if (WANT_VOL) for (int k = threadIdx.x; k < BOX_N; k += FNT) L.dbox[k] = 0ull;
+        if (WANT_TF) for (int k = threadIdx.x; k < 4 * P.R; k += FNT) L.dtf[k] = 0ull;
+        fs = make_fix_scale(P.stats[1]);
+    }
+    const f3 light = make_f3(cam.x + 0.0f, cam.y + 1.0f, cam.z + 0.0f);
+    const int NP = P.W * P.H;
+    const size_t seg_base = ((size_t)view * P.g.NL + c.layer) * NP;
+    const int ncand = (c.i1 - c.i0 + 1) * (c.j1 - c.j0 + 1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    bool any = false;
+
+    for (int cbase = 0; cbase < ncand; cbase += EC) {
+        int nE, M;
+        flat_build_entries<VT, MODE, BWD>(P, c, cam, view, cbase, ncand, seg_base, L, nE, M);  // syncs inside
+        any = any || nE > 0;
+        // this wave owns the contiguous entry range [ea, eb): segments never straddle two waves
+        const int ea = lower_bound_offs(L.offs, nE, (int)(((long long)M * wave) / FNW));
+        const int eb = (wave == FNW - 1) ? nE : lower_bound_offs(L.offs, nE, (int)(((long long)M * (wave + 1)) / FNW));
+        const int fa = L.offs[ea], fb = L.offs[eb];
+        Over carry = {0.f, 0.f, 0.f, 0.f};
+        int carry_e = -1;  // entry whose composite so far is in `carry` (continues into the next chunk)
+        int e_cur = ea;
+        for (int f0 = fa; f0 < fb; f0 += 64) {
+            const int f = f0 + lane;
+            const bool act = f < fb;
+            // entry of this lane: advance from the previous chunk's entry (flat order is entry order)
+            if (act) { while (f >= L.offs[e_cur + 1]) ++e_cur; }
+            const int e = act ? e_cur : eb - 1;
+            const int eoff = L.offs[e];
+            const int sl = max(lane - (f - eoff), 0);  // first lane of this lane's segment within the chunk
+            const float4 r0 = L.ray0[e], r1 = L.ray1[e];
+            const int s = f + L.s_rel[e];
+            RayGeom rg;
+            rg.t0 = r0.x; rg.exit_ = r0.y; rg.n = (int)r0.z + 1; rg.vx = r1.x; rg.vy = r1.y; rg.vz = r1.z;
+            const f3 vd = make_f3(r1.x, r1.y, r1.z);
+            Sample sm; TapCoords t;
+            bool valid = act && sample_coords(vol, c, rg, cam, s, sm, t);
+            float dx = 0.f, dy = 0.f, dz = 0.f;
+            Over el = {0.f, 0.f, 0.f, 0.f};
+            bool shaded = false;
+            if (valid) {
+                sample_taps_lds(L.box, t, sm.I, dx, dy, dz);
+                classify_from_I(L.tf, P.R, P.tf_len, P.inv_sr, sm);
+                if (!(MODE == DR_MODE_NONDIFF && !(sm.a > 1e-3f))) {
+                    shade_from_grad(dx, dy, dz, light, vd, MODE == DR_MODE_DIFF, sm);
+                    el.c0 = sm.L * sm.r * sm.op; el.c1 = sm.L * sm.g * sm.op; el.c2 = sm.L * sm.b * sm.op; el.a = sm.op;
+                    shaded = true;
+                }
+            }
+            // segmented inclusive scan of "over" across the wave (segments = entries)
+            Over inc = seg_scan_over(el, lane, sl);
+            // the first segment may continue an entry begun in an earlier chunk of this wave
+            const int e_first = __builtin_amdgcn_readfirstlane(e);
+            const bool cont = (carry_e == e_first);
+            Over exc = {0.f, 0.f, 0.f, 0.f};                  // composite before this sample, within the chunk
+            if (BWD) exc = shfl_up1_over(inc);
+            if (lane == sl) { exc.c0 = exc.c1 = exc.c2 = exc.a = 0.f; }
+            if (cont && e == e_first) { inc = over(carry, inc); exc = over(carry, exc); }
+            // carry out: composite of the last lane's entry if it continues past this chunk
+            {
+                const int e_last = __builtin_amdgcn_readlane(e, 63);
+                const Over last = readlane_over(inc, 63);
+                const bool more = (f0 + 64 < fb) && (L.offs[e_last + 1] > f0 + 64);
+                carry = last; carry_e = more ? e_last : -1;
+            }
+            const bool seg_end = act && (f == L.offs[e + 1] - 1);
+            if (!BWD) {
+                // count the in-brick samples of each segment piece, store finished segments
+                const unsigned long long vm = __ballot(valid);
+                const bool piece_end = act && (seg_end || lane == 63 || f == fb - 1);
+                if (piece_end) {
+                    const unsigned long long below = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+                    const unsigned long long from = ~((1ull << sl) - 1ull);
+                    const int cntp = __popcll(vm & below & from);
+                    const int before = cntp ? atomicAdd(&L.valid[e], cntp) : L.valid[e];
+                    // a (ray, layer) slot belongs to the one brick that holds samples of the ray: a candidate
+                    // segment without any in-brick sample must not touch it
+                    if (seg_end && before + cntp > 0)
+                        P.seg_rgba[seg_base + __float_as_int(r1.w)] = make_float4(inc.c0, inc.c1, inc.c2, inc.a);
+                }
+            } else {
+                SampleAdj ad;
+                ad.r_bar = ad.g_bar = ad.b_bar = ad.a_bar = 0.f; ad.gx = ad.gy = ad.gz = 0.f;
+                if (valid) {
+                    const float4 pre = L.pre[e], go = L.go[e], of = L.of[e];
+                    const Over preo = {pre.x, pre.y, pre.z, pre.w};
+                    const Over absi = over(preo, inc);                       // composite up to and including s
+                    const float T = (1.0f - pre.w) * (1.0f - exc.a);         // transmittance before s
+                    const bool last = (s == L.live[e] - 1);
+                    const float suffix = (go.x * (of.x - absi.c0) + go.y * (of.y - absi.c1) + go.z * (of.z - absi.c2)) +
+                                         go.w * (of.w - absi.a);
+                    sample_adjoint(sm, vd, T, suffix, last, go, P.inv_sr, ad);
+                }
+                if (WANT_TF) {
+                    // neighbouring lanes are consecutive samples of a ray: long runs fall between the same two
+                    // texels. Sum each run across lanes (DPP) and let its last lane do the eight LDS adds.
+                    const int key = valid ? sm.lo : -1 - lane;
+                    const int key_prev = __shfl_up(key, 1);
+                    const int rs = scan_max((lane == 0 || key != key_prev) ? lane : 0, lane);
+                    const float w0 = 1.0f - sm.fr, w1 = sm.fr;
+                    float tv[8] = {w0 * ad.r_bar, w0 * ad.g_bar, w0 * ad.b_bar, w0 * ad.a_bar,
+                                   w1 * ad.r_bar, w1 * ad.g_bar, w1 * ad.b_bar, w1 * ad.a_bar};
+                    seg_scan_sum<8>(tv, lane, rs);
+                    const int key_next = __shfl_down(key, 1);
+                    if (valid && (lane == 63 || key_next != key)) {
+                        unsigned long long *d0 = L.dtf + 4 * sm.lo, *d1 = L.dtf + 4 * sm.hi;
+                        fix_add(d0 + 0, fix_clamp(tv[0], fs), fs); fix_add(d0 + 1, fix_clamp(tv[1], fs), fs);
+                        fix_add(d0 + 2, fix_clamp(tv[2], fs), fs); fix_add(d0 + 3, fix_clamp(tv[3], fs), fs);
+                        fix_add(d1 + 0, fix_clamp(tv[4], fs), fs); fix_add(d1 + 1, fix_clamp(tv[5], fs), fs);
+                        fix_add(d1 + 2, fix_clamp(tv[6], fs), fs); fix_add(d1 + 3, fix_clamp(tv[7], fs), fs);
+                    }
+                }
+                if (WANT_VOL && valid) {
+                    const float I_bar = fix_clamp(intensity_adjoint(sm, L.tf[sm.lo], L.tf[sm.hi], ad, P.tf_len), fs);
+                    const int by = t.ly * BOX_SY, bz = t.lz, bx = t.lx * BOX_SX;
+                    tri_scatter_lds(L.dbox, bx + by + bz, t.fx, t.fy, t.fz, I_bar, fs);
+                    if (!sm.flat) {
+                        const float gx = fix_clamp(ad.gx, fs), gy = fix_clamp(ad.gy, fs), gz = fix_clamp(ad.gz, fs);
+                        tri_scatter_lds(L.dbox, t.lxp * BOX_SX + by + bz, t.fxp, t.fy, t.fz, gx, fs);
+                        tri_scatter_lds(L.dbox, t.lxm * BOX_SX + by + bz, t.fxm, t.fy, t.fz, -gx, fs);
+                        tri_scatter_lds(L.dbox, bx + t.lyp * BOX_SY + bz, t.fx, t.fyp, t.fz, gy, fs);
+                        tri_scatter_lds(L.dbox, bx + t.lym * BOX_SY + bz, t.fx, t.fym, t.fz, -gy, fs);
+                        tri_scatter_lds(L.dbox, bx + by + t.lzp, t.fx, t.fy, t.fzp, gz, fs);
+                        tri_scatter_lds(L.dbox, bx + by + t.lzm, t.fx, t.fy, t.fzm, -gz, fs);
+                    }
+                }
+            }
+            (void)shaded;
+        }
+        if (!BWD) {
+            // sample counts of the segments this wave owns (only this wave added to them)
+            for (int e = ea + lane; e < eb; e += 64) {
+                const int v = L.valid[e];
+                if (v > 0) P.seg_cnt[seg_base + __float_as_int(L.ray1[e].w)] = v;
+            }
+        }
+        __syncthreads();
+    }
+    if (!BWD || !any) return;  // uniform
+    // flush: one pass of global float atomics per brick, walking the gradient's fastest axis
+    if (WANT_VOL) {
+        GradView dv = P.dvol;
+        dv.p += view * P.dvol_vs;
+        const int fast = (dv.sx <= dv.sy && dv.sx <= dv.sz) ? 0 : ((dv.sy <= dv.sz) ? 1 : 2);
+        for (int idx = threadIdx.x; idx < BOX_N; idx += FNT) {
+            const int a = idx % BOX, b = (idx / BOX) % BOX, d = idx / (BOX * BOX);
+            int lx, ly, lz;
+            if (fast == 0) { lx = a; ly = b; lz = d; } else if (fast == 1) { ly = a; lx = b; lz = d; } else { lz = a; ly = b; lx = d; }
+            const unsigned long long raw = L.dbox[lx * BOX_SX + ly * BOX_SY + lz];
+            if (raw != 0ull) {
+                const int gx = c.ox + lx, gy = c.oy + ly, gz = c.oz + lz;  // in range whenever raw != 0
+                unsafeAtomicAdd(dv.p + gx * dv.sx + gy * dv.sy + gz * dv.sz, fix_to_float(raw, fs));
+            }
+        }
+    }
+    if (WANT_TF) {
+        float *dtf = P.d_tf + view * P.dtf_vs * 4;
+        for (int k = threadIdx.x; k < 4 * P.R; k += FNT) {
+            const unsigned long long raw = L.dtf[k];
+            if (raw != 0ull) unsafeAtomicAdd(dtf + k, fix_to_float(raw, fs));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host
+bool flat_path_supported(int VX, int VY, int VZ, int R) {
+    if (!brick_path_supported(VX, VY, VZ, R)) return false;
+    return flat_lds_bytes<true>(R, true, true) <= 160 * 1024;
+}
+
+template <typename VT>
+static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
+    const BrickGrid g = make_brick_grid(a.VX, a.VY, a.VZ);
+    const int NP = a.W * a.H;
+    Workspace w;
+    const size_t need = ws_layout(a.workspace, a.n_views, NP, g.NL, &w);
+    if (!a.workspace || a.workspace_bytes < need) return DR_EINVAL;
+    BrickParams<VT> P = make_brick_params<VT>(a, w);
+    hipError_t e = hipMemsetAsync(w.stats, 0, 256, stream);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(w.seg_cnt, 0, w.cnt_bytes, stream);
+    if (e != hipSuccess) return (int)e;
+    const size_t lds = flat_lds_bytes<false>(a.R, false, false);
+    const dim3 grid1(g.NBx * g.NBy * g.NBz, a.n_views);
+    if (a.mode == DR_MODE_DIFF) {
+        if ((e = allow_lds(brick_flat_kernel<VT, DR_MODE_DIFF, false, false, false>, lds)) != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((brick_flat_kernel<VT, DR_MODE_DIFF, false, false, false>), grid1, dim3(FNT), lds, stream, P);
+    } else {
+        if ((e = allow_lds(brick_flat_kernel<VT, DR_MODE_NONDIFF, false, false, false>, lds)) != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((brick_flat_kernel<VT, DR_MODE_NONDIFF, false, false, false>), grid1, dim3(FNT), lds, stream, P);
+    }
+    if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+    return launch_ray_compose(a, stream);
+}
+
+int launch_march_fwd_flat(const MarchArgs &a, hipStream_t stream) {
+    return a.vol_dtype == DR_F16 ? flat_fwd_dispatch<__half>(a, stream) : flat_fwd_dispatch<float>(a, stream);
+}
+
+template <typename VT>
+static int flat_bwd_dispatch(const MarchArgs &a, hipStream_t stream) {
+    const BrickGrid g = make_brick_grid(a.VX, a.VY, a.VZ);
+    const int NP = a.W * a.H;
+    Workspace w;
+    const size_t need = ws_layout(a.workspace, a.n_views, NP, g.NL, &w);
+    if (!a.workspace || a.workspace_bytes < need) return DR_EINVAL;
+    BrickParams<VT> P = make_brick_params<VT>(a, w);
+    const bool wv = a.d_vol != nullptr, wt = a.d_tf != nullptr;
+    const size_t lds = flat_lds_bytes<true>(a.R, wv, wt);
+    const dim3 grid1(g.NBx * g.NBy * g.NBz, a.n_views);
+    hipError_t e = hipMemsetAsync(w.stats + 1, 0, 4, stream);
+    if (e != hipSuccess) return (int)e;
+    const size_t ng = (size_t)a.n_views * NP * 4;
+    const size_t nb = (ng + 256 * 16 - 1) / (256 * 16);
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(nb > 1024 ? 1024 : nb)), dim3(256), 0, stream, a.grad_out, ng,
+                       w.stats + 1);
+    if (wv && wt) {
+        if ((e = allow_lds(brick_flat_kernel<VT, DR_MODE_DIFF, true, true, true>, lds)) != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((brick_flat_kernel<VT, DR_MODE_DIFF, true, true, true>), grid1, dim3(FNT), lds, stream, P);
+    } else if (wv) {
+        if ((e = allow_lds(brick_flat_kernel<VT, DR_MODE_DIFF, true, true, false>, lds)) != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((brick_flat_kernel<VT, DR_MODE_DIFF, true, true, false>), grid1, dim3(FNT), lds, stream, P);
+    } else {
+        if ((e = allow_lds(brick_flat_kernel<VT, DR_MODE_DIFF, true, false, true>, lds)) != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((brick_flat_kernel<VT, DR_MODE_DIFF, true, false, true>), grid1, dim3(FNT), lds, stream, P);
+    }
+    if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+    MarchArgs b = a;
+    b.only_flagged = w.rayflag;  // B2: irregular rays through the baseline backward
+    return launch_march_bwd_baseline(b, stream);
+}
+
+int launch_march_bwd_flat(const MarchArgs &a, hipStream_t stream) {
+    return a.vol_dtype == DR_F16 ? flat_bwd_dispatch<__half>(a, stream) : flat_bwd_dispatch<float>(a, stream);
+}
+
+}  // namespace dr

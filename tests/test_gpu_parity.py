@@ -49,7 +49,7 @@ class _Variant:
         self._ws = None
 
     def march_fwd(self, vol, tf, cam, e, x, r, n, S, sr, mode=0, **kw):
-        if self.variant == 0:
+        if self.variant != 1:
             self._ws = self._f.alloc_workspace(n.shape[0], n.shape[1:], vol.shape[-3:], tf.shape[-2], vol.device)
             assert self._ws is not None
         return self._f.march_fwd(vol, tf, cam, e, x, r, n, S, sr, mode, variant=self.variant, workspace=self._ws, **kw)
@@ -59,7 +59,7 @@ class _Variant:
                                  workspace=self._ws)
 
 
-@pytest.fixture(scope="module", params=[0, 1], ids=["brick", "baseline"])
+@pytest.fixture(scope="module", params=[0, 2, 1], ids=["flat", "brick", "baseline"])
 def F(hiplib, request):
     assert torch.cuda.is_available(), "gpu tests need a ROCm device"
     from differender_amd import functional
