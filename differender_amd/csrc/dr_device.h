@@ -130,7 +130,7 @@ struct Sample {
     int lo, hi;
     float r, g, b, a, op;
     f3 grad, nrm, ld, rf;
-    float gnorm, m, ndl, q, rdv, spec, Lraw, L;
+    float gnorm, ginv, m, ndl, q, rdv, spec, Lraw, L;  // ginv = 1/gnorm
     bool flat;
 };
 
@@ -170,19 +170,33 @@ __device__ __forceinline__ void classify(const VolView<VT> &v, const float4 *tf,
 
 // VR.py:191-203 normal, :287-299 Phong, given the central differences (dx,dy,dz) of the six normal taps.
 // clampL: the differentiable path clamps lighting (VR.py:298).
+// FAST: the two normalisations use v_rsq_f32 (1 ulp) instead of an IEEE sqrt + divide. These feed the
+// lighting term directly (no cancellation downstream), so the change is ~1e-7 in L -- unlike the taps, whose
+// bits decide the normal and are never touched. The baseline kernels keep FAST = false (exact twin of the oracle).
+template <bool FAST = false>
 __device__ __forceinline__ void shade_from_grad(float dx, float dy, float dz, f3 light_pos, f3 vd, bool clampL,
                                                 Sample &sm) {
     sm.grad = make_f3(dx, dy, dz);
-    sm.gnorm = sqrtf(dot3(sm.grad, sm.grad));
-    sm.flat = !(sm.gnorm > 0.0f);
-    sm.ld = normalized3(make_f3(sm.px - light_pos.x, sm.py - light_pos.y, sm.pz - light_pos.z));
+    const float gn2 = dot3(sm.grad, sm.grad);
+    const f3 lv = make_f3(sm.px - light_pos.x, sm.py - light_pos.y, sm.pz - light_pos.z);
+    if (FAST) {
+        sm.flat = !(gn2 >= 1.17549435e-38f);  // zero (or denormal: |grad| < 1e-19) gradient
+        sm.ginv = __builtin_amdgcn_rsqf(gn2);
+        sm.gnorm = gn2 * sm.ginv;
+        const float li = __builtin_amdgcn_rsqf(dot3(lv, lv));
+        sm.ld = make_f3(li * lv.x, li * lv.y, li * lv.z);
+    } else {
+        sm.gnorm = sqrtf(gn2);
+        sm.flat = !(sm.gnorm > 0.0f);
+        sm.ginv = 1.0f / (sm.gnorm + 0.0f);
+        sm.ld = normalized3(lv);
+    }
     if (sm.flat) {
         // 0/0 normal in the reference; NaN-suppressing max() gives ndl = rdv = 0
         sm.nrm = make_f3(0.f, 0.f, 0.f);
         sm.m = 0.f; sm.ndl = 0.f; sm.rf = sm.ld; sm.q = 0.f; sm.rdv = 0.f;
     } else {
-        float inv = 1.0f / (sm.gnorm + 0.0f);
-        sm.nrm = make_f3(inv * dx, inv * dy, inv * dz);
+        sm.nrm = make_f3(sm.ginv * dx, sm.ginv * dy, sm.ginv * dz);
         sm.m = dot3(sm.nrm, sm.ld);
         sm.ndl = fmaxf(sm.m, 0.0f);
         float two_m = 2.0f * sm.m;
@@ -200,7 +214,7 @@ __device__ __forceinline__ void shade(const VolView<VT> &v, f3 light_pos, f3 vd,
     float dx = tri_sample(v, sm.px + delta, sm.py, sm.pz) - tri_sample(v, sm.px - delta, sm.py, sm.pz);
     float dy = tri_sample(v, sm.px, sm.py + delta, sm.pz) - tri_sample(v, sm.px, sm.py - delta, sm.pz);
     float dz = tri_sample(v, sm.px, sm.py, sm.pz + delta) - tri_sample(v, sm.px, sm.py, sm.pz - delta);
-    shade_from_grad(dx, dy, dz, light_pos, vd, clampL, sm);
+    shade_from_grad<false>(dx, dy, dz, light_pos, vd, clampL, sm);
 }
 
 // Adjoint of one composited sample: everything downstream of the taps.
@@ -211,11 +225,13 @@ struct SampleAdj {
     float r_bar, g_bar, b_bar, a_bar;  // d/d(tf colour, tf alpha) of this sample
     float gx, gy, gz;                   // d/d(dx,dy,dz); 0 when the normal is flat
 };
+template <bool FAST = false>
 __device__ __forceinline__ void sample_adjoint(const Sample &sm, f3 vd, float T, float suffix, bool last, float4 go,
                                                float inv_sr, SampleAdj &ad) {
     const float rgbdot = go.x * sm.r + go.y * sm.g + go.z * sm.b;  // gC . rgb
     const float qs = sm.L * rgbdot + go.w;
-    const float op_bar = T * qs - (last ? 0.0f : suffix / (1.0f - sm.op));
+    const float sfx = FAST ? suffix * __builtin_amdgcn_rcpf(1.0f - sm.op) : suffix / (1.0f - sm.op);
+    const float op_bar = T * qs - (last ? 0.0f : sfx);
     const float Lop = sm.L * sm.op * T;
     ad.r_bar = Lop * go.x; ad.g_bar = Lop * go.y; ad.b_bar = Lop * go.z;
     const float L_bar = sm.op * T * rgbdot;
@@ -235,7 +251,7 @@ __device__ __forceinline__ void sample_adjoint(const Sample &sm, f3 vd, float T,
     const f3 n_bar = make_f3(m2 * rf_bar.x + m_bar * sm.ld.x, m2 * rf_bar.y + m_bar * sm.ld.y,
                              m2 * rf_bar.z + m_bar * sm.ld.z);
     const float nn = dot3(sm.nrm, n_bar);
-    const float inv = 1.0f / sm.gnorm;
+    const float inv = sm.ginv;
     ad.gx = inv * (n_bar.x - sm.nrm.x * nn);
     ad.gy = inv * (n_bar.y - sm.nrm.y * nn);
     ad.gz = inv * (n_bar.z - sm.nrm.z * nn);

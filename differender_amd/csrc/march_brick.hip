@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void brick_fwd_kernel(BrickParams<VT> P) {
                 sample_taps_lds(L.box, t, sm.I, dx, dy, dz);
                 classify_from_I(L.tf, P.R, P.tf_len, P.inv_sr, sm);
                 if (MODE == DR_MODE_NONDIFF && !(sm.a > 1e-3f)) continue;
-                shade_from_grad(dx, dy, dz, light, vd, MODE == DR_MODE_DIFF, sm);
+                shade_from_grad<true>(dx, dy, dz, light, vd, MODE == DR_MODE_DIFF, sm);
                 const float T = 1.0f - A;
                 C0 = fmaf(T, sm.L * sm.r * sm.op, C0);
                 C1 = fmaf(T, sm.L * sm.g * sm.op, C1);
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void brick_bwd_kernel(BrickParams<VT> P) {
                 float dx, dy, dz;
                 sample_taps_lds(L.box, t, sm.I, dx, dy, dz);
                 classify_from_I(L.tf, P.R, P.tf_len, P.inv_sr, sm);
-                shade_from_grad(dx, dy, dz, light, vd, true, sm);
+                shade_from_grad<true>(dx, dy, dz, light, vd, true, sm);
                 const float T = 1.0f - A;
                 C0 = fmaf(T, sm.L * sm.r * sm.op, C0);
                 C1 = fmaf(T, sm.L * sm.g * sm.op, C1);
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void brick_bwd_kernel(BrickParams<VT> P) {
                 const bool last = (s == live - 1);
                 const float suffix = (go.x * (of.x - C0) + go.y * (of.y - C1) + go.z * (of.z - C2)) + go.w * (of.w - A);
                 SampleAdj ad;
-                sample_adjoint(sm, vd, T, suffix, last, go, P.inv_sr, ad);
+                sample_adjoint<true>(sm, vd, T, suffix, last, go, P.inv_sr, ad);
                 if (WANT_TF) {
                     if (sm.lo != tf_lo) {
                         if (tf_lo >= 0) {

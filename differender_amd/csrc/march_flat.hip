@@ -16,9 +16,9 @@
 
 namespace dr {
 
-constexpr int FNT = 512;          // threads per workgroup
-constexpr int FNW = FNT / 64;     // waves per workgroup
-constexpr int FEC_FWD = 512;      // ray segments listed per round (forward)
+constexpr int FNT_FWD = 256;      // threads per workgroup (forward: 43 KB of LDS -> 3 workgroups per CU)
+constexpr int FNT_BWD = 512;      // (backward: 118 KB of LDS -> one workgroup per CU, so make it 8 waves)
+constexpr int FEC_FWD = 256;      // ray segments listed per round (<= threads: one candidate per thread)
 constexpr int FEC_BWD = 256;      // (backward: the entry table also holds prefix / gradient / output)
 
 struct FlatLds {
@@ -67,7 +67,7 @@ __device__ __forceinline__ FlatLds flat_carve(unsigned char *smem, int R, bool w
     return L;
 }
 
-template <typename VT>
+template <typename VT, int FNT>
 __device__ __forceinline__ void flat_load_tf_and_box(const BrickParams<VT> &P, const VolView<VT> &vol,
                                                      const BrickCtx &c, const float4 *tfg, FlatLds &L) {
     for (int k = threadIdx.x; k < P.R; k += FNT) L.tf[k] = tfg[k];
@@ -85,10 +85,11 @@ __device__ __forceinline__ void flat_load_tf_and_box(const BrickParams<VT> &P, c
 }
 
 // List the ray segments of candidates [cbase, cbase+EC) and their flat offsets. Returns (nE, M) via misc.
-template <typename VT, int MODE, bool BWD>
+template <typename VT, int MODE, bool BWD, int FNT>
 __device__ __forceinline__ void flat_build_entries(const BrickParams<VT> &P, const BrickCtx &c, f3 cam, int view,
                                                    int cbase, int ncand, size_t seg_base, FlatLds &L, int &nE, int &M) {
     constexpr int EC = BWD ? FEC_BWD : FEC_FWD;
+    constexpr int FNW = FNT / 64;
     static_assert(EC <= FNT, "one candidate per thread and round");
     const int NP = P.W * P.H;
     const int nj = c.j1 - c.j0 + 1;
@@ -266,10 +267,30 @@ __device__ __forceinline__ Over shfl_up1_over(const Over &v) {
     return r;
 }
 
+// adj * trilinear weight of each corner, order (x,y,z) = 000,100,010,110,001,101,011,111
+__device__ __forceinline__ void corner_weights(float fx, float fy, float fz, float adj, float (&w)[8]) {
+    const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;
+    const float a00 = gx * gy * adj, a10 = fx * gy * adj, a01 = gx * fy * adj, a11 = fx * fy * adj;
+    w[0] = a00 * gz; w[1] = a10 * gz; w[2] = a01 * gz; w[3] = a11 * gz;
+    w[4] = a00 * fz; w[5] = a10 * fz; w[6] = a01 * fz; w[7] = a11 * fz;
+}
+__device__ __forceinline__ void scatter8(unsigned long long *dbox, int base, const float (&w)[8], const FixScale &f) {
+    fix_add(dbox + base, w[0], f);
+    fix_add(dbox + base + BOX_SX, w[1], f);
+    fix_add(dbox + base + BOX_SY, w[2], f);
+    fix_add(dbox + base + BOX_SX + BOX_SY, w[3], f);
+    fix_add(dbox + base + 1, w[4], f);
+    fix_add(dbox + base + BOX_SX + 1, w[5], f);
+    fix_add(dbox + base + BOX_SY + 1, w[6], f);
+    fix_add(dbox + base + BOX_SX + BOX_SY + 1, w[7], f);
+}
+
 template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF>
-__global__ __launch_bounds__(FNT) void brick_flat_kernel(BrickParams<VT> P) {
+__global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD) void brick_flat_kernel(BrickParams<VT> P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int EC = BWD ? FEC_BWD : FEC_FWD;
+    constexpr int FNT = BWD ? FNT_BWD : FNT_FWD;
+    constexpr int FNW = FNT / 64;
     const int view = blockIdx.y;
     const f3 cam = make_f3(P.cam[3 * view], P.cam[3 * view + 1], P.cam[3 * view + 2]);
     BrickCtx c;
@@ -279,7 +300,7 @@ __global__ __launch_bounds__(FNT) void brick_flat_kernel(BrickParams<VT> P) {
     FlatLds L = flat_carve<BWD>(smem, P.R, WANT_VOL, WANT_TF);
     VolView<VT> vol = P.vol;
     vol.p += view * P.vol_vs;
-    flat_load_tf_and_box(P, vol, c, P.tf + view * P.tf_vs, L);
+    flat_load_tf_and_box<VT, FNT>(P, vol, c, P.tf + view * P.tf_vs, L);
     FixScale fs;
     if (BWD) {
         if (WANT_VOL) for (int k = threadIdx.x; k < BOX_N; k += FNT) L.dbox[k] = 0ull;
@@ -295,7 +316,7 @@ __global__ __launch_bounds__(FNT) void brick_flat_kernel(BrickParams<VT> P) {
 
     for (int cbase = 0; cbase < ncand; cbase += EC) {
         int nE, M;
-        flat_build_entries<VT, MODE, BWD>(P, c, cam, view, cbase, ncand, seg_base, L, nE, M);  // syncs inside
+        flat_build_entries<VT, MODE, BWD, FNT>(P, c, cam, view, cbase, ncand, seg_base, L, nE, M);  // syncs inside
         any = any || nE > 0;
         // this wave owns the contiguous entry range [ea, eb): segments never straddle two waves
         const int ea = lower_bound_offs(L.offs, nE, (int)(((long long)M * wave) / FNW));
@@ -326,7 +347,7 @@ __global__ __launch_bounds__(FNT) void brick_flat_kernel(BrickParams<VT> P) {
                 sample_taps_lds(L.box, t, sm.I, dx, dy, dz);
                 classify_from_I(L.tf, P.R, P.tf_len, P.inv_sr, sm);
                 if (!(MODE == DR_MODE_NONDIFF && !(sm.a > 1e-3f))) {
-                    shade_from_grad(dx, dy, dz, light, vd, MODE == DR_MODE_DIFF, sm);
+                    shade_from_grad<true>(dx, dy, dz, light, vd, MODE == DR_MODE_DIFF, sm);
                     el.c0 = sm.L * sm.r * sm.op; el.c1 = sm.L * sm.g * sm.op; el.c2 = sm.L * sm.b * sm.op; el.a = sm.op;
                     shaded = true;
                 }
@@ -373,7 +394,7 @@ __global__ __launch_bounds__(FNT) void brick_flat_kernel(BrickParams<VT> P) {
                     const bool last = (s == L.live[e] - 1);
                     const float suffix = (go.x * (of.x - absi.c0) + go.y * (of.y - absi.c1) + go.z * (of.z - absi.c2)) +
                                          go.w * (of.w - absi.a);
-                    sample_adjoint(sm, vd, T, suffix, last, go, P.inv_sr, ad);
+                    sample_adjoint<true>(sm, vd, T, suffix, last, go, P.inv_sr, ad);
                 }
                 if (WANT_TF) {
                     // neighbouring lanes are consecutive samples of a ray: long runs fall between the same two
@@ -394,19 +415,54 @@ __global__ __launch_bounds__(FNT) void brick_flat_kernel(BrickParams<VT> P) {
                         fix_add(d1 + 2, fix_clamp(tv[6], fs), fs); fix_add(d1 + 3, fix_clamp(tv[7], fs), fs);
                     }
                 }
-                if (WANT_VOL && valid) {
-                    const float I_bar = fix_clamp(intensity_adjoint(sm, L.tf[sm.lo], L.tf[sm.hi], ad, P.tf_len), fs);
-                    const int by = t.ly * BOX_SY, bz = t.lz, bx = t.lx * BOX_SX;
-                    tri_scatter_lds(L.dbox, bx + by + bz, t.fx, t.fy, t.fz, I_bar, fs);
-                    if (!sm.flat) {
-                        const float gx = fix_clamp(ad.gx, fs), gy = fix_clamp(ad.gy, fs), gz = fix_clamp(ad.gz, fs);
-                        tri_scatter_lds(L.dbox, t.lxp * BOX_SX + by + bz, t.fxp, t.fy, t.fz, gx, fs);
-                        tri_scatter_lds(L.dbox, t.lxm * BOX_SX + by + bz, t.fxm, t.fy, t.fz, -gx, fs);
-                        tri_scatter_lds(L.dbox, bx + t.lyp * BOX_SY + bz, t.fx, t.fyp, t.fz, gy, fs);
-                        tri_scatter_lds(L.dbox, bx + t.lym * BOX_SY + bz, t.fx, t.fym, t.fz, -gy, fs);
-                        tri_scatter_lds(L.dbox, bx + by + t.lzp, t.fx, t.fy, t.fzp, gz, fs);
-                        tri_scatter_lds(L.dbox, bx + by + t.lzm, t.fx, t.fy, t.fzm, -gz, fs);
+                if (WANT_VOL) {
+                    // d_volume. The 7 taps of a sample address the 8 corners of <= 7 cells, but a normal tap that
+                    // stays in the centre cell hits the SAME 8 voxels: fold it into the centre's 8 sums in
+                    // registers. Consecutive lanes (consecutive samples of a ray) mostly share the centre cell as
+                    // well: sum those runs across lanes (DPP) so that one lane per run touches LDS -- duplicate
+                    // addresses inside one ds_add cost ~8 cycles each (tools/microbench/lds_atomic_bench2).
+                    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    const int cbase_i = valid ? (t.lx * BOX_SX + t.ly * BOX_SY + t.lz) : (-1 - lane);
+                    float gq[3] = {0.f, 0.f, 0.f};
+                    if (valid) {
+                        const float I_bar = fix_clamp(intensity_adjoint(sm, L.tf[sm.lo], L.tf[sm.hi], ad, P.tf_len), fs);
+                        corner_weights(t.fx, t.fy, t.fz, I_bar, acc);
+                        if (!sm.flat) { gq[0] = fix_clamp(ad.gx, fs); gq[1] = fix_clamp(ad.gy, fs); gq[2] = fix_clamp(ad.gz, fs); }
                     }
+                    // per axis: taps inside the centre cell are folded; at most one of the +- pair can leave it
+                    // while delta < 0.5 voxel, the (rare) second one is handled under a wave-uniform branch
+                    const int lcp[3] = {t.lxp, t.lyp, t.lzp}, lcm[3] = {t.lxm, t.lym, t.lzm}, lc0[3] = {t.lx, t.ly, t.lz};
+                    const float fpv[3] = {t.fxp, t.fyp, t.fzp}, fmv[3] = {t.fxm, t.fym, t.fzm};
+                    const int strd[3] = {BOX_SX, BOX_SY, 1};
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const bool live_k = valid && gq[k] != 0.0f;
+                        const bool in_p = lcp[k] == lc0[k], in_m = lcm[k] == lc0[k];
+                        float fx = t.fx, fy = t.fy, fz = t.fz;
+                        float wp[8], wm[8];
+                        (k == 0 ? fx : k == 1 ? fy : fz) = fpv[k];
+                        corner_weights(fx, fy, fz, gq[k], wp);    // +delta tap
+                        (k == 0 ? fx : k == 1 ? fy : fz) = fmv[k];
+                        corner_weights(fx, fy, fz, -gq[k], wm);   // -delta tap
+                        const bool out_p = live_k && !in_p, out_m = live_k && !in_m;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) acc[q] += ((live_k && in_p) ? wp[q] : 0.0f) + ((live_k && in_m) ? wm[q] : 0.0f);
+                        if (out_p || out_m) {  // one scatter serves whichever tap left the centre cell
+                            float wo[8];
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) wo[q] = out_p ? wp[q] : wm[q];
+                            scatter8(L.dbox, cbase_i + ((out_p ? lcp[k] : lcm[k]) - lc0[k]) * strd[k], wo, fs);
+                        }
+                        if (__any(out_p && out_m)) {  // both left it: only when delta >= 0.5 voxel (dim > 1000)
+                            if (out_p && out_m) scatter8(L.dbox, cbase_i + (lcm[k] - lc0[k]) * strd[k], wm, fs);
+                        }
+                    }
+                    // centre corners: run-reduce over lanes with the same centre cell, run tails add to LDS
+                    const int kprev = __shfl_up(cbase_i, 1);
+                    const int rs = scan_max((lane == 0 || cbase_i != kprev) ? lane : 0, lane);
+                    seg_scan_sum<8>(acc, lane, rs);
+                    const int knext = __shfl_down(cbase_i, 1);
+                    if (valid && (lane == 63 || knext != cbase_i)) scatter8(L.dbox, cbase_i, acc, fs);
                 }
             }
             (void)shaded;
@@ -468,10 +524,10 @@ static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     const dim3 grid1(g.NBx * g.NBy * g.NBz, a.n_views);
     if (a.mode == DR_MODE_DIFF) {
         if ((e = allow_lds(brick_flat_kernel<VT, DR_MODE_DIFF, false, false, false>, lds)) != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((brick_flat_kernel<VT, DR_MODE_DIFF, false, false, false>), grid1, dim3(FNT), lds, stream, P);
+        hipLaunchKernelGGL((brick_flat_kernel<VT, DR_MODE_DIFF, false, false, false>), grid1, dim3(FNT_FWD), lds, stream, P);
     } else {
         if ((e = allow_lds(brick_flat_kernel<VT, DR_MODE_NONDIFF, false, false, false>, lds)) != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((brick_flat_kernel<VT, DR_MODE_NONDIFF, false, false, false>), grid1, dim3(FNT), lds, stream, P);
+        hipLaunchKernelGGL((brick_flat_kernel<VT, DR_MODE_NONDIFF, false, false, false>), grid1, dim3(FNT_FWD), lds, stream, P);
     }
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
     return launch_ray_compose(a, stream);
@@ -500,13 +556,13 @@ static int flat_bwd_dispatch(const MarchArgs &a, hipStream_t stream) {
                        w.stats + 1);
     if (wv && wt) {
         if ((e = allow_lds(brick_flat_kernel<VT, DR_MODE_DIFF, true, true, true>, lds)) != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((brick_flat_kernel<VT, DR_MODE_DIFF, true, true, true>), grid1, dim3(FNT), lds, stream, P);
+        hipLaunchKernelGGL((brick_flat_kernel<VT, DR_MODE_DIFF, true, true, true>), grid1, dim3(FNT_BWD), lds, stream, P);
     } else if (wv) {
         if ((e = allow_lds(brick_flat_kernel<VT, DR_MODE_DIFF, true, true, false>, lds)) != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((brick_flat_kernel<VT, DR_MODE_DIFF, true, true, false>), grid1, dim3(FNT), lds, stream, P);
+        hipLaunchKernelGGL((brick_flat_kernel<VT, DR_MODE_DIFF, true, true, false>), grid1, dim3(FNT_BWD), lds, stream, P);
     } else {
         if ((e = allow_lds(brick_flat_kernel<VT, DR_MODE_DIFF, true, false, true>, lds)) != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((brick_flat_kernel<VT, DR_MODE_DIFF, true, false, true>), grid1, dim3(FNT), lds, stream, P);
+        hipLaunchKernelGGL((brick_flat_kernel<VT, DR_MODE_DIFF, true, false, true>), grid1, dim3(FNT_BWD), lds, stream, P);
     }
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
     MarchArgs b = a;
