@@ -1,0 +1,122 @@
+"""BASELINE.json's full size (512^3 f32 volume, 512^2 image, 256-entry TF) on the GPU: oracle parity on
+pixel patches (the oracle is too slow for the whole image) plus size-independent properties: sample-count
+conservation, agreement of independent kernel variants, linearity of the backward, run-to-run stability."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+N, IMG, R = 512, 512, 256
+
+
+@pytest.fixture(scope="module")
+def scene(hiplib):
+    import bench
+    from differender_amd import functional as F
+    dev = torch.device("cuda:0")
+    vol = bench.synth_volume_torch(N, dev)
+    tf = bench.bench_tf_torch(R, 3.0 / (6.0 * (N - 1)), dev)
+    tf[:, 3] = torch.linspace(0.0005, 0.0025, R, device=dev)  # non-constant alpha: d_vol sees the TF slope
+    cam = torch.tensor([bench.in_circles(0.4)], dtype=torch.float32, device=dev)
+    e, x, r, n = F.ray_setup(cam, (IMG, IMG), (N, N, N), 1.0)
+    return dict(F=F, dev=dev, vol=vol, tf=tf, cam=cam, rays=(e, x, r, n))
+
+
+def _fwd(sc, variant, mode=0, tf=None):
+    F = sc["F"]
+    ws = F.alloc_workspace(1, (IMG, IMG), (N, N, N), R, sc["dev"]) if variant != 1 else None
+    out, steps = F.march_fwd(sc["vol"], sc["tf"] if tf is None else tf, sc["cam"], *sc["rays"], 1 << 20, 1.0, mode,
+                             variant=variant, workspace=ws)
+    return out, steps, ws
+
+
+def test_sample_conservation_and_variant_agreement(scene):
+    F = scene["F"]
+    n = scene["rays"][3]
+    out0, steps0, ws0 = _fwd(scene, 0)
+    assert int(F.workspace_stats(ws0)[0]) == 0, "rays fell back to individual marching"
+    assert torch.equal(steps0, n)  # alpha this low never terminates a ray: every planned sample is marched
+    assert int(steps0.sum()) > 2.0e8
+    out2, steps2, ws2 = _fwd(scene, 2)
+    assert torch.equal(steps2, n)
+    assert float((out0 - out2).abs().max()) <= 1e-5
+    outb, stepsb, _ = _fwd(scene, 1)
+    assert float((out0 - outb).abs().max()) <= 1e-5 and torch.equal(stepsb, n)
+
+
+def test_patch_parity_with_oracle(scene, oracle):
+    """Oracle on three 12x12 pixel patches of the 512^2 image (full 512^3 volume on the host)."""
+    F = scene["F"]
+    e, x, r, n = (t[0].cpu().numpy() for t in scene["rays"])
+    vol_h = scene["vol"].cpu().numpy(); tf_h = scene["tf"].cpu().numpy(); cam_h = scene["cam"][0].cpu().numpy()
+    out, steps, ws = _fwd(scene, 0)
+    out_h = out[0].cpu().numpy()
+    rng = np.random.RandomState(11)
+    g = np.zeros((IMG, IMG, 4), np.float32)
+    patches = [(250, 250), (100, 300), (330, 60)]
+    refs = []
+    for (i0, j0) in patches:
+        sl = (slice(i0, i0 + 12), slice(j0, j0 + 12))
+        ref, st = oracle.march_fwd(vol_h, tf_h, cam_h, e[sl], x[sl], r[sl], n[sl], 1 << 20, 1.0, 0)
+        assert np.abs(out_h[sl] - ref).max() <= 1e-5
+        g[sl] = rng.randn(12, 12, 4).astype(np.float32)
+        refs.append(sl)
+    # backward with the upstream gradient confined to the patches
+    dv_ref = np.zeros_like(vol_h); dt_ref = np.zeros_like(tf_h)
+    for sl in refs:
+        a, b = oracle.march_bwd(vol_h, tf_h, cam_h, e[sl], x[sl], r[sl], n[sl], 1 << 20, 1.0, g[sl])
+        dv_ref += a; dt_ref += b
+    dv, dt = F.march_bwd(scene["vol"], scene["tf"], scene["cam"], *scene["rays"], 1 << 20, 1.0,
+                         torch.from_numpy(g[None]).to(scene["dev"]), out, workspace=ws)
+    dv_h = dv.cpu().numpy(); dt_h = dt.cpu().numpy()
+    assert np.abs(dt_h - dt_ref).max() <= 1e-4 * np.abs(dt_ref).max()
+    assert np.abs(dv_h - dv_ref).max() <= 1e-4 * np.abs(dv_ref).max()
+    assert np.count_nonzero(dv_h) == np.count_nonzero(dv_ref) or np.abs(dv_h[dv_ref == 0]).max() <= 1e-6 * np.abs(dv_ref).max()
+
+
+def test_backward_linearity_and_stability(scene):
+    F = scene["F"]
+    dev = scene["dev"]
+    out, steps, ws = _fwd(scene, 0)
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    g1 = torch.randn((1, IMG, IMG, 4), generator=gen).to(dev)
+    g2 = torch.randn((1, IMG, IMG, 4), generator=gen).to(dev)
+
+    def bwd(g):
+        return F.march_bwd(scene["vol"], scene["tf"], scene["cam"], *scene["rays"], 1 << 20, 1.0, g, out, workspace=ws)
+
+    dv1, dt1 = bwd(g1)
+    dv2, dt2 = bwd(g2)
+    dv3, dt3 = bwd(2.0 * g1 - 0.5 * g2)
+    sv = float(dv3.abs().max()); st = float(dt3.abs().max())
+    assert float((dv3 - (2.0 * dv1 - 0.5 * dv2)).abs().max()) <= 2e-5 * sv
+    assert float((dt3 - (2.0 * dt1 - 0.5 * dt2)).abs().max()) <= 2e-5 * st
+    dv1b, dt1b = bwd(g1)  # float atomics across bricks may reorder: equal up to rounding
+    assert float((dv1b - dv1).abs().max()) <= 1e-6 * float(dv1.abs().max())
+    assert float((dt1b - dt1).abs().max()) <= 1e-6 * float(dt1.abs().max())
+    assert torch.isfinite(dv1).all() and torch.isfinite(dt1).all()
+    # a second variant of the backward (one lane per ray segment) agrees
+    out2, _, ws2 = _fwd(scene, 2)
+    dvr, dtr = F.march_bwd(scene["vol"], scene["tf"], scene["cam"], *scene["rays"], 1 << 20, 1.0, g1, out2, variant=2,
+                           workspace=ws2)
+    assert float((dvr - dv1).abs().max()) <= 1e-4 * float(dv1.abs().max())
+    assert float((dtr - dt1).abs().max()) <= 1e-4 * float(dt1.abs().max())
+
+
+def test_early_termination_at_full_size(scene):
+    """An opaque-ish TF: rays stop early; the exact re-march of the crossing segment must agree with the baseline."""
+    tf = scene["tf"].clone()
+    tf[:, 3] = torch.linspace(0.0, 0.2, R, device=scene["dev"])
+    out0, steps0, ws0 = _fwd(scene, 0, tf=tf)
+    outb, stepsb, _ = _fwd(scene, 1, tf=tf)
+    n = scene["rays"][3]
+    assert float((steps0 < n).float().mean()) > 0.5
+    same = steps0 == stepsb
+    assert float(same.float().mean()) > 0.999
+    assert float((out0 - outb).abs().amax(-1)[same].max()) <= 1e-5
+    assert float((out0 - outb).abs().max()) <= 2e-3
