@@ -164,8 +164,23 @@ def main():
                 "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "avg_launch_ms": round(ms, 4),
                 "bytes_per_voxel_step": bytes_per_step, "voxel_steps_per_launch": int(steps_per_launch)}
 
+    # HBM bytes per launch from the latest committed PMC profile (collected with tools/profile_round.sh in
+    # separate --pmc passes: FETCH_SIZE, WRITE_SIZE). FETCH_SIZE is reported raw: the guide's x2 correction applies
+    # to 16-B-per-lane streaming reads, these kernels read 4-B elements in 19-element rows (uncalibrated width).
+    traffic = {}
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_per_launch.json")))
+        for k, v in pm.items():
+            if "brick_flat_kernel" in k and "FETCH_SIZE" in v:
+                traffic["bwd" if "true" in k.split("<")[1].split(",")[2] else "fwd"] = int((v["FETCH_SIZE"] + v.get("WRITE_SIZE", 0)) * 1024)
+    except Exception:
+        pass
     roof_fwd = roof("march_fwd", fwd_ms, B_FWD)
     roof_bwd = roof("march_bwd", bwd_ms, B_BWD_VOL if want_vol else B_BWD_TF) if want_bwd else None
+    if N == 512 and IMG == 512 and args.variant == 0:
+        roof_fwd["traffic"] = traffic.get("fwd")
+        if roof_bwd and want_vol and want_tf:
+            roof_bwd["traffic"] = traffic.get("bwd")
     dominant = roof_bwd if (roof_bwd and bwd_ms >= fwd_ms) else roof_fwd
 
     cpu_baseline = None
