@@ -250,6 +250,7 @@ __device__ __forceinline__ void load_ray(const float *entry, const float *exit_,
 // value = x * 2^shift, stored as a two's-complement int64. fx_hi = 2^(shift-32) is passed around as a float.
 struct FixScale {
     float hi;    // 2^(shift-32): x*hi has the high word in its integer part, the low word in its fraction
+    float lo;    // 2^shift
     float lim;   // adjoints are clamped to +-lim = 2^20 * max|grad_out| (keeps every sum inside 63 bits)
     double inv;  // 2^-shift
 };
@@ -261,6 +262,7 @@ __device__ __forceinline__ FixScale make_fix_scale(unsigned int gmax_bits) {
     const int shift = 28 - e;    // gmax * 2^shift < 2^28
     FixScale f;
     f.hi = ldexpf(1.0f, shift - 32);
+    f.lo = ldexpf(1.0f, shift);
     f.lim = ldexpf(1.0f, e + 20);
     f.inv = ldexp(1.0, -shift);
     return f;
@@ -268,13 +270,24 @@ __device__ __forceinline__ FixScale make_fix_scale(unsigned int gmax_bits) {
 __device__ __forceinline__ float fix_clamp(float x, const FixScale &f) {
     return fminf(fmaxf(x, -f.lim), f.lim);  // NaN -> -lim (finite), as nan_to_num would make it finite later
 }
-__device__ __forceinline__ void fix_add(unsigned long long *p, float x, const FixScale &f) {
+// Exact conversion (any magnitude inside the clamp): split x*2^(shift-32) into integer and fraction.
+__device__ __forceinline__ void fix_add_wide(unsigned long long *p, float x, const FixScale &f) {
     const float t = x * f.hi;
     const float hf = floorf(t);
     const unsigned int lo = (unsigned int)((t - hf) * 4294967296.0f);  // fraction in [0,1): exact product
     const unsigned long long v = ((unsigned long long)(unsigned int)(int)hf << 32) | lo;
     atomicAdd(p, v);  // ds_add_u64
 }
+// Common case: |x * 2^shift| < 2^31 -- one multiply, one float->int conversion (exact to 2^-shift), a sign
+// extension. Callers test the magnitude once per sample (fix_fits) and pick WIDE under a wave-uniform branch.
+__device__ __forceinline__ bool fix_fits(float absmax, const FixScale &f) { return absmax * f.lo < 2147483520.0f; }
+template <bool WIDE>
+__device__ __forceinline__ void fix_add_t(unsigned long long *p, float x, const FixScale &f) {
+    if (WIDE) { fix_add_wide(p, x, f); return; }
+    const int q = __float2int_rn(x * f.lo);
+    atomicAdd(p, (unsigned long long)(long long)q);  // ds_add_u64
+}
+__device__ __forceinline__ void fix_add(unsigned long long *p, float x, const FixScale &f) { fix_add_wide(p, x, f); }
 __device__ __forceinline__ float fix_to_float(unsigned long long v, const FixScale &f) {
     return (float)((double)(long long)v * f.inv);
 }

@@ -39,7 +39,7 @@ __host__ __device__ inline size_t flat_lds_bytes(int R, bool want_vol, bool want
     if (BWD && want_vol) s += align16(BOX_N * 8);
     if (BWD && want_tf) s += (size_t)R * 32;
     s += (size_t)EC * 32 + (BWD ? (size_t)EC * 48 : 0);
-    s += (size_t)EC * 4 + align16((EC + 1) * 4) + (size_t)EC * 4 + (BWD ? (size_t)EC * 4 : 0) + 64;  // + misc
+    s += (size_t)EC * 4 + align16((EC + 1) * 4) + (size_t)EC * 4 + (BWD ? (size_t)EC * 4 : 0) + 128;  // + misc (32 ints)
     return s;
 }
 template <bool BWD>
@@ -63,7 +63,7 @@ __device__ __forceinline__ FlatLds flat_carve(unsigned char *smem, int R, bool w
     L.offs = reinterpret_cast<int *>(smem + o); o += align16((EC + 1) * 4);
     L.valid = reinterpret_cast<int *>(smem + o); o += (size_t)EC * 4;
     if (BWD) { L.live = reinterpret_cast<int *>(smem + o); o += (size_t)EC * 4; }
-    L.misc = reinterpret_cast<int *>(smem + o);  // 16 ints
+    L.misc = reinterpret_cast<int *>(smem + o);  // 32 ints: [1] M, [4 + wave] per-wave entry counts
     return L;
 }
 
@@ -235,8 +235,8 @@ __device__ __forceinline__ void seg_scan_sum(float (&v)[NV], int lane, int sl) {
     {                                                                    \
         const bool ok = scan_src_ok<K>(lane, sl);                        \
         _Pragma("unroll") for (int i = 0; i < NV; ++i) {                 \
-            const float o = dpp_f<CTRL>(v[i]);                           \
-            v[i] += ok ? o : 0.0f;                                       \
+            const float t = v[i] + dpp_f<CTRL>(v[i]);                    \
+            v[i] = ok ? t : v[i];                                        \
         }                                                                \
     }
     DR_SUM_STEP(0x111, 0) DR_SUM_STEP(0x112, 1) DR_SUM_STEP(0x114, 2) DR_SUM_STEP(0x118, 3)
@@ -274,15 +274,54 @@ __device__ __forceinline__ void corner_weights(float fx, float fy, float fz, flo
     w[0] = a00 * gz; w[1] = a10 * gz; w[2] = a01 * gz; w[3] = a11 * gz;
     w[4] = a00 * fz; w[5] = a10 * fz; w[6] = a01 * fz; w[7] = a11 * fz;
 }
+template <bool WIDE>
 __device__ __forceinline__ void scatter8(unsigned long long *dbox, int base, const float (&w)[8], const FixScale &f) {
-    fix_add(dbox + base, w[0], f);
-    fix_add(dbox + base + BOX_SX, w[1], f);
-    fix_add(dbox + base + BOX_SY, w[2], f);
-    fix_add(dbox + base + BOX_SX + BOX_SY, w[3], f);
-    fix_add(dbox + base + 1, w[4], f);
-    fix_add(dbox + base + BOX_SX + 1, w[5], f);
-    fix_add(dbox + base + BOX_SY + 1, w[6], f);
-    fix_add(dbox + base + BOX_SX + BOX_SY + 1, w[7], f);
+    fix_add_t<WIDE>(dbox + base, w[0], f);
+    fix_add_t<WIDE>(dbox + base + BOX_SX, w[1], f);
+    fix_add_t<WIDE>(dbox + base + BOX_SY, w[2], f);
+    fix_add_t<WIDE>(dbox + base + BOX_SX + BOX_SY, w[3], f);
+    fix_add_t<WIDE>(dbox + base + 1, w[4], f);
+    fix_add_t<WIDE>(dbox + base + BOX_SX + 1, w[5], f);
+    fix_add_t<WIDE>(dbox + base + BOX_SY + 1, w[6], f);
+    fix_add_t<WIDE>(dbox + base + BOX_SX + BOX_SY + 1, w[7], f);
+}
+
+// d_volume scatter of one sample: in-cell normal taps folded into the centre's 8 corners, at most one tap per
+// axis leaves the centre cell while delta < 0.5 voxel (the rare second one under a wave-uniform branch).
+template <bool WIDE>
+__device__ __forceinline__ void scatter_sample(unsigned long long *dbox, const TapCoords &t, bool valid, int cbase_i,
+                                               float I_bar, const float (&gq)[3], const FixScale &fs) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (valid) corner_weights(t.fx, t.fy, t.fz, I_bar, acc);
+    const int lcp[3] = {t.lxp, t.lyp, t.lzp}, lcm[3] = {t.lxm, t.lym, t.lzm}, lc0[3] = {t.lx, t.ly, t.lz};
+    const float fpv[3] = {t.fxp, t.fyp, t.fzp}, fmv[3] = {t.fxm, t.fym, t.fzm};
+    const int strd[3] = {BOX_SX, BOX_SY, 1};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const bool live_k = valid && gq[k] != 0.0f;
+        const bool in_p = lcp[k] == lc0[k], in_m = lcm[k] == lc0[k];
+        float fx = t.fx, fy = t.fy, fz = t.fz;
+        float wp[8], wm[8];
+        (k == 0 ? fx : k == 1 ? fy : fz) = fpv[k];
+        corner_weights(fx, fy, fz, gq[k], wp);    // +delta tap
+        (k == 0 ? fx : k == 1 ? fy : fz) = fmv[k];
+        corner_weights(fx, fy, fz, -gq[k], wm);   // -delta tap
+        const bool out_p = live_k && !in_p, out_m = live_k && !in_m;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] += ((live_k && in_p) ? wp[q] : 0.0f) + ((live_k && in_m) ? wm[q] : 0.0f);
+        if (out_p || out_m) {  // one scatter serves whichever tap left the centre cell
+            float wo[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) wo[q] = out_p ? wp[q] : wm[q];
+            scatter8<WIDE>(dbox, cbase_i + ((out_p ? lcp[k] : lcm[k]) - lc0[k]) * strd[k], wo, fs);
+        }
+        if (__any(out_p && out_m)) {  // both left it: only when delta >= 0.5 voxel (dim > 1000)
+            if (out_p && out_m) scatter8<WIDE>(dbox, cbase_i + (lcm[k] - lc0[k]) * strd[k], wm, fs);
+        }
+    }
+    // centre corners (in-cell taps folded in). Lanes sharing a cell do collide here (~8 cycles per duplicate)
+    // but the LDS pipe has headroom while VALU does not: a cross-lane run reduction cost more than it saved.
+    if (valid) scatter8<WIDE>(dbox, cbase_i, acc, fs);
 }
 
 template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF>
@@ -407,7 +446,7 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD) void brick_flat_kernel(Bri
                                    w1 * ad.r_bar, w1 * ad.g_bar, w1 * ad.b_bar, w1 * ad.a_bar};
                     seg_scan_sum<8>(tv, lane, rs);
                     const int key_next = __shfl_down(key, 1);
-                    if (valid && (lane == 63 || key_next != key)) {
+                    if (valid && (lane == 63 || key_next != key)) {  // run totals may be large: exact wide adds
                         unsigned long long *d0 = L.dtf + 4 * sm.lo, *d1 = L.dtf + 4 * sm.hi;
                         fix_add(d0 + 0, fix_clamp(tv[0], fs), fs); fix_add(d0 + 1, fix_clamp(tv[1], fs), fs);
                         fix_add(d0 + 2, fix_clamp(tv[2], fs), fs); fix_add(d0 + 3, fix_clamp(tv[3], fs), fs);
@@ -416,53 +455,18 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD) void brick_flat_kernel(Bri
                     }
                 }
                 if (WANT_VOL) {
-                    // d_volume. The 7 taps of a sample address the 8 corners of <= 7 cells, but a normal tap that
-                    // stays in the centre cell hits the SAME 8 voxels: fold it into the centre's 8 sums in
-                    // registers. Consecutive lanes (consecutive samples of a ray) mostly share the centre cell as
-                    // well: sum those runs across lanes (DPP) so that one lane per run touches LDS -- duplicate
-                    // addresses inside one ds_add cost ~8 cycles each (tools/microbench/lds_atomic_bench2).
-                    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    const int cbase_i = valid ? (t.lx * BOX_SX + t.ly * BOX_SY + t.lz) : (-1 - lane);
+                    // d_volume: fixed-point adds into the LDS gradient box (dr_brick_common.h). A 32-bit addend
+                    // suffices unless some adjoint of the wave exceeds 2^31 / 2^shift (then: exact wide path).
+                    const int cbase_i = valid ? (t.lx * BOX_SX + t.ly * BOX_SY + t.lz) : 0;
+                    float I_bar = 0.f;
                     float gq[3] = {0.f, 0.f, 0.f};
                     if (valid) {
-                        const float I_bar = fix_clamp(intensity_adjoint(sm, L.tf[sm.lo], L.tf[sm.hi], ad, P.tf_len), fs);
-                        corner_weights(t.fx, t.fy, t.fz, I_bar, acc);
+                        I_bar = fix_clamp(intensity_adjoint(sm, L.tf[sm.lo], L.tf[sm.hi], ad, P.tf_len), fs);
                         if (!sm.flat) { gq[0] = fix_clamp(ad.gx, fs); gq[1] = fix_clamp(ad.gy, fs); gq[2] = fix_clamp(ad.gz, fs); }
                     }
-                    // per axis: taps inside the centre cell are folded; at most one of the +- pair can leave it
-                    // while delta < 0.5 voxel, the (rare) second one is handled under a wave-uniform branch
-                    const int lcp[3] = {t.lxp, t.lyp, t.lzp}, lcm[3] = {t.lxm, t.lym, t.lzm}, lc0[3] = {t.lx, t.ly, t.lz};
-                    const float fpv[3] = {t.fxp, t.fyp, t.fzp}, fmv[3] = {t.fxm, t.fym, t.fzm};
-                    const int strd[3] = {BOX_SX, BOX_SY, 1};
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const bool live_k = valid && gq[k] != 0.0f;
-                        const bool in_p = lcp[k] == lc0[k], in_m = lcm[k] == lc0[k];
-                        float fx = t.fx, fy = t.fy, fz = t.fz;
-                        float wp[8], wm[8];
-                        (k == 0 ? fx : k == 1 ? fy : fz) = fpv[k];
-                        corner_weights(fx, fy, fz, gq[k], wp);    // +delta tap
-                        (k == 0 ? fx : k == 1 ? fy : fz) = fmv[k];
-                        corner_weights(fx, fy, fz, -gq[k], wm);   // -delta tap
-                        const bool out_p = live_k && !in_p, out_m = live_k && !in_m;
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) acc[q] += ((live_k && in_p) ? wp[q] : 0.0f) + ((live_k && in_m) ? wm[q] : 0.0f);
-                        if (out_p || out_m) {  // one scatter serves whichever tap left the centre cell
-                            float wo[8];
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) wo[q] = out_p ? wp[q] : wm[q];
-                            scatter8(L.dbox, cbase_i + ((out_p ? lcp[k] : lcm[k]) - lc0[k]) * strd[k], wo, fs);
-                        }
-                        if (__any(out_p && out_m)) {  // both left it: only when delta >= 0.5 voxel (dim > 1000)
-                            if (out_p && out_m) scatter8(L.dbox, cbase_i + (lcm[k] - lc0[k]) * strd[k], wm, fs);
-                        }
-                    }
-                    // centre corners: run-reduce over lanes with the same centre cell, run tails add to LDS
-                    const int kprev = __shfl_up(cbase_i, 1);
-                    const int rs = scan_max((lane == 0 || cbase_i != kprev) ? lane : 0, lane);
-                    seg_scan_sum<8>(acc, lane, rs);
-                    const int knext = __shfl_down(cbase_i, 1);
-                    if (valid && (lane == 63 || knext != cbase_i)) scatter8(L.dbox, cbase_i, acc, fs);
+                    const float bound = fabsf(I_bar) + 2.0f * (fabsf(gq[0]) + fabsf(gq[1]) + fabsf(gq[2]));
+                    if (__any(!fix_fits(bound, fs))) scatter_sample<true>(L.dbox, t, valid, cbase_i, I_bar, gq, fs);
+                    else scatter_sample<false>(L.dbox, t, valid, cbase_i, I_bar, gq, fs);
                 }
             }
             (void)shaded;
