@@ -6,7 +6,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdifferender_hip.so")
+# DIFFERENDER_HIP_LIB lets tools/ab.sh time two builds of the library in one job (A/B on the same device)
+LIB_PATH = os.environ.get("DIFFERENDER_HIP_LIB") or os.path.join(_HERE, "libdifferender_hip.so")
 
 DR_F32, DR_F16 = 0, 1
 DR_MODE_DIFF, DR_MODE_NONDIFF = 0, 1

@@ -32,26 +32,29 @@ struct FlatLds {
     int *live;      // backward: live sample count of the ray
     int *misc;
 };
+// LDS layout: everything of compile-time size first (so every address below is an immediate), then the two
+// tables whose size depends on the run-time TF resolution R.
 template <bool BWD>
-__host__ __device__ inline size_t flat_lds_bytes(int R, bool want_vol, bool want_tf) {
-    const int EC = BWD ? FEC_BWD : FEC_FWD;
-    size_t s = (size_t)R * 16 + align16(BOX_N * 4);
-    if (BWD && want_vol) s += align16(BOX_N * 8);
-    if (BWD && want_tf) s += (size_t)R * 32;
+__host__ __device__ constexpr size_t flat_fixed_bytes(bool want_vol) {
+    constexpr int EC = BWD ? FEC_BWD : FEC_FWD;
+    size_t s = ((size_t)BOX_N * 4 + 15) / 16 * 16;
+    if (BWD && want_vol) s += ((size_t)BOX_N * 8 + 15) / 16 * 16;
     s += (size_t)EC * 32 + (BWD ? (size_t)EC * 48 : 0);
-    s += (size_t)EC * 4 + align16((EC + 1) * 4) + (size_t)EC * 4 + (BWD ? (size_t)EC * 4 : 0) + 128;  // + misc (32 ints)
+    s += (size_t)EC * 4 + (((size_t)EC + 1) * 4 + 15) / 16 * 16 + (size_t)EC * 4 + (BWD ? (size_t)EC * 4 : 0) + 128;
     return s;
 }
 template <bool BWD>
-__device__ __forceinline__ FlatLds flat_carve(unsigned char *smem, int R, bool want_vol, bool want_tf) {
-    const int EC = BWD ? FEC_BWD : FEC_FWD;
+__host__ __device__ inline size_t flat_lds_bytes(int R, bool want_vol, bool want_tf) {
+    return flat_fixed_bytes<BWD>(want_vol) + (size_t)R * 16 + ((BWD && want_tf) ? (size_t)R * 32 : 0);
+}
+template <bool BWD, bool WANT_VOL, bool WANT_TF>
+__device__ __forceinline__ FlatLds flat_carve(unsigned char *smem, int R) {
+    constexpr int EC = BWD ? FEC_BWD : FEC_FWD;
     FlatLds L;
     size_t o = 0;
-    L.tf = reinterpret_cast<float4 *>(smem + o); o += (size_t)R * 16;
     L.box = reinterpret_cast<float *>(smem + o); o += align16(BOX_N * 4);
     L.dbox = nullptr; L.dtf = nullptr; L.pre = L.go = L.of = nullptr; L.live = nullptr;
-    if (BWD && want_vol) { L.dbox = reinterpret_cast<unsigned long long *>(smem + o); o += align16(BOX_N * 8); }
-    if (BWD && want_tf) { L.dtf = reinterpret_cast<unsigned long long *>(smem + o); o += (size_t)R * 32; }
+    if (BWD && WANT_VOL) { L.dbox = reinterpret_cast<unsigned long long *>(smem + o); o += align16(BOX_N * 8); }
     L.ray0 = reinterpret_cast<float4 *>(smem + o); o += (size_t)EC * 16;
     L.ray1 = reinterpret_cast<float4 *>(smem + o); o += (size_t)EC * 16;
     if (BWD) {
@@ -63,7 +66,9 @@ __device__ __forceinline__ FlatLds flat_carve(unsigned char *smem, int R, bool w
     L.offs = reinterpret_cast<int *>(smem + o); o += align16((EC + 1) * 4);
     L.valid = reinterpret_cast<int *>(smem + o); o += (size_t)EC * 4;
     if (BWD) { L.live = reinterpret_cast<int *>(smem + o); o += (size_t)EC * 4; }
-    L.misc = reinterpret_cast<int *>(smem + o);  // 32 ints: [1] M, [4 + wave] per-wave entry counts
+    L.misc = reinterpret_cast<int *>(smem + o); o += 128;  // 32 ints: [1] M, [4 + wave] per-wave entry counts
+    L.tf = reinterpret_cast<float4 *>(smem + o); o += (size_t)R * 16;
+    if (BWD && WANT_TF) L.dtf = reinterpret_cast<unsigned long long *>(smem + o);
     return L;
 }
 
@@ -336,7 +341,7 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD) void brick_flat_kernel(Bri
     brick_setup(P, blockIdx.x, cam, c);
     if (c.i0 > c.i1 || c.j0 > c.j1) return;  // uniform: the brick projects outside the image
 
-    FlatLds L = flat_carve<BWD>(smem, P.R, WANT_VOL, WANT_TF);
+    FlatLds L = flat_carve<BWD, WANT_VOL, WANT_TF>(smem, P.R);
     VolView<VT> vol = P.vol;
     vol.p += view * P.vol_vs;
     flat_load_tf_and_box<VT, FNT>(P, vol, c, P.tf + view * P.tf_vs, L);
@@ -364,7 +369,11 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD) void brick_flat_kernel(Bri
         Over carry = {0.f, 0.f, 0.f, 0.f};
         int carry_e = -1;  // entry whose composite so far is in `carry` (continues into the next chunk)
         int e_cur = ea;
+#ifdef DR_ABL_NOLOOP
+        for (int f0 = fa; f0 < fa; f0 += 64) {
+#else
         for (int f0 = fa; f0 < fb; f0 += 64) {
+#endif
             const int f = f0 + lane;
             const bool act = f < fb;
             // entry of this lane: advance from the previous chunk's entry (flat order is entry order)
@@ -435,7 +444,12 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD) void brick_flat_kernel(Bri
                                          go.w * (of.w - absi.a);
                     sample_adjoint<true>(sm, vd, T, suffix, last, go, P.inv_sr, ad);
                 }
+#ifdef DR_ABL_NOSCATTER
+                asm volatile("" :: "v"(ad.r_bar), "v"(ad.g_bar), "v"(ad.b_bar), "v"(ad.a_bar), "v"(ad.gx), "v"(ad.gy), "v"(ad.gz));
+                if (false) {
+#else
                 if (WANT_TF) {
+#endif
                     // neighbouring lanes are consecutive samples of a ray: long runs fall between the same two
                     // texels. Sum each run across lanes (DPP) and let its last lane do the eight LDS adds.
                     const int key = valid ? sm.lo : -1 - lane;
@@ -454,7 +468,11 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD) void brick_flat_kernel(Bri
                         fix_add(d1 + 2, fix_clamp(tv[6], fs), fs); fix_add(d1 + 3, fix_clamp(tv[7], fs), fs);
                     }
                 }
+#ifdef DR_ABL_NOSCATTER
+                if (false) {
+#else
                 if (WANT_VOL) {
+#endif
                     // d_volume: fixed-point adds into the LDS gradient box (dr_brick_common.h). A 32-bit addend
                     // suffices unless some adjoint of the wave exceeds 2^31 / 2^shift (then: exact wide path).
                     const int cbase_i = valid ? (t.lx * BOX_SX + t.ly * BOX_SY + t.lz) : 0;
