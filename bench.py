@@ -70,7 +70,7 @@ def main():
                     help="vol+tf = C4 (default); tf = C3; none = forward only (C2-style)")
     ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 baseline kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-img", type=int, default=96, help="image edge of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-img", type=int, default=224, help="image edge of the bounded CPU-baseline sample")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -17,6 +17,15 @@ def _free_port():
 
 
 def _worker(rank, world, port, n_views, q):
+    try:
+        _worker_body(rank, world, port, n_views, q)
+    except Exception as exc:  # surface the reason in the parent instead of a bare non-zero exit code
+        import traceback
+        q.put(("error", rank, traceback.format_exc()))
+        raise
+
+
+def _worker_body(rank, world, port, n_views, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
     import torch.distributed as dist
@@ -55,7 +64,9 @@ def test_two_rank_gradient_allreduce_matches_single_process(oracle):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, n_views, q)) for r in range(2)]
     for p in procs:
         p.start()
-    mine, dv, dt = q.get(timeout=240)
+    got = q.get(timeout=240)
+    assert got[0] != "error", got
+    mine, dv, dt = got
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
