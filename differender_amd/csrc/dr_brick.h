@@ -15,7 +15,10 @@
 
 namespace dr {
 
-constexpr int BRK = 16;                    // cells per brick edge
+#ifndef DR_BRK
+#define DR_BRK 12
+#endif
+constexpr int BRK = DR_BRK;                    // cells per brick edge
 constexpr int BOX = BRK + 3;               // voxels per LDS box edge
 constexpr int BOX_SY = BOX;                // LDS strides (z fastest); 19 and 361 are odd -> lanes that walk
 constexpr int BOX_SX = BOX * BOX;          // along any axis spread over the 32 LDS banks

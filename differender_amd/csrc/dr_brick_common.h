@@ -226,7 +226,7 @@ __device__ __forceinline__ bool sample_coords(const VolView<VT> &vol, const Bric
     axis_coord(sm.px, vol.scx, x0, t.fx);
     axis_coord(sm.py, vol.scy, y0, t.fy);
     axis_coord(sm.pz, vol.scz, z0, t.fz);
-    if ((x0 >> 4) != c.bx || (y0 >> 4) != c.by || (z0 >> 4) != c.bz) return false;
+    if (x0 / BRK != c.bx || y0 / BRK != c.by || z0 / BRK != c.bz) return false;  // x0 >= 0
     const float delta = 1e-3f;
     int k;
     t.lx = x0 - c.ox; t.ly = y0 - c.oy; t.lz = z0 - c.oz;

@@ -16,10 +16,25 @@
 
 namespace dr {
 
-constexpr int FNT_FWD = 256;      // threads per workgroup (forward: 43 KB of LDS -> 3 workgroups per CU)
-constexpr int FNT_BWD = 512;      // (backward: 118 KB of LDS -> one workgroup per CU, so make it 8 waves)
-constexpr int FEC_FWD = 256;      // ray segments listed per round (<= threads: one candidate per thread)
-constexpr int FEC_BWD = 256;      // (backward: the entry table also holds prefix / gradient / output)
+#ifndef DR_FNT_BWD
+#define DR_FNT_BWD 512
+#endif
+#ifndef DR_BWD_WAVES
+#define DR_BWD_WAVES 4
+#endif
+#ifndef DR_FNT_FWD
+#define DR_FNT_FWD 256
+#endif
+constexpr int FNT_FWD = DR_FNT_FWD;      // threads per workgroup (forward: 43 KB of LDS -> 3 workgroups per CU)
+constexpr int FNT_BWD = DR_FNT_BWD;     // (backward: 118 KB of LDS -> one workgroup per CU, so make it 8 waves)
+#ifndef DR_FEC_FWD
+#define DR_FEC_FWD 256
+#endif
+#ifndef DR_FEC_BWD
+#define DR_FEC_BWD 256
+#endif
+constexpr int FEC_FWD = DR_FEC_FWD;      // ray segments listed per round (<= threads: one candidate per thread)
+constexpr int FEC_BWD = DR_FEC_BWD;      // (backward: the entry table also holds prefix / gradient / output)
 
 struct FlatLds {
     float4 *tf; float *box; unsigned long long *dbox; unsigned long long *dtf;
@@ -330,7 +345,7 @@ __device__ __forceinline__ void scatter_sample(unsigned long long *dbox, const T
 }
 
 template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF>
-__global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD) void brick_flat_kernel(BrickParams<VT> P) {
+__global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : 4) void brick_flat_kernel(BrickParams<VT> P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int EC = BWD ? FEC_BWD : FEC_FWD;
     constexpr int FNT = BWD ? FNT_BWD : FNT_FWD;

@@ -28,7 +28,7 @@ def segs(variant):
     ws = F.alloc_workspace(1, WH, vol.shape, 64, dev)
     out, steps = F.march_fwd(T(vol), T(tf), T(cam[None]), e, x, r, n, 1 << 20, sr, 1, variant=variant, workspace=ws)
     NP = WH[0] * WH[1]
-    NB = [(s - 1 + 15) // 16 for s in vol.shape]; NL = sum(NB) - 2
+    NB = [(s - 1 + 11) // 12 for s in vol.shape]; NL = sum(NB) - 2
     rgba = ws[256:256 + NL * NP * 16].view(torch.float32).view(NL, NP, 4).cpu().numpy()
     cnt = ws[256 + NL * NP * 16:256 + NL * NP * 20].view(torch.int32).view(NL, NP).cpu().numpy()
     return rgba, cnt
