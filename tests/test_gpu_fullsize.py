@@ -120,3 +120,66 @@ def test_early_termination_at_full_size(scene):
     assert float(same.float().mean()) > 0.999
     assert float((out0 - outb).abs().amax(-1)[same].max()) <= 1e-5
     assert float((out0 - outb).abs().max()) <= 2e-3
+
+
+def test_config_c2_256_forward_only(hiplib, oracle):
+    """BASELINE config C2: 256^3 f32 volume, 256^2 image, 256-entry TF, forward only (all kernel variants, patches vs oracle)."""
+    import bench
+    from differender_amd import functional as F
+    dev = torch.device("cuda:0")
+    n, img = 256, 256
+    vol = bench.synth_volume_torch(n, dev)
+    tf = bench.bench_tf_torch(256, 2e-3, dev)
+    cam = torch.tensor([bench.in_circles(0.1)], dtype=torch.float32, device=dev)
+    e, x, r, ns = F.ray_setup(cam, (img, img), (n, n, n), 1.0)
+    outs = {}
+    for variant in (0, 2, 1):
+        ws = F.alloc_workspace(1, (img, img), (n, n, n), 256, dev) if variant != 1 else None
+        outs[variant], steps = F.march_fwd(vol, tf, cam, e, x, r, ns, 1 << 20, 1.0, variant=variant, workspace=ws)
+        assert torch.equal(steps, ns)
+    assert float((outs[0] - outs[1]).abs().max()) <= 1e-5 and float((outs[2] - outs[1]).abs().max()) <= 1e-5
+    vol_h = vol.cpu().numpy(); tf_h = tf.cpu().numpy(); cam_h = cam[0].cpu().numpy()
+    eh, xh, rh, nh = (t[0].cpu().numpy() for t in (e, x, r, ns))
+    for (i0, j0) in [(120, 120), (40, 200)]:
+        sl = (slice(i0, i0 + 16), slice(j0, j0 + 16))
+        ref, _ = oracle.march_fwd(vol_h, tf_h, cam_h, eh[sl], xh[sl], rh[sl], nh[sl], 1 << 20, 1.0, 0)
+        assert np.abs(outs[0][0].cpu().numpy()[sl] - ref).max() <= 1e-5
+
+
+def test_config_c5_fp16_1024_jittered_view(hiplib, oracle):
+    """BASELINE config C5, one of its views on one GPU: 1024^3 fp16 volume, 1024^2 image, jitter on, fwd + bwd.
+    Patches against the oracle run on the f16-rounded volume; the 8-GPU run itself is the driver's."""
+    import bench
+    from differender_amd import functional as F
+    dev = torch.device("cuda:0")
+    n, img, R = 1024, 1024, 256
+    vol16 = bench.synth_volume_torch(n, dev).half()
+    tf = bench.bench_tf_torch(R, 5e-4, dev)
+    tf[:, 3] = torch.linspace(2e-4, 1e-3, R, device=dev)
+    cam = torch.tensor([bench.in_circles(0.3)], dtype=torch.float32, device=dev)
+    e, x, r, ns = F.ray_setup(cam, (img, img), (n, n, n), 1.0, jitter_seed=42, view_base=5)
+    ws = F.alloc_workspace(1, (img, img), (n, n, n), R, dev)
+    assert ws is not None
+    out, steps = F.march_fwd(vol16, tf, cam, e, x, r, ns, 1 << 20, 1.0, workspace=ws)
+    assert int(F.workspace_stats(ws)[0]) == 0 and torch.equal(steps, ns) and int(steps.sum()) > 1.5e9
+    eh, xh, rh, nh = (t[0].cpu().numpy() for t in (e, x, r, ns))
+    vol_h = vol16.float().cpu().numpy(); tf_h = tf.cpu().numpy(); cam_h = cam[0].cpu().numpy()
+    g = np.zeros((img, img, 4), np.float32)
+    rng = np.random.RandomState(5)
+    sls = []
+    for (i0, j0) in [(500, 500), (300, 650)]:
+        sl = (slice(i0, i0 + 8), slice(j0, j0 + 8))
+        ref, _ = oracle.march_fwd(vol_h, tf_h, cam_h, eh[sl], xh[sl], rh[sl], nh[sl], 1 << 20, 1.0, 0)
+        assert np.abs(out[0].cpu().numpy()[sl] - ref).max() <= 1e-5
+        g[sl] = rng.randn(8, 8, 4).astype(np.float32)
+        sls.append(sl)
+    dv, dt = F.march_bwd(vol16, tf, cam, e, x, r, ns, 1 << 20, 1.0, torch.from_numpy(g[None]).to(dev), out, workspace=ws)
+    dt_ref = np.zeros_like(tf_h)
+    dv_h = dv.cpu().numpy()
+    for sl in sls:
+        a, b = oracle.march_bwd(vol_h, tf_h, cam_h, eh[sl], xh[sl], rh[sl], nh[sl], 1 << 20, 1.0, g[sl])
+        dt_ref += b
+        nz = a != 0  # the patches are far apart: their d_vol supports do not overlap
+        assert np.abs(dv_h[nz] - a[nz]).max() <= 1e-4 * np.abs(a).max()
+    assert np.abs(dt.cpu().numpy() - dt_ref).max() <= 1e-4 * np.abs(dt_ref).max()
+    assert dv.dtype == torch.float32 and torch.isfinite(dv).all()
