@@ -78,14 +78,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local_rank % ndev)  # (% ndev only matters for the 1-GPU rehearsal below)
+    dev = torch.device("cuda", local_rank % ndev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # DR_BENCH_BACKEND=gloo rehearses the N > 1 control flow on a 1-GPU box (ranks share the card);
+        # the real run uses RCCL ("nccl" on ROCm) over xGMI.
+        backend = os.environ.get("DR_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from differender_amd import functional as F
     from differender_amd.distributed import all_reduce_gradients
@@ -128,11 +135,21 @@ def main():
             if timed:
                 b1.record(); ev["bwd"].append((b0, b1))
             if world > 1:
-                all_reduce_gradients([g for g in (dv, dt) if g is not None])
+                # RCCL sum of the shared gradients on its own stream: it overlaps the next step's forward; the
+                # previous step's reduction is awaited first so at most one is in flight (and all before timing ends)
+                for h in pending:
+                    h.wait()
+                pending[:] = all_reduce_gradients([g for g in (dv, dt) if g is not None], async_op=True)
+                keep_alive[:] = [dv, dt]
         if timed:
             total_steps.add_(steps.sum())
 
+    pending, keep_alive = [], []
+
     def barrier():
+        for h in pending:
+            h.wait()
+        pending[:] = []
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()

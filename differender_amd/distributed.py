@@ -40,12 +40,12 @@ def all_reduce_gradients(grads, group=None, async_op=False):
                 handles.append(h)
     if small:
         flat = torch.cat([g.reshape(-1) for g in small])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)  # a few KiB: latency-bound, not worth deferring
         off = 0
         for g in small:
             g.copy_(flat[off:off + g.numel()].view_as(g))
             off += g.numel()
-    return handles
+    return handles  # async_op: call .wait() on each before reading the large tensors
 
 
 def _dense(t):
