@@ -20,9 +20,19 @@ namespace dr {
 #endif
 constexpr int BRK = DR_BRK;                    // cells per brick edge
 constexpr int BOX = BRK + 3;               // voxels per LDS box edge
-constexpr int BOX_SY = BOX;                // LDS strides (z fastest); 19 and 361 are odd -> lanes that walk
-constexpr int BOX_SX = BOX * BOX;          // along any axis spread over the 32 LDS banks
-constexpr int BOX_N = BOX * BOX * BOX;     // 6859 floats = 27.4 KB
+// LDS strides of the box (z fastest). All three are odd, and SX mod 32 differs from SZ = 1 and from SY mod 32, so
+// that the ~10 distinct cells a 32-lane group touches while walking along a ray land in distinct banks
+// (the orbit cameras march mostly in the x-z plane: SX = 225 = 1 (mod 32) aliased x-steps with z-steps).
+#ifndef DR_BOX_PADX
+#define DR_BOX_PADX 12
+#endif
+#ifndef DR_BOX_PADY
+#define DR_BOX_PADY 0
+#endif
+constexpr int BOX_SY = BOX + DR_BOX_PADY;
+constexpr int BOX_SX = BOX * BOX_SY + DR_BOX_PADX;
+constexpr int BOX_VOX = BOX * BOX * BOX;   // voxels staged per brick
+constexpr int BOX_LDS = BOX * BOX_SX;      // LDS elements reserved for them
 constexpr int ECHUNK = 512;                // ray segments listed per round
 constexpr float BRICK_EPS = 2e-4f;         // world-space slack of the conservative ray/brick tests
 

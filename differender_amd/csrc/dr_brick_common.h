@@ -97,7 +97,9 @@ __device__ __forceinline__ bool segment_range(const BrickCtx &c, f3 cam, f3 vd, 
     }
     if (!(ta <= tb)) return false;
     const float scale = (float)(n - 1) / (exit_ - t0);
-    float sa = floorf((ta - t0) * scale) - 1.0f, sb = ceilf((tb - t0) * scale) + 2.0f;
+    // the slab already carries BRICK_EPS (~0.2 samples at 512^3) of slack; one more sample at the far end covers the
+    // rounding of this inverse map. A miss would be caught by the per-ray sample-count check (and marched whole).
+    float sa = floorf((ta - t0) * scale), sb = ceilf((tb - t0) * scale) + 1.0f;
     sa = fminf(fmaxf(sa, 0.0f), (float)nmarch); sb = fminf(fmaxf(sb, 0.0f), (float)nmarch);
     s0 = (int)sa; s1 = (int)sb;
     return s1 > s0;
@@ -109,8 +111,8 @@ struct LdsLayout {
 };
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
 __host__ __device__ inline size_t brick_lds_bytes(int R, bool bwd_vol, bool bwd_tf) {
-    size_t s = (size_t)R * 16 + align16(BOX_N * 4);
-    if (bwd_vol) s += align16(BOX_N * 8);
+    size_t s = (size_t)R * 16 + align16(BOX_LDS * 4);
+    if (bwd_vol) s += align16(BOX_LDS * 8);
     if (bwd_tf) s += (size_t)R * 32;
     s += 3 * ECHUNK * 4 + ECHUNK * 2 + 128 * 4 + 16;
     return s;
@@ -119,9 +121,9 @@ __device__ __forceinline__ LdsLayout carve(unsigned char *smem, int R, bool bwd_
     LdsLayout L;
     size_t o = 0;
     L.tf = reinterpret_cast<float4 *>(smem + o); o += (size_t)R * 16;
-    L.box = reinterpret_cast<float *>(smem + o); o += align16(BOX_N * 4);
+    L.box = reinterpret_cast<float *>(smem + o); o += align16(BOX_LDS * 4);
     L.dbox = nullptr; L.dtf = nullptr;
-    if (bwd_vol) { L.dbox = reinterpret_cast<unsigned long long *>(smem + o); o += align16(BOX_N * 8); }
+    if (bwd_vol) { L.dbox = reinterpret_cast<unsigned long long *>(smem + o); o += align16(BOX_LDS * 8); }
     if (bwd_tf) { L.dtf = reinterpret_cast<unsigned long long *>(smem + o); o += (size_t)R * 32; }
     L.e_pix = reinterpret_cast<int *>(smem + o); o += ECHUNK * 4;
     L.e_s0 = reinterpret_cast<int *>(smem + o); o += ECHUNK * 4;
@@ -138,7 +140,7 @@ __device__ __forceinline__ void load_tf_and_box(const BrickParams<VT> &P, const 
                                                 const float4 *tfg, LdsLayout &L) {
     for (int k = threadIdx.x; k < P.R; k += 256) L.tf[k] = tfg[k];
     const int fast = (vol.sx <= vol.sy && vol.sx <= vol.sz) ? 0 : ((vol.sy <= vol.sz) ? 1 : 2);
-    for (int idx = threadIdx.x; idx < BOX_N; idx += 256) {
+    for (int idx = threadIdx.x; idx < BOX_VOX; idx += 256) {
         const int a = idx % BOX, b = (idx / BOX) % BOX, d = idx / (BOX * BOX);
         int lx, ly, lz;
         if (fast == 0) { lx = a; ly = b; lz = d; } else if (fast == 1) { ly = a; lx = b; lz = d; } else { lz = a; ly = b; lx = d; }

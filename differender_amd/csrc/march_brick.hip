@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void brick_bwd_kernel(BrickParams<VT> P) {
     VolView<VT> vol = P.vol;
     vol.p += view * P.vol_vs;
     load_tf_and_box(P, vol, c, P.tf + view * P.tf_vs, L);
-    if (WANT_VOL) for (int k = threadIdx.x; k < BOX_N; k += 256) L.dbox[k] = 0ull;
+    if (WANT_VOL) for (int k = threadIdx.x; k < BOX_LDS; k += 256) L.dbox[k] = 0ull;
     if (WANT_TF) for (int k = threadIdx.x; k < 4 * P.R; k += 256) L.dtf[k] = 0ull;
     const FixScale fs = make_fix_scale(P.stats[1]);
     const f3 light = make_f3(cam.x + 0.0f, cam.y + 1.0f, cam.z + 0.0f);
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void brick_bwd_kernel(BrickParams<VT> P) {
         GradView dv = P.dvol;
         dv.p += view * P.dvol_vs;
         const int fast = (dv.sx <= dv.sy && dv.sx <= dv.sz) ? 0 : ((dv.sy <= dv.sz) ? 1 : 2);
-        for (int idx = threadIdx.x; idx < BOX_N; idx += 256) {
+        for (int idx = threadIdx.x; idx < BOX_VOX; idx += 256) {
             const int a = idx % BOX, b = (idx / BOX) % BOX, d = idx / (BOX * BOX);
             int lx, ly, lz;
             if (fast == 0) { lx = a; ly = b; lz = d; } else if (fast == 1) { ly = a; lx = b; lz = d; } else { lz = a; ly = b; lx = d; }

@@ -52,8 +52,8 @@ struct FlatLds {
 template <bool BWD>
 __host__ __device__ constexpr size_t flat_fixed_bytes(bool want_vol) {
     constexpr int EC = BWD ? FEC_BWD : FEC_FWD;
-    size_t s = ((size_t)BOX_N * 4 + 15) / 16 * 16;
-    if (BWD && want_vol) s += ((size_t)BOX_N * 8 + 15) / 16 * 16;
+    size_t s = ((size_t)BOX_LDS * 4 + 15) / 16 * 16;
+    if (BWD && want_vol) s += ((size_t)BOX_LDS * 8 + 15) / 16 * 16;
     s += (size_t)EC * 32 + (BWD ? (size_t)EC * 48 : 0);
     s += (size_t)EC * 4 + (((size_t)EC + 1) * 4 + 15) / 16 * 16 + (size_t)EC * 4 + (BWD ? (size_t)EC * 4 : 0) + 128;
     return s;
@@ -67,9 +67,9 @@ __device__ __forceinline__ FlatLds flat_carve(unsigned char *smem, int R) {
     constexpr int EC = BWD ? FEC_BWD : FEC_FWD;
     FlatLds L;
     size_t o = 0;
-    L.box = reinterpret_cast<float *>(smem + o); o += align16(BOX_N * 4);
+    L.box = reinterpret_cast<float *>(smem + o); o += align16(BOX_LDS * 4);
     L.dbox = nullptr; L.dtf = nullptr; L.pre = L.go = L.of = nullptr; L.live = nullptr;
-    if (BWD && WANT_VOL) { L.dbox = reinterpret_cast<unsigned long long *>(smem + o); o += align16(BOX_N * 8); }
+    if (BWD && WANT_VOL) { L.dbox = reinterpret_cast<unsigned long long *>(smem + o); o += align16(BOX_LDS * 8); }
     L.ray0 = reinterpret_cast<float4 *>(smem + o); o += (size_t)EC * 16;
     L.ray1 = reinterpret_cast<float4 *>(smem + o); o += (size_t)EC * 16;
     if (BWD) {
@@ -92,7 +92,7 @@ __device__ __forceinline__ void flat_load_tf_and_box(const BrickParams<VT> &P, c
                                                      const BrickCtx &c, const float4 *tfg, FlatLds &L) {
     for (int k = threadIdx.x; k < P.R; k += FNT) L.tf[k] = tfg[k];
     const int fast = (vol.sx <= vol.sy && vol.sx <= vol.sz) ? 0 : ((vol.sy <= vol.sz) ? 1 : 2);
-    for (int idx = threadIdx.x; idx < BOX_N; idx += FNT) {
+    for (int idx = threadIdx.x; idx < BOX_VOX; idx += FNT) {
         const int a = idx % BOX, b = (idx / BOX) % BOX, d = idx / (BOX * BOX);
         int lx, ly, lz;
         if (fast == 0) { lx = a; ly = b; lz = d; } else if (fast == 1) { ly = a; lx = b; lz = d; } else { lz = a; ly = b; lx = d; }
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : 4) vo
     flat_load_tf_and_box<VT, FNT>(P, vol, c, P.tf + view * P.tf_vs, L);
     FixScale fs;
     if (BWD) {
-        if (WANT_VOL) for (int k = threadIdx.x; k < BOX_N; k += FNT) L.dbox[k] = 0ull;
+        if (WANT_VOL) for (int k = threadIdx.x; k < BOX_LDS; k += FNT) L.dbox[k] = 0ull;
         if (WANT_TF) for (int k = threadIdx.x; k < 4 * P.R; k += FNT) L.dtf[k] = 0ull;
         fs = make_fix_scale(P.stats[1]);
     }
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : 4) vo
         GradView dv = P.dvol;
         dv.p += view * P.dvol_vs;
         const int fast = (dv.sx <= dv.sy && dv.sx <= dv.sz) ? 0 : ((dv.sy <= dv.sz) ? 1 : 2);
-        for (int idx = threadIdx.x; idx < BOX_N; idx += FNT) {
+        for (int idx = threadIdx.x; idx < BOX_VOX; idx += FNT) {
             const int a = idx % BOX, b = (idx / BOX) % BOX, d = idx / (BOX * BOX);
             int lx, ly, lz;
             if (fast == 0) { lx = a; ly = b; lz = d; } else if (fast == 1) { ly = a; lx = b; lz = d; } else { lz = a; ly = b; lx = d; }
