@@ -190,6 +190,12 @@ static MarchParams<VT> make_params(const MarchArgs &a) {
     return P;
 }
 
+template <typename K>
+static hipError_t big_lds(K kernel, size_t bytes) {  // dynamic LDS above 64 KB needs an explicit opt-in
+    if (bytes <= 64 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
 static dim3 tile_grid(const MarchArgs &a) {
     const int tiles = ((a.W + 7) / 8) * ((a.H + 7) / 8);
     return dim3((tiles + 3) / 4, a.n_views);
@@ -198,12 +204,15 @@ static dim3 tile_grid(const MarchArgs &a) {
 template <typename VT>
 static int fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     const size_t lds = (size_t)a.R * sizeof(float4);
-    if (lds > 64 * 1024) return DR_EUNSUPPORTED;
+    if (lds > 160 * 1024) return DR_EUNSUPPORTED;  // TF table must fit the CU's LDS (R <= 10240)
     MarchParams<VT> P = make_params<VT>(a);
-    if (a.mode == DR_MODE_DIFF)
+    if (a.mode == DR_MODE_DIFF) {
+        if (big_lds(march_fwd_baseline_kernel<VT, DR_MODE_DIFF>, lds) != hipSuccess) return DR_EUNSUPPORTED;
         hipLaunchKernelGGL((march_fwd_baseline_kernel<VT, DR_MODE_DIFF>), tile_grid(a), dim3(256), lds, stream, P);
-    else
+    } else {
+        if (big_lds(march_fwd_baseline_kernel<VT, DR_MODE_NONDIFF>, lds) != hipSuccess) return DR_EUNSUPPORTED;
         hipLaunchKernelGGL((march_fwd_baseline_kernel<VT, DR_MODE_NONDIFF>), tile_grid(a), dim3(256), lds, stream, P);
+    }
     return (int)hipGetLastError();
 }
 
@@ -214,8 +223,9 @@ int launch_march_fwd_baseline(const MarchArgs &a, hipStream_t stream) {
 template <typename VT>
 static int bwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     const size_t lds = 2 * (size_t)a.R * sizeof(float4);
-    if (lds > 64 * 1024) return DR_EUNSUPPORTED;
+    if (lds > 160 * 1024) return DR_EUNSUPPORTED;  // TF + its gradient table in LDS (R <= 5120)
     MarchParams<VT> P = make_params<VT>(a);
+    if (big_lds(march_bwd_baseline_kernel<VT>, lds) != hipSuccess) return DR_EUNSUPPORTED;
     hipLaunchKernelGGL((march_bwd_baseline_kernel<VT>), tile_grid(a), dim3(256), lds, stream, P);
     return (int)hipGetLastError();
 }

@@ -301,3 +301,70 @@ def test_optimisation_loop_reduces_loss(oracle, F):
             vol.clamp_(0.0, 1.0)
         losses.append(float(loss.detach()))
     assert losses[-1] < 0.7 * losses[0], losses
+
+
+@pytest.mark.parametrize("cam", [(0.2, 0.1, 0.3), (0.9, 0.3, -1.15), (0.0, 1.6, 0.05)],
+                         ids=["inside", "near-corner", "above-nearly-along-y"])
+def test_unusual_cameras(oracle, F, cam):
+    """Camera inside the box (every ray irregular -> marched individually), very close to it (bricks project to
+    large pixel rectangles: several listing rounds per brick) and nearly along the up vector."""
+    vol, tf, _ = scene(oracle, N=40, R=32, alpha=0.04)
+    tf[:, 3] = np.linspace(0.01, 0.1, 32)
+    cam = np.array(cam, np.float32)
+    WH = (48, 40)
+    e0, x0, r0, n0 = oracle.ray_setup(cam, *WH, vol.shape)
+    ref, sref = oracle.march_fwd(vol, tf, cam, e0, x0, r0, n0, 1 << 20, 1.0, 0)
+    e, x, r, n = gpu_setup(F, cam, WH, vol.shape)
+    assert np.array_equal(n[0].cpu().numpy(), n0)
+    out, steps = F.march_fwd(T(vol), T(tf), T(cam[None]), e, x, r, n, 1 << 20, 1.0)
+    o = out[0].cpu().numpy()
+    same = steps[0].cpu().numpy() == sref
+    assert same.mean() > 0.99
+    assert np.abs(o - ref).max(-1)[same].max() <= FWD_TOL
+    g = np.random.RandomState(4).randn(*WH, 4).astype(np.float32)
+    g[~same] = 0.0
+    dv0, dt0 = oracle.march_bwd(vol, tf, cam, e0, x0, r0, n0, 1 << 20, 1.0, g)
+    dv, dt = F.march_bwd(T(vol), T(tf), T(cam[None]), e, x, r, n, 1 << 20, 1.0, T(g[None]), out)
+    ok, err = grad_close(dv.cpu().numpy(), dv0, 2e-4); assert ok, err
+    ok, err = grad_close(dt.cpu().numpy(), dt0, 2e-4); assert ok, err
+
+
+@pytest.mark.parametrize("vshape,WH,R", [((2, 2, 2), (8, 8), 2), ((5, 7, 3), (3, 5), 1), ((13, 12, 14), (1, 1), 4),
+                                         ((12, 13, 25), (17, 9), 7)])
+def test_tiny_and_ragged_shapes(oracle, F, vshape, WH, R):
+    rng = np.random.RandomState(1)
+    vol = rng.uniform(0.1, 0.9, size=vshape).astype(np.float32)
+    tf = rng.uniform(0.05, 0.5, size=(R, 4)).astype(np.float32)
+    cam = oracle.in_circles(2.5)
+    e0, x0, r0, n0 = oracle.ray_setup(cam, *WH, vshape)
+    ref, sref = oracle.march_fwd(vol, tf, cam, e0, x0, r0, n0, 1 << 20, 1.0, 0)
+    e, x, r, n = gpu_setup(F, cam, WH, vshape)
+    out, steps = F.march_fwd(T(vol), T(tf), T(cam[None]), e, x, r, n, 1 << 20, 1.0)
+    assert np.array_equal(steps[0].cpu().numpy(), sref)
+    assert np.abs(out[0].cpu().numpy() - ref).max() <= FWD_TOL
+    g = rng.randn(*WH, 4).astype(np.float32)
+    dv0, dt0 = oracle.march_bwd(vol, tf, cam, e0, x0, r0, n0, 1 << 20, 1.0, g)
+    dv, dt = F.march_bwd(T(vol), T(tf), T(cam[None]), e, x, r, n, 1 << 20, 1.0, T(g[None]), out)
+    if np.abs(dv0).max() > 0:
+        assert grad_close(dv.cpu().numpy(), dv0)[0]
+    if np.abs(dt0).max() > 0:
+        assert grad_close(dt.cpu().numpy(), dt0)[0]
+
+
+def test_large_tf_falls_back_to_supported_kernels(oracle, hiplib):
+    """A TF too large for the LDS budget of the fast kernels: dr_workspace_bytes() reports 0 and AUTO runs the
+    baseline kernels -- same results, no error."""
+    from differender_amd import functional as Fn
+    vol, _, cam = scene(oracle, N=24)
+    R = 16384
+    tf = oracle.bench_tf(R, 0.03)
+    assert Fn.alloc_workspace(1, (16, 16), vol.shape, R, dev()) is None
+    e, x, r, n = Fn.ray_setup(T(cam[None]), (16, 16), vol.shape, 1.0)
+    with pytest.raises(RuntimeError, match="unsupported"):
+        Fn.march_fwd(T(vol), T(tf), T(cam[None]), e, x, r, n, 4096, 1.0)
+    tf2 = oracle.bench_tf(2048, 0.03)
+    ws = Fn.alloc_workspace(1, (16, 16), vol.shape, 2048, dev())
+    out, _ = Fn.march_fwd(T(vol), T(tf2), T(cam[None]), e, x, r, n, 4096, 1.0, workspace=ws)
+    e0, x0, r0, n0 = oracle.ray_setup(cam, 16, 16, vol.shape)
+    ref, _ = oracle.march_fwd(vol, tf2, cam, e0, x0, r0, n0, 4096, 1.0, 0)
+    assert np.abs(out[0].cpu().numpy() - ref).max() <= FWD_TOL
