@@ -241,6 +241,23 @@ __device__ __forceinline__ bool sample_coords(const VolView<VT> &vol, const Bric
     return true;
 }
 
+// Tap coordinates alone, from a position (same arithmetic as sample_coords).
+template <typename VT>
+__device__ __forceinline__ void tap_coords(const VolView<VT> &vol, const BrickCtx &c, float px, float py, float pz,
+                                           TapCoords &t) {
+    const float delta = 1e-3f;
+    int k;
+    axis_coord(px, vol.scx, k, t.fx); t.lx = k - c.ox;
+    axis_coord(py, vol.scy, k, t.fy); t.ly = k - c.oy;
+    axis_coord(pz, vol.scz, k, t.fz); t.lz = k - c.oz;
+    axis_coord(px + delta, vol.scx, k, t.fxp); t.lxp = k - c.ox;
+    axis_coord(px - delta, vol.scx, k, t.fxm); t.lxm = k - c.ox;
+    axis_coord(py + delta, vol.scy, k, t.fyp); t.lyp = k - c.oy;
+    axis_coord(py - delta, vol.scy, k, t.fym); t.lym = k - c.oy;
+    axis_coord(pz + delta, vol.scz, k, t.fzp); t.lzp = k - c.oz;
+    axis_coord(pz - delta, vol.scz, k, t.fzm); t.lzm = k - c.oz;
+}
+
 __device__ __forceinline__ void load_ray(const float *entry, const float *exit_, const float *rays, const int32_t *nsamp,
                                          size_t p, RayGeom &rg) {
     rg.n = nsamp[p]; rg.entry = entry[p]; rg.exit_ = exit_[p];

@@ -281,9 +281,22 @@ __device__ __forceinline__ Over readlane_over(const Over &v, int lane) {
     r.a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.a), lane));
     return r;
 }
+// whole-wave shifts by one lane with DPP (wave_shr:1 = 0x138, wave_shl:1 = 0x130; gfx9 family): lane 0 / lane 63
+// keep the `edge` value. No LDS crossbar traffic, unlike __shfl_up/__shfl_down (ds_bpermute).
+#ifdef DR_NO_WAVE_SHIFT
+__device__ __forceinline__ float wave_up1(float v, float edge) { const float r = __shfl_up(v, 1); return (threadIdx.x & 63) ? r : edge; }
+__device__ __forceinline__ int wave_up1(int v, int edge) { const int r = __shfl_up(v, 1); return (threadIdx.x & 63) ? r : edge; }
+__device__ __forceinline__ int wave_down1(int v, int edge) { const int r = __shfl_down(v, 1); return ((threadIdx.x & 63) != 63) ? r : edge; }
+#else
+__device__ __forceinline__ float wave_up1(float v, float edge) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ int wave_up1(int v, int edge) { return __builtin_amdgcn_update_dpp(edge, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int wave_down1(int v, int edge) { return __builtin_amdgcn_update_dpp(edge, v, 0x130, 0xf, 0xf, false); }
+#endif
 __device__ __forceinline__ Over shfl_up1_over(const Over &v) {
     Over r;
-    r.c0 = __shfl_up(v.c0, 1); r.c1 = __shfl_up(v.c1, 1); r.c2 = __shfl_up(v.c2, 1); r.a = __shfl_up(v.a, 1);
+    r.c0 = wave_up1(v.c0, 0.f); r.c1 = wave_up1(v.c1, 0.f); r.c2 = wave_up1(v.c2, 0.f); r.a = wave_up1(v.a, 0.f);
     return r;
 }
 
@@ -468,13 +481,13 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : 4) vo
                     // neighbouring lanes are consecutive samples of a ray: long runs fall between the same two
                     // texels. Sum each run across lanes (DPP) and let its last lane do the eight LDS adds.
                     const int key = valid ? sm.lo : -1 - lane;
-                    const int key_prev = __shfl_up(key, 1);
+                    const int key_prev = wave_up1(key, key);
                     const int rs = scan_max((lane == 0 || key != key_prev) ? lane : 0, lane);
                     const float w0 = 1.0f - sm.fr, w1 = sm.fr;
                     float tv[8] = {w0 * ad.r_bar, w0 * ad.g_bar, w0 * ad.b_bar, w0 * ad.a_bar,
                                    w1 * ad.r_bar, w1 * ad.g_bar, w1 * ad.b_bar, w1 * ad.a_bar};
                     seg_scan_sum<8>(tv, lane, rs);
-                    const int key_next = __shfl_down(key, 1);
+                    const int key_next = wave_down1(key, key);
                     if (valid && (lane == 63 || key_next != key)) {  // run totals may be large: exact wide adds
                         unsigned long long *d0 = L.dtf + 4 * sm.lo, *d1 = L.dtf + 4 * sm.hi;
                         fix_add(d0 + 0, fix_clamp(tv[0], fs), fs); fix_add(d0 + 1, fix_clamp(tv[1], fs), fs);
@@ -490,6 +503,13 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : 4) vo
 #endif
                     // d_volume: fixed-point adds into the LDS gradient box (dr_brick_common.h). A 32-bit addend
                     // suffices unless some adjoint of the wave exceeds 2^31 / 2^shift (then: exact wide path).
+                    // the 24 tap coordinates are cheap to rebuild from the position (45 VALU) and expensive to keep
+                    // alive across shading and the adjoint (the kernel is register-bound: spills go to scratch)
+                    {
+                        float qx = sm.px, qy = sm.py, qz = sm.pz;
+                        asm volatile("" : "+v"(qx), "+v"(qy), "+v"(qz));
+                        if (valid) tap_coords(vol, c, qx, qy, qz, t);
+                    }
                     const int cbase_i = valid ? (t.lx * BOX_SX + t.ly * BOX_SY + t.lz) : 0;
                     float I_bar = 0.f;
                     float gq[3] = {0.f, 0.f, 0.f};
