@@ -69,6 +69,9 @@ def main():
     ap.add_argument("--grads", default="vol+tf", choices=["vol+tf", "tf", "vol", "none"],
                     help="vol+tf = C4 (default); tf = C3; none = forward only (C2-style)")
     ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 baseline kernels")
+    ap.add_argument("--tf", default="bench", choices=["bench", "tf1"],
+                    help="bench: constant alpha (no early termination, the headline); tf1: the reference's preset "
+                         "(UT.py:9-21) -- empty ranges and early termination, reported separately")
     ap.add_argument("--views", type=int, default=1, help="views per rank per step (one native batched launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-img", type=int, default=224, help="image edge of the bounded CPU-baseline sample")
@@ -107,6 +110,9 @@ def main():
     alpha = 3.0 / n_max
     vol = synth_volume_torch(N, dev)
     tf = bench_tf_torch(R, alpha, dev)
+    if args.tf == "tf1":
+        from differender_amd.utils import get_tf
+        tf = get_tf("tf1", R).t().contiguous().to(dev)
     gen = torch.Generator(device="cpu").manual_seed(4321)
     V = args.views
     target = torch.rand((1, IMG, IMG, 4), generator=gen).to(dev)
@@ -228,7 +234,7 @@ def main():
                                    f"{V} view(s) per rank per step, orbit cameras in_circles(0.1*v), jitter off",
                        "volume": N, "image": IMG, "tf_res": R, "views_per_rank_per_step": V,
                        "parallelism": f"view-sharded x{world}" + (" + RCCL all-reduce(d_vol,d_tf)" if world > 1 else ""),
-                       "passes_per_voxel_step": passes, "kernel_variant": args.variant},
+                       "passes_per_voxel_step": passes, "kernel_variant": args.variant, "tf": args.tf},
             "voxel_steps_per_step": int(vsteps / max(args.steps, 1)),
             "roofline": dominant, "roofline_fwd": roof_fwd, "roofline_bwd": roof_bwd,
             "rays_marched_individually": (int(F.workspace_stats(ws)[0]) if ws is not None else None),

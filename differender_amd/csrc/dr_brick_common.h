@@ -219,6 +219,17 @@ __device__ __forceinline__ void sample_taps_lds(const float *box, const TapCoord
     dz = tri_lds(box, bx + by + t.lzp, t.fx, t.fy, t.fzp) - tri_lds(box, bx + by + t.lzm, t.fx, t.fy, t.fzm);
 }
 
+// The same in two halves, so that the six normal taps can be skipped when no lane needs the lighting term.
+__device__ __forceinline__ float sample_centre_lds(const float *box, const TapCoords &t) {
+    return tri_lds(box, t.lx * BOX_SX + t.ly * BOX_SY + t.lz, t.fx, t.fy, t.fz);
+}
+__device__ __forceinline__ void sample_normal_taps_lds(const float *box, const TapCoords &t, float &dx, float &dy, float &dz) {
+    const int by = t.ly * BOX_SY, bz = t.lz, bx = t.lx * BOX_SX;
+    dx = tri_lds(box, t.lxp * BOX_SX + by + bz, t.fxp, t.fy, t.fz) - tri_lds(box, t.lxm * BOX_SX + by + bz, t.fxm, t.fy, t.fz);
+    dy = tri_lds(box, bx + t.lyp * BOX_SY + bz, t.fx, t.fyp, t.fz) - tri_lds(box, bx + t.lym * BOX_SY + bz, t.fx, t.fym, t.fz);
+    dz = tri_lds(box, bx + by + t.lzp, t.fx, t.fy, t.fzp) - tri_lds(box, bx + by + t.lzm, t.fx, t.fy, t.fzm);
+}
+
 // Position of sample s and its tap coordinates; returns whether the sample's cell lies in this brick.
 template <typename VT>
 __device__ __forceinline__ bool sample_coords(const VolView<VT> &vol, const BrickCtx &c, const RayGeom &rg, f3 cam,

@@ -420,9 +420,17 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : 4) vo
             Over el = {0.f, 0.f, 0.f, 0.f};
             bool shaded = false;
             if (valid) {
-                sample_taps_lds(L.box, t, sm.I, dx, dy, dz);
+                sm.I = sample_centre_lds(L.box, t);
                 classify_from_I(L.tf, P.R, P.tf_len, P.inv_sr, sm);
-                if (!(MODE == DR_MODE_NONDIFF && !(sm.a > 1e-3f))) {
+            }
+            // Lighting only matters where the sample has opacity: c = L*rgb*op is exactly 0 for op == 0 whatever L
+            // is (the nondiff path skips alpha <= 1e-3 by definition, VR.py:334). Lanes are consecutive samples of a
+            // ray, so empty stretches of the transfer function are wave-uniform: skip the six normal taps (48 of the
+            // 56 LDS reads) and the shading for the whole wave. The backward always needs L (d/d alpha).
+            const bool lit = valid && (BWD || (MODE == DR_MODE_NONDIFF ? (sm.a > 1e-3f) : (sm.op != 0.0f)));
+            if (BWD || __any(lit)) {
+                if (lit) {
+                    sample_normal_taps_lds(L.box, t, dx, dy, dz);
                     shade_from_grad<true>(dx, dy, dz, light, vd, MODE == DR_MODE_DIFF, sm);
                     el.c0 = sm.L * sm.r * sm.op; el.c1 = sm.L * sm.g * sm.op; el.c2 = sm.L * sm.b * sm.op; el.a = sm.op;
                     shaded = true;
