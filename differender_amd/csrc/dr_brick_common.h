@@ -20,7 +20,9 @@ struct BrickParams {
     int32_t *seg_cnt;    // [view][NL][NP]: samples of the ray inside the brick of that layer
     uint8_t *rayflag;    // [view][NP]: 1 = irregular ray (marched whole by F2 / B2)
     int32_t *ws_steps;   // [view][NP]: live samples per ray (F2 -> B1)
-    unsigned int *stats; // [0] rays repaired by the count check, [1] bits of max|grad_out| (backward)
+    unsigned int *stats; // [0] rays repaired by the count check, [1] bits of max|grad_out| (backward),
+                         // [2 + view] 1 if some ray of the view may reach alpha >= 0.99 (alpha pre-pass ran)
+    int use_live;        // forward: ws_steps holds each ray's exact live sample count (from the alpha pre-pass)
     float *out; int32_t *steps;
     const float *grad_out, *out_fwd;
     GradView dvol; int64_t dvol_vs;
@@ -337,6 +339,24 @@ __device__ __forceinline__ void tri_scatter_lds(unsigned long long *dbox, int ba
     fix_add(dbox + base + BOX_SX + BOX_SY + 1, a11 * fz, f);
 }
 
+// Can any ray of a view terminate early? Upper bound from the largest TF alpha: after n_max samples of opacity
+// op_max the accumulated alpha is 1 - (1 - op_max)^n_max. One wave per view.
+static __global__ __launch_bounds__(64) void may_terminate_kernel(const float4 *tf, long tf_vs, int R, float inv_sr,
+                                                                  float n_max, unsigned int *flags) {
+    const float4 *t = tf + blockIdx.x * tf_vs;
+    float amax = 0.0f;
+    for (int k = threadIdx.x; k < R; k += 64) {
+        const float a = t[k].w;
+        amax = (a != a) ? 1.0f : fmaxf(amax, a);  // NaN alpha: assume anything can happen
+    }
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    if (threadIdx.x == 0) {
+        const float op = 1.0f - powf(fmaxf(1.0f - fminf(amax, 1.0f), 0.0f), inv_sr);
+        const float remain = powf(1.0f - op, n_max);  // transmittance left after the longest possible ray
+        flags[blockIdx.x] = (remain <= 0.02f) ? 1u : 0u;  // 0.01 is the exact bound; keep a margin
+    }
+}
+
 // max |x| over a buffer -> bits of the (non-negative) float, combined with atomicMax on the integer view
 static __global__ __launch_bounds__(256) void absmax_kernel(const float *x, size_t n, unsigned int *out_bits) {
     float m = 0.0f;
@@ -389,6 +409,7 @@ static inline BrickParams<VT> make_brick_params(const MarchArgs &a, const Worksp
     P.near_ = (float)a.near_plane; P.near_h = (float)near_h; P.near_w = (float)(near_h * ((double)a.W / (double)a.H));
     P.g = make_brick_grid(a.VX, a.VY, a.VZ);
     P.seg_rgba = w.seg_rgba; P.seg_cnt = w.seg_cnt; P.rayflag = w.rayflag; P.stats = w.stats; P.ws_steps = w.ws_steps;
+    P.use_live = a.use_live;
     P.out = a.out; P.steps = a.steps;
     P.grad_out = a.grad_out; P.out_fwd = a.out_fwd;
     P.dvol.p = a.d_vol; P.dvol.sx = a.dsx; P.dvol.sy = a.dsy; P.dvol.sz = a.dsz; P.dvol_vs = a.dvol_vs;

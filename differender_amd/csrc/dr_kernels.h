@@ -20,6 +20,7 @@ struct MarchArgs {
     double fov_rad, near_plane;
     void *workspace; size_t workspace_bytes;
     const uint8_t *only_flagged;  // baseline backward: restrict to rays with a non-zero flag (may be null)
+    int use_live;                 // forward: per-ray live sample counts are available (alpha pre-pass)
 };
 
 hipError_t launch_ray_setup(const float *cam, int n_views, int W, int H, int VX, int VY, int VZ, double fov_rad,
@@ -36,6 +37,7 @@ size_t brick_workspace_bytes(int n_views, int W, int H, int VX, int VY, int VZ);
 int launch_march_fwd_brick(const MarchArgs &a, hipStream_t stream);  // one lane per ray segment
 int launch_march_bwd_brick(const MarchArgs &a, hipStream_t stream);
 int launch_ray_compose(const MarchArgs &a, hipStream_t stream);      // F2, shared by the brick pipelines
+int launch_ray_alpha(const MarchArgs &a, hipStream_t stream);        // alpha pre-pass composition (exact termination)
 bool flat_path_supported(int VX, int VY, int VZ, int R);
 int launch_march_fwd_flat(const MarchArgs &a, hipStream_t stream);   // one lane per sample
 int launch_march_bwd_flat(const MarchArgs &a, hipStream_t stream);

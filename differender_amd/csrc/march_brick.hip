@@ -104,14 +104,18 @@ __global__ __launch_bounds__(256) void ray_compose_kernel(BrickParams<VT> P) {
         const f3 cam = make_f3(P.cam[3 * view], P.cam[3 * view + 1], P.cam[3 * view + 2]);
         const f3 light = make_f3(cam.x + 0.0f, cam.y + 1.0f, cam.z + 0.0f);
         const f3 vd = make_f3(rg.vx, rg.vy, rg.vz);
-        const int nmarch = (MODE == DR_MODE_DIFF && rg.n > P.S) ? P.S : rg.n;
+        int nmarch = (MODE == DR_MODE_DIFF && rg.n > P.S) ? P.S : rg.n;
+        const int nfull = nmarch;
         const size_t seg0 = (size_t)view * P.g.NL * NP + pl;
         bool regular = ray_is_regular(rg.n, rg.entry);
+        // with an alpha pre-pass the bricks marched exactly the live samples of the ray: no crossing to look for
+        const bool use_live = P.use_live && P.stats[2 + view] != 0u;
+        if (regular && use_live) nmarch = min(nmarch, P.ws_steps[p]);
         if (regular) {
             // safety net: the segments must account for every sample, else march this ray whole
             int total = 0;
             for (int l = 0; l < P.g.NL; ++l) total += P.seg_cnt[seg0 + (size_t)l * NP];
-            if (total != nmarch) { regular = false; atomicAdd(&P.stats[0], 1u); }
+            if (total != nmarch) { regular = false; nmarch = nfull; atomicAdd(&P.stats[0], 1u); }
         }
         int s_from = 0, s_to = 0;  // samples to march one by one with early termination
         if (!regular) {
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(256) void ray_compose_kernel(BrickParams<VT> P) {
                 if (MODE == DR_MODE_DIFF) P.seg_rgba[si] = make_float4(C0, C1, C2, A);  // prefix for the backward
                 const float T = 1.0f - A;
                 const float A_after = fmaf(T, sg.w, A);
-                if (!(A_after < 0.99f)) {  // alpha crosses 0.99 inside this segment
+                if (!use_live && !(A_after < 0.99f)) {  // alpha crosses 0.99 inside this segment
                     s_from = sacc; s_to = sacc + cnt;
                     break;
                 }
@@ -182,6 +186,64 @@ __global__ __launch_bounds__(256) void ray_compose_kernel(BrickParams<VT> P) {
     if (P.steps) P.steps[p] = steps;
     P.ws_steps[p] = steps;
     P.rayflag[p] = flag;
+}
+
+// ------------------------------------------------------------------------------------------------ P2
+// Alpha pre-pass, per ray: accumulated alpha does not depend on lighting (A_s = A_{s-1} + (1-A_{s-1}) op_s with
+// op_s a function of the centre tap only), so the sample at which a ray terminates can be found from alpha-only
+// partials at a fraction of the cost. Composes the alpha partials of the bricks front to back; the segment in which
+// alpha crosses 0.99 is re-marched sample by sample (centre tap from global memory) -- the same decisions, in the
+// same arithmetic, as ray_compose_kernel would take. Writes ws_steps[p] = exact number of live samples.
+template <typename VT, int MODE>
+__global__ __launch_bounds__(256) void ray_alpha_kernel(BrickParams<VT> P) {
+    extern __shared__ __attribute__((aligned(16))) float4 lds_tf[];
+    const int view = blockIdx.y;
+    if (P.stats[2 + view] == 0u) return;  // uniform: no ray of this view can terminate, nothing to find
+    const float4 *tfg = P.tf + view * P.tf_vs;
+    for (int k = threadIdx.x; k < P.R; k += 256) lds_tf[k] = tfg[k];
+    __syncthreads();
+    const int NP = P.W * P.H;
+    const int pl = blockIdx.x * 256 + threadIdx.x;
+    if (pl >= NP) return;
+    const size_t p = (size_t)view * NP + pl;
+    RayGeom rg;
+    load_ray(P.entry, P.exit_, P.rays, P.nsamp, p, rg);
+    const int nmarch = (MODE == DR_MODE_DIFF && rg.n > P.S) ? P.S : rg.n;
+    int live = nmarch;
+    if (ray_is_regular(rg.n, rg.entry)) {
+        const size_t seg0 = (size_t)view * P.g.NL * NP + pl;
+        int total = 0;
+        for (int l = 0; l < P.g.NL; ++l) total += P.seg_cnt[seg0 + (size_t)l * NP];
+        if (total == nmarch) {  // otherwise: no culling for this ray, F2 will sort it out
+            VolView<VT> vol = P.vol;
+            vol.p += view * P.vol_vs;
+            const f3 cam = make_f3(P.cam[3 * view], P.cam[3 * view + 1], P.cam[3 * view + 2]);
+            float A = 0.f;
+            int sacc = 0;
+            for (int l = 0; l < P.g.NL; ++l) {
+                const size_t si = seg0 + (size_t)l * NP;
+                const int cnt = P.seg_cnt[si];
+                if (cnt == 0) continue;
+                const float A_after = fmaf(1.0f - A, P.seg_rgba[si].w, A);
+                if (!(A_after < 0.99f)) {  // the crossing segment: samples [sacc, sacc+cnt), then (rounding) beyond
+                    int s = sacc;
+                    for (; s < nmarch; ++s) {
+                        if (!(A < 0.99f)) break;
+                        Sample sm;
+                        sample_pos(rg, cam.x, cam.y, cam.z, s, sm.px, sm.py, sm.pz);
+                        classify(vol, lds_tf, P.R, P.tf_len, P.inv_sr, sm);
+                        if (MODE == DR_MODE_NONDIFF && !(sm.a > 1e-3f)) continue;
+                        A = fmaf(1.0f - A, sm.op, A);
+                    }
+                    live = s;
+                    break;
+                }
+                A = A_after;
+                sacc += cnt;
+            }
+        }
+    }
+    P.ws_steps[p] = live;
 }
 
 // ------------------------------------------------------------------------------------------------ B1
@@ -366,6 +428,26 @@ static int ray_compose_dispatch(const MarchArgs &a, hipStream_t stream) {
 
 int launch_ray_compose(const MarchArgs &a, hipStream_t stream) {
     return a.vol_dtype == DR_F16 ? ray_compose_dispatch<__half>(a, stream) : ray_compose_dispatch<float>(a, stream);
+}
+
+template <typename VT>
+static int ray_alpha_dispatch(const MarchArgs &a, hipStream_t stream) {
+    const BrickGrid g = make_brick_grid(a.VX, a.VY, a.VZ);
+    const int NP = a.W * a.H;
+    Workspace w;
+    ws_layout(a.workspace, a.n_views, NP, g.NL, &w);
+    BrickParams<VT> P = make_brick_params<VT>(a, w);
+    const dim3 grid2((NP + 255) / 256, a.n_views);
+    const size_t lds2 = (size_t)a.R * 16;
+    if (a.mode == DR_MODE_DIFF)
+        hipLaunchKernelGGL((ray_alpha_kernel<VT, DR_MODE_DIFF>), grid2, dim3(256), lds2, stream, P);
+    else
+        hipLaunchKernelGGL((ray_alpha_kernel<VT, DR_MODE_NONDIFF>), grid2, dim3(256), lds2, stream, P);
+    return (int)hipGetLastError();
+}
+
+int launch_ray_alpha(const MarchArgs &a, hipStream_t stream) {
+    return a.vol_dtype == DR_F16 ? ray_alpha_dispatch<__half>(a, stream) : ray_alpha_dispatch<float>(a, stream);
 }
 
 int launch_march_fwd_brick(const MarchArgs &a, hipStream_t stream) {

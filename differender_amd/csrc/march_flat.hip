@@ -87,57 +87,107 @@ __device__ __forceinline__ FlatLds flat_carve(unsigned char *smem, int R) {
     return L;
 }
 
-template <typename VT, int FNT>
+// Stage TF and the brick's voxel box in LDS. All global loads are issued first (into registers), the LDS stores
+// follow: one memory latency per brick instead of one per loop iteration. Reads walk the smallest-stride axis.
+template <typename VT, int FNT, bool BATCH>
 __device__ __forceinline__ void flat_load_tf_and_box(const BrickParams<VT> &P, const VolView<VT> &vol,
                                                      const BrickCtx &c, const float4 *tfg, FlatLds &L) {
-    for (int k = threadIdx.x; k < P.R; k += FNT) L.tf[k] = tfg[k];
+    constexpr int NLD = (BOX_VOX + FNT - 1) / FNT;
     const int fast = (vol.sx <= vol.sy && vol.sx <= vol.sz) ? 0 : ((vol.sy <= vol.sz) ? 1 : 2);
-    for (int idx = threadIdx.x; idx < BOX_VOX; idx += FNT) {
+    if (!BATCH) {  // register-bound callers: load and store element by element
+        for (int k = threadIdx.x; k < P.R; k += FNT) L.tf[k] = tfg[k];
+        for (int idx = threadIdx.x; idx < BOX_VOX; idx += FNT) {
+            const int a = idx % BOX, b = (idx / BOX) % BOX, d = idx / (BOX * BOX);
+            int lx, ly, lz;
+            if (fast == 0) { lx = a; ly = b; lz = d; } else if (fast == 1) { ly = a; lx = b; lz = d; } else { lz = a; ly = b; lx = d; }
+            const int gx = c.ox + lx, gy = c.oy + ly, gz = c.oz + lz;
+            float v = 0.0f;
+            if (gx >= 0 && gx < vol.VX && gy >= 0 && gy < vol.VY && gz >= 0 && gz < vol.VZ)
+                v = ld_voxel(vol.p + gx * vol.sx + gy * vol.sy + gz * vol.sz);
+            L.box[lx * BOX_SX + ly * BOX_SY + lz] = v;
+        }
+        return;
+    }
+    float bv[NLD];
+    int ba[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int idx = threadIdx.x + k * FNT;
         const int a = idx % BOX, b = (idx / BOX) % BOX, d = idx / (BOX * BOX);
         int lx, ly, lz;
         if (fast == 0) { lx = a; ly = b; lz = d; } else if (fast == 1) { ly = a; lx = b; lz = d; } else { lz = a; ly = b; lx = d; }
         const int gx = c.ox + lx, gy = c.oy + ly, gz = c.oz + lz;
-        float v = 0.0f;
-        if (gx >= 0 && gx < vol.VX && gy >= 0 && gy < vol.VY && gz >= 0 && gz < vol.VZ)
-            v = ld_voxel(vol.p + gx * vol.sx + gy * vol.sy + gz * vol.sz);
-        L.box[lx * BOX_SX + ly * BOX_SY + lz] = v;
+        bv[k] = 0.0f;
+        ba[k] = (idx < BOX_VOX) ? lx * BOX_SX + ly * BOX_SY + lz : -1;
+        if (idx < BOX_VOX && gx >= 0 && gx < vol.VX && gy >= 0 && gy < vol.VY && gz >= 0 && gz < vol.VZ)
+            bv[k] = ld_voxel(vol.p + gx * vol.sx + gy * vol.sy + gz * vol.sz);
     }
+    for (int k = threadIdx.x; k < P.R; k += FNT) L.tf[k] = tfg[k];
+#pragma unroll
+    for (int k = 0; k < NLD; ++k)
+        if (ba[k] >= 0) L.box[ba[k]] = bv[k];
 }
 
-// List the ray segments of candidates [cbase, cbase+EC) and their flat offsets. Returns (nE, M) via misc.
-template <typename VT, int MODE, bool BWD, int FNT>
-__device__ __forceinline__ void flat_build_entries(const BrickParams<VT> &P, const BrickCtx &c, f3 cam, int view,
-                                                   int cbase, int ncand, size_t seg_base, FlatLds &L, int &nE, int &M) {
+// What a thread reads from global memory for its candidate pixel of a round -- issued as ONE batch of loads (the
+// ray buffers, and for the backward the coarse tape and the gradients), before any of it is looked at.
+struct CandData {
+    bool have;
+    int pl; size_t p;
+    int n; float entry, exit_, vx, vy, vz;
+    int live, scnt; unsigned char rflag;
+};
+template <typename VT, int MODE, bool BWD, bool ALPHA>
+__device__ __forceinline__ void cand_load(const BrickParams<VT> &P, const BrickCtx &c, int view, int cbase, int ncand,
+                                          size_t seg_base, CandData &d) {
     constexpr int EC = BWD ? FEC_BWD : FEC_FWD;
-    constexpr int FNW = FNT / 64;
-    static_assert(EC <= FNT, "one candidate per thread and round");
     const int NP = P.W * P.H;
     const int nj = c.j1 - c.j0 + 1;
     const int cc = cbase + threadIdx.x;
+    d.have = (int)threadIdx.x < EC && cc < ncand;
+    d.pl = 0; d.p = 0; d.n = 0; d.entry = -1.0f; d.exit_ = 0.f; d.vx = d.vy = d.vz = 0.f;
+    d.live = 0; d.scnt = 0; d.rflag = 0;
+    if (!d.have) return;
+    const int i = c.i0 + cc / nj, j = c.j0 + cc % nj;
+    d.pl = i * P.H + j;
+    d.p = (size_t)view * NP + d.pl;
+    d.n = P.nsamp[d.p];
+    d.entry = P.entry[d.p];
+    d.exit_ = P.exit_[d.p];
+    d.vx = P.rays[3 * d.p]; d.vy = P.rays[3 * d.p + 1]; d.vz = P.rays[3 * d.p + 2];
+    if (BWD || (!ALPHA && P.use_live)) d.live = P.ws_steps[d.p];
+    if (BWD) {  // (the three float4 of the coarse tape / gradients are fetched when the entry is written: the
+        d.rflag = P.rayflag[d.p];  //  backward kernel is register-bound and they would be held across the box staging)
+        d.scnt = P.seg_cnt[seg_base + d.pl];
+    }
+}
+
+// List the ray segments of the round's candidates and their flat offsets. Returns (nE, M).
+template <typename VT, int MODE, bool BWD, int FNT, bool ALPHA = false>
+__device__ __forceinline__ void flat_build_entries(const BrickParams<VT> &P, const BrickCtx &c, f3 cam, int view,
+                                                   const CandData &d, size_t seg_base, FlatLds &L, int &nE, int &M) {
+    constexpr int EC = BWD ? FEC_BWD : FEC_FWD;
+    constexpr int FNW = FNT / 64;
+    static_assert(EC <= FNT, "one candidate per thread and round");
     // each thread examines at most one candidate pixel; slots are handed out in candidate order
     // (ballot compaction), so the flat sample order -- and with it every rounding -- is reproducible
     bool has = false;
-    int pl = 0, s0 = 0, s1 = 0, live = 0;
-    float t0 = 0.f, exit_ = 0.f, nm1 = 0.f;
-    f3 vd = make_f3(0.f, 0.f, 0.f);
-    size_t p = 0;
-    if (threadIdx.x < EC && cc < ncand) {
-        const int i = c.i0 + cc / nj, j = c.j0 + cc % nj;
-        pl = i * P.H + j;
-        p = (size_t)view * NP + pl;
-        const int n = P.nsamp[p];
-        const float entry = P.entry[p];
-        bool ok = ray_is_regular(n, entry);
+    int s0 = 0, s1 = 0;
+    float t0 = 0.f, nm1 = 0.f;
+    const int pl = d.pl, live = d.live;
+    const float exit_ = d.exit_;
+    const f3 vd = make_f3(d.vx, d.vy, d.vz);
+    if (d.have) {
+        const int n = d.n;
+        bool ok = ray_is_regular(n, d.entry);
         int nmarch = (MODE == DR_MODE_DIFF && n > P.S) ? P.S : n;
+        if (!BWD && !ALPHA && ok && P.use_live && P.stats[2 + view] != 0u)
+            nmarch = min(nmarch, live);  // exact live count from the alpha pre-pass: dead samples are not marched
         if (BWD && ok) {
-            ok = !P.rayflag[p] && P.seg_cnt[seg_base + pl] != 0;  // irregular ray / no sample in this brick
-            live = P.ws_steps[p];
+            ok = !d.rflag && d.scnt != 0;  // irregular ray / no sample in this brick
             nmarch = min(nmarch, live);
         }
         if (ok) {
-            exit_ = P.exit_[p];
-            vd = make_f3(P.rays[3 * p], P.rays[3 * p + 1], P.rays[3 * p + 2]);
-            t0 = entry + 0.5f * (exit_ - entry) / (float)n;
+            t0 = d.entry + 0.5f * (exit_ - d.entry) / (float)n;
             nm1 = (float)(n - 1);
             has = segment_range(c, cam, vd, t0, exit_, n, nmarch, s0, s1);
         }
@@ -163,8 +213,8 @@ __device__ __forceinline__ void flat_build_entries(const BrickParams<VT> &P, con
         L.valid[slot] = 0;
         if (BWD) {
             L.pre[slot] = P.seg_rgba[seg_base + pl];
-            L.go[slot] = reinterpret_cast<const float4 *>(P.grad_out)[p];
-            L.of[slot] = reinterpret_cast<const float4 *>(P.out_fwd)[p];
+            L.go[slot] = reinterpret_cast<const float4 *>(P.grad_out)[d.p];
+            L.of[slot] = reinterpret_cast<const float4 *>(P.out_fwd)[d.p];
             L.live[slot] = live;
         }
     }
@@ -263,6 +313,16 @@ __device__ __forceinline__ void seg_scan_sum(float (&v)[NV], int lane, int sl) {
     DR_SUM_STEP(0x142, 4) DR_SUM_STEP(0x143, 5)
 #undef DR_SUM_STEP
 }
+// segmented inclusive PRODUCT of one value (transmittance of the alpha pre-pass)
+__device__ __forceinline__ float seg_scan_prod(float v, int lane, int sl) {
+    { const float o = dpp_f<0x111>(v); if (scan_src_ok<0>(lane, sl)) v *= o; }
+    { const float o = dpp_f<0x112>(v); if (scan_src_ok<1>(lane, sl)) v *= o; }
+    { const float o = dpp_f<0x114>(v); if (scan_src_ok<2>(lane, sl)) v *= o; }
+    { const float o = dpp_f<0x118>(v); if (scan_src_ok<3>(lane, sl)) v *= o; }
+    { const float o = dpp_f<0x142>(v); if (scan_src_ok<4>(lane, sl)) v *= o; }
+    { const float o = dpp_f<0x143>(v); if (scan_src_ok<5>(lane, sl)) v *= o; }
+    return v;
+}
 // inclusive max scan of an int (used to propagate run starts)
 __device__ __forceinline__ int scan_max(int v, int lane) {
     { const int o = dpp_i<0x111>(v); if ((lane & 15) >= 1) v = max(v, o); }
@@ -357,9 +417,11 @@ __device__ __forceinline__ void scatter_sample(unsigned long long *dbox, const T
     if (valid) scatter8<WIDE>(dbox, cbase_i, acc, fs);
 }
 
-template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF>
+// ALPHA (forward only): the alpha pre-pass -- centre tap + TF only, the partial of a segment is its accumulated alpha.
+template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, bool ALPHA = false>
 __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : 4) void brick_flat_kernel(BrickParams<VT> P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (ALPHA && P.stats[2 + blockIdx.y] == 0u) return;  // uniform: no ray of this view can terminate early
     constexpr int EC = BWD ? FEC_BWD : FEC_FWD;
     constexpr int FNT = BWD ? FNT_BWD : FNT_FWD;
     constexpr int FNW = FNT / 64;
@@ -372,7 +434,12 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : 4) vo
     FlatLds L = flat_carve<BWD, WANT_VOL, WANT_TF>(smem, P.R);
     VolView<VT> vol = P.vol;
     vol.p += view * P.vol_vs;
-    flat_load_tf_and_box<VT, FNT>(P, vol, c, P.tf + view * P.tf_vs, L);
+    const int NP = P.W * P.H;
+    const size_t seg_base = ((size_t)view * P.g.NL + c.layer) * NP;
+    const int ncand = (c.i1 - c.i0 + 1) * (c.j1 - c.j0 + 1);
+    CandData cd;
+    cand_load<VT, MODE, BWD, ALPHA>(P, c, view, 0, ncand, seg_base, cd);  // in flight while the box is staged
+    flat_load_tf_and_box<VT, FNT, !BWD>(P, vol, c, P.tf + view * P.tf_vs, L);
     FixScale fs;
     if (BWD) {
         if (WANT_VOL) for (int k = threadIdx.x; k < BOX_LDS; k += FNT) L.dbox[k] = 0ull;
@@ -380,15 +447,13 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : 4) vo
         fs = make_fix_scale(P.stats[1]);
     }
     const f3 light = make_f3(cam.x + 0.0f, cam.y + 1.0f, cam.z + 0.0f);
-    const int NP = P.W * P.H;
-    const size_t seg_base = ((size_t)view * P.g.NL + c.layer) * NP;
-    const int ncand = (c.i1 - c.i0 + 1) * (c.j1 - c.j0 + 1);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     bool any = false;
 
     for (int cbase = 0; cbase < ncand; cbase += EC) {
         int nE, M;
-        flat_build_entries<VT, MODE, BWD, FNT>(P, c, cam, view, cbase, ncand, seg_base, L, nE, M);  // syncs inside
+        if (cbase > 0) cand_load<VT, MODE, BWD, ALPHA>(P, c, view, cbase, ncand, seg_base, cd);
+        flat_build_entries<VT, MODE, BWD, FNT, ALPHA>(P, c, cam, view, cd, seg_base, L, nE, M);  // syncs inside
         any = any || nE > 0;
         // this wave owns the contiguous entry range [ea, eb): segments never straddle two waves
         const int ea = lower_bound_offs(L.offs, nE, (int)(((long long)M * wave) / FNW));
@@ -414,6 +479,45 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : 4) vo
             RayGeom rg;
             rg.t0 = r0.x; rg.exit_ = r0.y; rg.n = (int)r0.z + 1; rg.vx = r1.x; rg.vy = r1.y; rg.vz = r1.z;
             const f3 vd = make_f3(r1.x, r1.y, r1.z);
+            if (ALPHA) {
+                // alpha pre-pass: position, centre cell, one tap, TF -> transmittance; nothing else
+                Sample sa;
+                int x0 = 0, y0 = 0, z0 = 0;
+                float fx = 0.f, fy = 0.f, fz = 0.f;
+                bool va = act;
+                if (va) {
+                    sample_pos(rg, cam.x, cam.y, cam.z, s, sa.px, sa.py, sa.pz);
+                    axis_coord(sa.px, vol.scx, x0, fx); axis_coord(sa.py, vol.scy, y0, fy); axis_coord(sa.pz, vol.scz, z0, fz);
+                    va = x0 / BRK == c.bx && y0 / BRK == c.by && z0 / BRK == c.bz;
+                }
+                float Tl = 1.0f;
+                if (va) {
+                    sa.I = tri_lds(L.box, (x0 - c.ox) * BOX_SX + (y0 - c.oy) * BOX_SY + (z0 - c.oz), fx, fy, fz);
+                    classify_from_I(L.tf, P.R, P.tf_len, P.inv_sr, sa);
+                    if (!(MODE == DR_MODE_NONDIFF && !(sa.a > 1e-3f))) Tl = 1.0f - sa.op;
+                }
+                Tl = seg_scan_prod(Tl, lane, sl);
+                const int e_first = __builtin_amdgcn_readfirstlane(e);
+                if (carry_e == e_first && e == e_first) Tl *= carry.a;  // carry.a holds the transmittance so far
+                {
+                    const int e_last = __builtin_amdgcn_readlane(e, 63);
+                    const float lastT = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Tl), 63));
+                    const bool more = (f0 + 64 < fb) && (L.offs[e_last + 1] > f0 + 64);
+                    carry.a = lastT; carry_e = more ? e_last : -1;
+                }
+                const bool seg_end = act && (f == L.offs[e + 1] - 1);
+                const unsigned long long vm = __ballot(va);
+                const bool piece_end = act && (seg_end || lane == 63 || f == fb - 1);
+                if (piece_end) {
+                    const unsigned long long below = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+                    const unsigned long long from = ~((1ull << sl) - 1ull);
+                    const int cntp = __popcll(vm & below & from);
+                    const int before = cntp ? atomicAdd(&L.valid[e], cntp) : L.valid[e];
+                    if (seg_end && before + cntp > 0)
+                        P.seg_rgba[seg_base + __float_as_int(r1.w)] = make_float4(0.f, 0.f, 0.f, 1.0f - Tl);
+                }
+                continue;
+            }
             Sample sm; TapCoords t;
             bool valid = act && sample_coords(vol, c, rg, cam, s, sm, t);
             float dx = 0.f, dy = 0.f, dz = 0.f;
@@ -427,7 +531,7 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : 4) vo
             // is (the nondiff path skips alpha <= 1e-3 by definition, VR.py:334). Lanes are consecutive samples of a
             // ray, so empty stretches of the transfer function are wave-uniform: skip the six normal taps (48 of the
             // 56 LDS reads) and the shading for the whole wave. The backward always needs L (d/d alpha).
-            const bool lit = valid && (BWD || (MODE == DR_MODE_NONDIFF ? (sm.a > 1e-3f) : (sm.op != 0.0f)));
+            const bool lit = !ALPHA && valid && (BWD || (MODE == DR_MODE_NONDIFF ? (sm.a > 1e-3f) : (sm.op != 0.0f)));
             if (BWD || __any(lit)) {
                 if (lit) {
                     sample_normal_taps_lds(L.box, t, dx, dy, dz);
@@ -587,6 +691,30 @@ static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     if (e != hipSuccess) return (int)e;
     const size_t lds = flat_lds_bytes<false>(a.R, false, false);
     const dim3 grid1(g.NBx * g.NBy * g.NBz, a.n_views);
+    // Alpha pre-pass (early-termination culling): only if the TF can make some ray reach alpha >= 0.99 -- decided on
+    // the device from max(alpha), the kernels of the pre-pass return at once otherwise.
+    const bool prepass = a.n_views <= 48;
+    if (prepass) {
+        const double diag = sqrt((double)(a.VX - 1) * (a.VX - 1) + (double)(a.VY - 1) * (a.VY - 1) + (double)(a.VZ - 1) * (a.VZ - 1));
+        double n_max = floor((double)a.sr * 2.0 * sqrt(3.0) * diag) + 1.0;  // longest chord of the box (VR.py:251-253)
+        if (a.mode == DR_MODE_DIFF && n_max > a.S) n_max = a.S;
+        hipLaunchKernelGGL(may_terminate_kernel, dim3(a.n_views), dim3(64), 0, stream, reinterpret_cast<const float4 *>(a.tf),
+                           (long)(a.tf_vs / 4), a.R, 1.0f / a.sr, (float)n_max, w.stats + 2);
+        if (a.mode == DR_MODE_DIFF) {
+            if ((e = allow_lds(brick_flat_kernel<VT, DR_MODE_DIFF, false, false, false, true>, lds)) != hipSuccess) return (int)e;
+            hipLaunchKernelGGL((brick_flat_kernel<VT, DR_MODE_DIFF, false, false, false, true>), grid1, dim3(FNT_FWD), lds, stream, P);
+        } else {
+            if ((e = allow_lds(brick_flat_kernel<VT, DR_MODE_NONDIFF, false, false, false, true>, lds)) != hipSuccess) return (int)e;
+            hipLaunchKernelGGL((brick_flat_kernel<VT, DR_MODE_NONDIFF, false, false, false, true>), grid1, dim3(FNT_FWD), lds, stream, P);
+        }
+        if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+        const int rc = launch_ray_alpha(a, stream);
+        if (rc) return rc;
+        if ((e = hipMemsetAsync(w.seg_cnt, 0, w.cnt_bytes, stream)) != hipSuccess) return (int)e;
+    }
+    MarchArgs b = a;
+    b.use_live = prepass ? 1 : 0;
+    P.use_live = b.use_live;
     if (a.mode == DR_MODE_DIFF) {
         if ((e = allow_lds(brick_flat_kernel<VT, DR_MODE_DIFF, false, false, false>, lds)) != hipSuccess) return (int)e;
         hipLaunchKernelGGL((brick_flat_kernel<VT, DR_MODE_DIFF, false, false, false>), grid1, dim3(FNT_FWD), lds, stream, P);
@@ -595,7 +723,7 @@ static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
         hipLaunchKernelGGL((brick_flat_kernel<VT, DR_MODE_NONDIFF, false, false, false>), grid1, dim3(FNT_FWD), lds, stream, P);
     }
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
-    return launch_ray_compose(a, stream);
+    return launch_ray_compose(b, stream);
 }
 
 int launch_march_fwd_flat(const MarchArgs &a, hipStream_t stream) {
