@@ -33,6 +33,10 @@ constexpr int FNT_BWD = DR_FNT_BWD;     // (backward: 118 KB of LDS -> one workg
 #ifndef DR_FEC_BWD
 #define DR_FEC_BWD 256
 #endif
+#ifndef DR_BWD_TABLES_GLOBAL
+#define DR_BWD_TABLES_GLOBAL 1
+#endif
+constexpr bool BWD_TABLES_GLOBAL = DR_BWD_TABLES_GLOBAL != 0;  // per-ray backward inputs from global memory, not LDS
 constexpr int FEC_FWD = DR_FEC_FWD;      // ray segments listed per round (<= threads: one candidate per thread)
 constexpr int FEC_BWD = DR_FEC_BWD;      // (backward: the entry table also holds prefix / gradient / output)
 
@@ -54,7 +58,7 @@ __host__ __device__ constexpr size_t flat_fixed_bytes(bool want_vol) {
     constexpr int EC = BWD ? FEC_BWD : FEC_FWD;
     size_t s = ((size_t)BOX_LDS * 4 + 15) / 16 * 16;
     if (BWD && want_vol) s += ((size_t)BOX_LDS * 8 + 15) / 16 * 16;
-    s += (size_t)EC * 32 + (BWD ? (size_t)EC * 48 : 0);
+    s += (size_t)EC * 32 + ((BWD && !BWD_TABLES_GLOBAL) ? (size_t)EC * 48 : 0);
     s += (size_t)EC * 4 + (((size_t)EC + 1) * 4 + 15) / 16 * 16 + (size_t)EC * 4 + (BWD ? (size_t)EC * 4 : 0) + 128;
     return s;
 }
@@ -72,7 +76,7 @@ __device__ __forceinline__ FlatLds flat_carve(unsigned char *smem, int R) {
     if (BWD && WANT_VOL) { L.dbox = reinterpret_cast<unsigned long long *>(smem + o); o += align16(BOX_LDS * 8); }
     L.ray0 = reinterpret_cast<float4 *>(smem + o); o += (size_t)EC * 16;
     L.ray1 = reinterpret_cast<float4 *>(smem + o); o += (size_t)EC * 16;
-    if (BWD) {
+    if (BWD && !BWD_TABLES_GLOBAL) {
         L.pre = reinterpret_cast<float4 *>(smem + o); o += (size_t)EC * 16;
         L.go = reinterpret_cast<float4 *>(smem + o); o += (size_t)EC * 16;
         L.of = reinterpret_cast<float4 *>(smem + o); o += (size_t)EC * 16;
@@ -212,9 +216,11 @@ __device__ __forceinline__ void flat_build_entries(const BrickParams<VT> &P, con
         L.offs[slot + 1] = s1 - s0;   // length; prefix-summed below
         L.valid[slot] = 0;
         if (BWD) {
-            L.pre[slot] = P.seg_rgba[seg_base + pl];
-            L.go[slot] = reinterpret_cast<const float4 *>(P.grad_out)[d.p];
-            L.of[slot] = reinterpret_cast<const float4 *>(P.out_fwd)[d.p];
+            if (!BWD_TABLES_GLOBAL) {
+                L.pre[slot] = P.seg_rgba[seg_base + pl];
+                L.go[slot] = reinterpret_cast<const float4 *>(P.grad_out)[d.p];
+                L.of[slot] = reinterpret_cast<const float4 *>(P.out_fwd)[d.p];
+            }
             L.live[slot] = live;
         }
     }
@@ -575,7 +581,13 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : 4) vo
                 SampleAdj ad;
                 ad.r_bar = ad.g_bar = ad.b_bar = ad.a_bar = 0.f; ad.gx = ad.gy = ad.gz = 0.f;
                 if (valid) {
-                    const float4 pre = L.pre[e], go = L.go[e], of = L.of[e];
+                    float4 pre, go, of;
+                    if (BWD_TABLES_GLOBAL) {  // lanes of a chunk share a few rays: these are broadcast-like cached loads
+                        const int plq = __float_as_int(r1.w);
+                        pre = P.seg_rgba[seg_base + plq];
+                        go = reinterpret_cast<const float4 *>(P.grad_out)[(size_t)view * NP + plq];
+                        of = reinterpret_cast<const float4 *>(P.out_fwd)[(size_t)view * NP + plq];
+                    } else { pre = L.pre[e]; go = L.go[e]; of = L.of[e]; }
                     const Over preo = {pre.x, pre.y, pre.z, pre.w};
                     const Over absi = over(preo, inc);                       // composite up to and including s
                     const float T = (1.0f - pre.w) * (1.0f - exc.a);         // transmittance before s
