@@ -368,3 +368,18 @@ def test_large_tf_falls_back_to_supported_kernels(oracle, hiplib):
     e0, x0, r0, n0 = oracle.ray_setup(cam, 16, 16, vol.shape)
     ref, _ = oracle.march_fwd(vol, tf2, cam, e0, x0, r0, n0, 4096, 1.0, 0)
     assert np.abs(out[0].cpu().numpy() - ref).max() <= FWD_TOL
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_high_sampling_rate_with_termination(oracle, F, mode):
+    """sr = 8 (the reference renders its ground truth at 8x, OPT.py:67) with a terminating TF: long segments that span
+    many 64-sample chunks, the alpha pre-pass and the exact termination sample."""
+    vol, tf, cam = scene(oracle, N=64, tf="peaks", R=128, cam_i=2.6)
+    tf[:, 3] = np.linspace(0.0, 0.5, 128)
+    WH = (96, 80)
+    ref, sref, out, steps, (e0, x0, r0, n0), _ = _fwd_both(oracle, F, vol, tf, cam, WH, sr=8.0, mode=mode)
+    assert n0.max() > 1500 and (sref < n0)[n0 > 100].mean() > 0.5
+    same = steps == sref
+    assert same.mean() > 0.995
+    assert np.abs(out - ref).max(-1)[same].max() <= FWD_TOL
+    assert np.abs(out - ref).max() <= 2e-3
