@@ -202,7 +202,10 @@ def main():
         pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_per_launch.json")))
         for k, v in pm.items():
             if "brick_flat_kernel" in k and "FETCH_SIZE" in v:
-                traffic["bwd" if "true" in k.split("<")[1].split(",")[2] else "fwd"] = int((v["FETCH_SIZE"] + v.get("WRITE_SIZE", 0)) * 1024)
+                targs = [t.strip(" >") for t in k.split("<")[1].split(",")]  # <VT, MODE, BWD, VOL, TF, ALPHA>
+                if len(targs) >= 6 and targs[5] == "true":
+                    continue  # the (gated) alpha pre-pass
+                traffic["bwd" if targs[2] == "true" else "fwd"] = int((v["FETCH_SIZE"] + v.get("WRITE_SIZE", 0)) * 1024)
     except Exception:
         pass
     roof_fwd = roof("march_fwd", fwd_ms, B_FWD)
