@@ -26,6 +26,8 @@ SIGNATURES = {
                           _I, _I, _I, _I, _F, _D, _D, _I, _I, _P, _P, _P, _Z, _P]),
     "dr_march_bwd": (_I, [_P, _I, _I, _I, _I, _L, _L, _L, _L, _P, _I, _L, _P, _P, _P, _P, _P,
                           _I, _I, _I, _I, _F, _D, _D, _I, _P, _P, _P, _L, _L, _L, _L, _P, _L, _P, _Z, _P]),
+    "dr_mse_loss_grad": (_I, [_P, _P, _L, _F, _P, _P, _P]),
+    "dr_tf_momentum_step": (_I, [_P, _P, _P, _I, _F, _F, _F, _P]),
 }
 
 _lib = None
@@ -44,7 +46,7 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.dr_abi_version() != 2:
+        if handle.dr_abi_version() != 3:
             raise ImportError("libdifferender_hip.so ABI version mismatch; rebuild it")
         _lib = handle
     return _lib

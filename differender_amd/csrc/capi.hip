@@ -106,4 +106,16 @@ int dr_march_bwd(const void *vol, int vol_dtype, int VX, int VY, int VZ, int64_t
     return launch_march_bwd_baseline(a, (hipStream_t)stream);
 }
 
+int dr_mse_loss_grad(const float *out_rgba, const float *reference, int64_t n, float inv_norm, float *grad_out,
+                     double *loss, void *stream) {
+    if (!out_rgba || !reference || n <= 0 || (!grad_out && !loss)) return DR_EINVAL;
+    return (int)launch_mse_loss_grad(out_rgba, reference, n, inv_norm, grad_out, loss, (hipStream_t)stream);
+}
+
+int dr_tf_momentum_step(float *tf, const float *d_tf, float *momentum, int n, float lr, float gamma, float max_grad,
+                        void *stream) {
+    if (!tf || !d_tf || !momentum || n <= 0 || !(max_grad >= 0.0f)) return DR_EINVAL;
+    return (int)launch_tf_momentum_step(tf, d_tf, momentum, n, lr, gamma, max_grad, (hipStream_t)stream);
+}
+
 }  // extern "C"

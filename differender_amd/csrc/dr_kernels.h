@@ -42,4 +42,10 @@ bool flat_path_supported(int VX, int VY, int VZ, int R);
 int launch_march_fwd_flat(const MarchArgs &a, hipStream_t stream);   // one lane per sample
 int launch_march_bwd_flat(const MarchArgs &a, hipStream_t stream);
 
+// Loss / optimiser epilogue (epilogue.hip)
+hipError_t launch_mse_loss_grad(const float *out, const float *ref, int64_t n, float inv_norm, float *grad,
+                                double *loss, hipStream_t stream);
+hipError_t launch_tf_momentum_step(float *tf, const float *g, float *mom, int n, float lr, float gamma,
+                                   float max_grad, hipStream_t stream);
+
 }  // namespace dr

@@ -10,7 +10,8 @@ import torch
 
 from . import _native as N
 
-__all__ = ["ray_setup", "march_fwd", "march_bwd", "new_jitter_seed", "alloc_workspace", "workspace_stats"]
+__all__ = ["ray_setup", "march_fwd", "march_bwd", "new_jitter_seed", "alloc_workspace", "workspace_stats",
+           "mse_loss_grad", "tf_momentum_step"]
 
 
 def _stream():
@@ -161,3 +162,40 @@ def march_bwd(vol, tf, cam, entry, exit_, rays, n, max_samples, sampling_rate, g
                                   grad_out.data_ptr(), out.data_ptr(), *dv, *dt, *_ws_args(workspace), _stream())
     N.check(rc, "dr_march_bwd")
     return d_vol, d_tf
+
+
+def mse_loss_grad(out, reference, inv_norm=None, want_grad=True, loss=None):
+    """Image loss and its gradient in one pass over the render (dr_mse_loss_grad; replaces compute_loss,
+    EX.py:368-373, and the torch mse_loss round trip of EX.py:439-443).
+    Returns (loss, grad_out): loss is a 0-d float64 tensor on the device (accumulated into `loss` if given),
+    grad_out has the shape of `out`. inv_norm defaults to 1/numel (= torch.nn.functional.mse_loss)."""
+    _require_gpu(out, "out")
+    if reference.shape != out.shape or reference.device != out.device:
+        raise ValueError("reference must match out in shape and device")
+    if out.dtype != torch.float32 or reference.dtype != torch.float32:
+        raise TypeError("out and reference must be float32")
+    out = out.contiguous()
+    reference = reference.contiguous()
+    if loss is None:
+        loss = torch.zeros((), dtype=torch.float64, device=out.device)
+    grad = torch.empty_like(out) if want_grad else None
+    inv_norm = 1.0 / out.numel() if inv_norm is None else float(inv_norm)
+    with torch.cuda.device(out.device):
+        rc = N.lib().dr_mse_loss_grad(out.data_ptr(), reference.data_ptr(), out.numel(), inv_norm,
+                                      grad.data_ptr() if want_grad else None, loss.data_ptr(), _stream())
+    N.check(rc, "dr_mse_loss_grad")
+    return loss, grad
+
+
+def tf_momentum_step(tf, d_tf, momentum, lr, gamma, max_grad):
+    """In-place momentum step on the transfer function (dr_tf_momentum_step; apply_grad, EX.py:375-381):
+    momentum = gamma*momentum + lr*clamp(d_tf, +-max_grad); tf = max(tf - momentum, 0)."""
+    _require_gpu(tf, "tf")
+    for t, name in ((tf, "tf"), (d_tf, "d_tf"), (momentum, "momentum")):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.shape != tf.shape or t.device != tf.device:
+            raise ValueError(f"{name} must be a contiguous float32 tensor of tf's shape on tf's device")
+    with torch.cuda.device(tf.device):
+        rc = N.lib().dr_tf_momentum_step(tf.data_ptr(), d_tf.data_ptr(), momentum.data_ptr(), tf.numel(), float(lr),
+                                         float(gamma), float(max_grad), _stream())
+    N.check(rc, "dr_tf_momentum_step")
+    return tf, momentum

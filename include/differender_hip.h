@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DR_ABI_VERSION 2
+#define DR_ABI_VERSION 3
 
 enum { DR_F32 = 0, DR_F16 = 1 };
 enum { DR_MODE_DIFF = 0, DR_MODE_NONDIFF = 1 };
@@ -109,6 +109,22 @@ int dr_march_bwd(const void *vol, int vol_dtype, int VX, int VY, int VZ,
                  float *d_vol, int64_t dsx, int64_t dsy, int64_t dsz, int64_t dvol_view_stride,
                  float *d_tf, int64_t dtf_view_stride,
                  void *workspace, size_t workspace_bytes, void *stream);
+
+/* Image loss and its gradient, one pass over the rendered image (the step after the march in an optimisation
+ * loop): replaces compute_loss (examples/taichi_volume_raycaster.py:368-373, "EX.py") and the torch mse_loss
+ * round trip of EX.py:439-443.
+ *   out_rgba, reference  [n] f32 (n = n_views*W*H*4)
+ *   grad_out [n] f32, nullable:  (out - ref) * (2*inv_norm)
+ *   loss     one f64 on the device, nullable; ACCUMULATED into:  += inv_norm * sum (out - ref)^2
+ * inv_norm = 1/n gives torch.nn.functional.mse_loss; 1/(3*W*H) gives EX.py:369-373. */
+int dr_mse_loss_grad(const float *out_rgba, const float *reference, int64_t n, float inv_norm,
+                     float *grad_out, double *loss, void *stream);
+
+/* Momentum gradient step on the transfer function, in place (apply_grad, EX.py:375-381):
+ *   momentum = gamma*momentum + lr*clamp(d_tf, -max_grad, max_grad);  tf = max(tf - momentum, 0)
+ *   tf, d_tf, momentum [n] f32 (n = R*4). */
+int dr_tf_momentum_step(float *tf, const float *d_tf, float *momentum, int n, float lr, float gamma,
+                        float max_grad, void *stream);
 
 #ifdef __cplusplus
 }

@@ -38,3 +38,28 @@
 #include "dr_oracle_impl.inc"
 
 int dro_abi_version(void) { return 1; }
+
+/* ---- loss / optimiser epilogue (f32 only; the f64 check is a numpy one-liner in the tests) ---- */
+
+/* compute_loss (examples/taichi_volume_raycaster.py:368-373) and the mse_loss round trip of :439-443:
+ * grad = (out - ref) * (2*inv_norm);  returns inv_norm * sum (out - ref)^2 (sum carried in double). */
+double dro_mse_loss_grad_f32(const float *out, const float *ref, int64_t n, float inv_norm, float *grad) {
+    double acc = 0.0;
+    float two_inv = 2.0f * inv_norm;
+    for (int64_t i = 0; i < n; ++i) {
+        float d = out[i] - ref[i];
+        if (grad) grad[i] = d * two_inv;
+        acc += (double)d * (double)d;
+    }
+    return acc * (double)inv_norm;
+}
+
+/* apply_grad (examples/taichi_volume_raycaster.py:375-381): momentum step with gradient clipping, tf >= 0. */
+void dro_tf_momentum_step_f32(float *tf, const float *g, float *mom, int n, float lr, float gamma, float max_grad) {
+    for (int i = 0; i < n; ++i) {
+        float c = fminf(max_grad, fmaxf(-max_grad, g[i]));
+        float m = gamma * mom[i] + lr * c;
+        mom[i] = m;
+        tf[i] = fmaxf(tf[i] - m, 0.0f);
+    }
+}

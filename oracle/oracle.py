@@ -111,6 +111,32 @@ def march_bwd(vol, tf, cam, entry, exit_, rays, n, S, sr, grad_out, want_vol=Tru
     return d_vol, d_tf
 
 
+def mse_loss_grad(out, ref, inv_norm=None):
+    """(loss, grad) of inv_norm * sum (out-ref)^2; inv_norm defaults to 1/numel (torch mse_loss, EX.py:439-443)."""
+    out = np.ascontiguousarray(out, np.float32)
+    ref = np.ascontiguousarray(ref, np.float32)
+    inv_norm = 1.0 / out.size if inv_norm is None else inv_norm
+    grad = np.empty_like(out)
+    fn = lib().dro_mse_loss_grad_f32
+    fn.restype = ctypes.c_double
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p]
+    loss = fn(_p(out), _p(ref), out.size, np.float32(inv_norm), _p(grad))
+    return loss, grad
+
+
+def tf_momentum_step(tf, d_tf, momentum, lr, gamma, max_grad):
+    """In-place apply_grad (EX.py:375-381) on copies; returns (tf, momentum)."""
+    tf = np.array(tf, np.float32, order="C")
+    mom = np.array(momentum, np.float32, order="C")
+    g = np.ascontiguousarray(d_tf, np.float32)
+    fn = lib().dro_tf_momentum_step_f32
+    fn.restype = None
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_float,
+                   ctypes.c_float]
+    fn(_p(tf), _p(g), _p(mom), tf.size, lr, gamma, max_grad)
+    return tf, mom
+
+
 def render(vol, tf, cam, out_shape, S=1 << 30, sr=1.0, mode=0, jitter_seed=0, view=0, fov_deg=30.0, near=0.1):
     """ray_setup + march_fwd in one call (the sequence of VR.py:431-438)."""
     W, H = out_shape

@@ -14,7 +14,8 @@ def _declared_symbols():
 
 def test_header_declares_expected_entry_points():
     syms = _declared_symbols()
-    for s in ("dr_abi_version", "dr_error_string", "dr_ray_setup", "dr_march_fwd", "dr_march_bwd"):
+    for s in ("dr_abi_version", "dr_error_string", "dr_ray_setup", "dr_march_fwd", "dr_march_bwd",
+              "dr_mse_loss_grad", "dr_tf_momentum_step"):
         assert s in syms
 
 
@@ -24,7 +25,7 @@ def test_library_exports_every_declared_symbol(hiplib):
     for s in _declared_symbols():
         assert hasattr(raw, s), f"{s} declared in include/differender_hip.h but not exported"
         assert s in N.SIGNATURES, f"{s} has no ctypes signature in differender_amd/_native.py"
-    assert hiplib.dr_abi_version() == 2
+    assert hiplib.dr_abi_version() == 3
     assert b"invalid" in hiplib.dr_error_string(-1)
 
 

@@ -303,6 +303,57 @@ def test_optimisation_loop_reduces_loss(oracle, F):
     assert losses[-1] < 0.7 * losses[0], losses
 
 
+def test_loss_epilogue_and_momentum_step(oracle, hiplib):
+    """dr_mse_loss_grad / dr_tf_momentum_step vs the oracle's statement of EX.py:368-381 (bit-exact
+    elementwise results; the loss sum is carried in double on both sides)."""
+    from differender_amd import functional as Fn
+    rng = np.random.default_rng(11)
+    out = rng.random((2, 40, 24, 4), dtype=np.float32)
+    ref = rng.random((2, 40, 24, 4), dtype=np.float32)
+    for inv in (None, 1.0 / (3 * 40 * 24)):
+        loss_o, grad_o = oracle.mse_loss_grad(out, ref, inv)
+        loss_g, grad_g = Fn.mse_loss_grad(T(out), T(ref), inv)
+        assert np.array_equal(grad_g.cpu().numpy(), grad_o)
+        assert abs(float(loss_g) - loss_o) <= 1e-12 * abs(loss_o) + 1e-15
+    acc = torch.zeros((), dtype=torch.float64, device=dev())
+    Fn.mse_loss_grad(T(out[0]), T(ref[0]), 1.0 / out.size, want_grad=False, loss=acc)
+    Fn.mse_loss_grad(T(out[1]), T(ref[1]), 1.0 / out.size, want_grad=False, loss=acc)   # accumulates over views
+    assert abs(float(acc) - oracle.mse_loss_grad(out, ref)[0]) < 1e-10
+
+    tf = (rng.random((64, 4), dtype=np.float32) * 0.1)
+    g = (rng.standard_normal((64, 4)) * 3).astype(np.float32)
+    mom = (rng.standard_normal((64, 4)) * 0.01).astype(np.float32)
+    tf_o, mom_o = oracle.tf_momentum_step(tf, g, mom, 0.05, 0.9, 1.0)
+    tf_g, mom_g = Fn.tf_momentum_step(T(tf), T(g), T(mom), 0.05, 0.9, 1.0)
+    assert np.array_equal(tf_g.cpu().numpy(), tf_o) and np.array_equal(mom_g.cpu().numpy(), mom_o)
+    with pytest.raises(ValueError):
+        Fn.tf_momentum_step(T(tf), T(g[:32]), T(mom), 0.05, 0.9, 1.0)
+
+
+def test_tf_optimisation_with_fused_epilogue(oracle, F):
+    """The loop of examples/taichi_volume_raycaster.py:583-601 (render, loss, backward, momentum step on the TF)
+    through the C ABI only: no framework elementwise ops between the kernels. The loss must go down."""
+    from differender_amd import functional as Fn
+    N, R, WH = 32, 32, (48, 48)
+    vol = T(oracle.synth_volume(N))
+    tf_gt = T(oracle.peaks_tf(R))
+    tf = T(oracle.bench_tf(R, 0.05)).clone()
+    mom = torch.zeros_like(tf)
+    cam = T(np.atleast_2d(oracle.in_circles(0.4)))
+    e, x, r, n = F.ray_setup(cam, WH, vol.shape, 1.0, 30.0, 0.1, 0, 0)
+    ref, _ = F.march_fwd(vol, tf_gt, cam, e, x, r, n, 4096, 1.0)
+    ref = ref.clone()
+    losses = []
+    for it in range(25):
+        out, _ = F.march_fwd(vol, tf, cam, e, x, r, n, 4096, 1.0)
+        loss, g = Fn.mse_loss_grad(out, ref)
+        _, d_tf = F.march_bwd(vol, tf, cam, e, x, r, n, 4096, 1.0, g, out, want_vol=False)
+        Fn.tf_momentum_step(tf, d_tf, mom, 0.5, 0.8, 1.0)
+        losses.append(float(loss))
+    assert (tf >= 0).all()
+    assert losses[-1] < 0.5 * losses[0], losses
+
+
 @pytest.mark.parametrize("cam", [(0.2, 0.1, 0.3), (0.9, 0.3, -1.15), (0.0, 1.6, 0.05)],
                          ids=["inside", "near-corner", "above-nearly-along-y"])
 def test_unusual_cameras(oracle, F, cam):

@@ -208,3 +208,26 @@ def test_f32_oracle_tracks_f64(oracle):
     o32, _ = oracle.march_fwd(vol.astype(f), tf.astype(f), cam.astype(f), e.astype(f), x.astype(f), r.astype(f), n,
                               1 << 20, 1.0, 0)
     assert np.abs(o32 - o64).max() < 5e-5
+
+
+def test_epilogue_loss_and_momentum_step(oracle):
+    O = oracle
+    """oracle epilogue vs. a float64 numpy statement of EX.py:368-381 / torch mse_loss."""
+    rng = np.random.default_rng(5)
+    out = rng.random((3, 8, 8, 4), dtype=np.float32)
+    ref = rng.random((3, 8, 8, 4), dtype=np.float32)
+    loss, grad = O.mse_loss_grad(out, ref)
+    d = out.astype(np.float64) - ref
+    assert abs(loss - (d * d).mean()) < 1e-7 * loss      # d and 1/n are rounded to f32
+    np.testing.assert_allclose(grad, 2 * d / d.size, rtol=3e-7, atol=0)
+    loss3, _ = O.mse_loss_grad(out[0], ref[0], inv_norm=1.0 / (3 * 64))   # EX.py:369-373 normalisation
+    assert abs(loss3 - (d[0] * d[0]).sum() / (3 * 64)) < 1e-7 * loss3
+
+    tf = rng.random((16, 4), dtype=np.float32) * 0.1
+    g = (rng.standard_normal((16, 4)) * 3).astype(np.float32)
+    mom = (rng.standard_normal((16, 4)) * 0.01).astype(np.float32)
+    tf2, mom2 = O.tf_momentum_step(tf, g, mom, lr=0.05, gamma=0.9, max_grad=1.0)
+    m_ref = 0.9 * mom.astype(np.float64) + 0.05 * np.clip(g.astype(np.float64), -1, 1)
+    np.testing.assert_allclose(mom2, m_ref, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(tf2, np.maximum(tf - m_ref, 0), rtol=1e-6, atol=1e-8)
+    assert (tf2 >= 0).all() and (tf2 == 0).any()      # the clamp at zero is exercised
