@@ -50,10 +50,10 @@ __host__ __device__ inline BrickGrid make_brick_grid(int VX, int VY, int VZ) {
 // The canonical per-axis coordinate of VR.py:163-168 (must stay bit-identical everywhere it is used:
 // it decides which brick owns a sample).
 __device__ __forceinline__ void axis_coord(float pos, float sc, int &cell, float &fr) {
-    float q = fminf(1.0f, fmaxf(0.0f, fmaf(0.5f, pos, 0.5f))) * sc;
-    float low = floorf(q);
-    fr = q - low;
-    cell = (int)low;
+    const float q = fminf(1.0f, fmaxf(0.0f, fmaf(0.5f, pos, 0.5f))) * sc;
+    // q >= 0: q - floor(q) is exact, so v_fract_f32 returns the same bits; the conversion truncates = floor
+    fr = __builtin_amdgcn_fractf(q);
+    cell = (int)q;
 }
 
 // brick coordinate of the camera along one axis (unclamped linear map, may be negative or >= NB)

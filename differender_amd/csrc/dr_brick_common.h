@@ -232,19 +232,19 @@ __device__ __forceinline__ void sample_normal_taps_lds(const float *box, const T
     dz = tri_lds(box, bx + by + t.lzp, t.fx, t.fy, t.fzp) - tri_lds(box, bx + by + t.lzm, t.fx, t.fy, t.fzm);
 }
 
-// Position of sample s and its tap coordinates; returns whether the sample's cell lies in this brick.
+// Tap coordinates of a sample at (sm.px, sm.py, sm.pz); returns whether the sample's cell lies in this brick.
 template <typename VT>
-__device__ __forceinline__ bool sample_coords(const VolView<VT> &vol, const BrickCtx &c, const RayGeom &rg, f3 cam,
-                                              int s, Sample &sm, TapCoords &t) {
-    sample_pos(rg, cam.x, cam.y, cam.z, s, sm.px, sm.py, sm.pz);
+__device__ __forceinline__ bool sample_coords_at(const VolView<VT> &vol, const BrickCtx &c, Sample &sm, TapCoords &t) {
     int x0, y0, z0;
     axis_coord(sm.px, vol.scx, x0, t.fx);
     axis_coord(sm.py, vol.scy, y0, t.fy);
     axis_coord(sm.pz, vol.scz, z0, t.fz);
-    if (x0 / BRK != c.bx || y0 / BRK != c.by || z0 / BRK != c.bz) return false;  // x0 >= 0
+    t.lx = x0 - c.ox; t.ly = y0 - c.oy; t.lz = z0 - c.oz;
+    // the brick's cells are box elements 1 .. BRK along each axis (element 0 is the voxel below the brick)
+    if ((unsigned)(t.lx - 1) >= (unsigned)BRK || (unsigned)(t.ly - 1) >= (unsigned)BRK || (unsigned)(t.lz - 1) >= (unsigned)BRK)
+        return false;
     const float delta = 1e-3f;
     int k;
-    t.lx = x0 - c.ox; t.ly = y0 - c.oy; t.lz = z0 - c.oz;
     axis_coord(sm.px + delta, vol.scx, k, t.fxp); t.lxp = k - c.ox;
     axis_coord(sm.px - delta, vol.scx, k, t.fxm); t.lxm = k - c.ox;
     axis_coord(sm.py + delta, vol.scy, k, t.fyp); t.lyp = k - c.oy;
@@ -252,6 +252,13 @@ __device__ __forceinline__ bool sample_coords(const VolView<VT> &vol, const Bric
     axis_coord(sm.pz + delta, vol.scz, k, t.fzp); t.lzp = k - c.oz;
     axis_coord(sm.pz - delta, vol.scz, k, t.fzm); t.lzm = k - c.oz;
     return true;
+}
+// Position of sample s and its tap coordinates.
+template <typename VT>
+__device__ __forceinline__ bool sample_coords(const VolView<VT> &vol, const BrickCtx &c, const RayGeom &rg, f3 cam,
+                                              int s, Sample &sm, TapCoords &t) {
+    sample_pos(rg, cam.x, cam.y, cam.z, s, sm.px, sm.py, sm.pz);
+    return sample_coords_at(vol, c, sm, t);
 }
 
 // Tap coordinates alone, from a position (same arithmetic as sample_coords).
@@ -316,7 +323,7 @@ __device__ __forceinline__ bool fix_fits(float absmax, const FixScale &f) { retu
 template <bool WIDE>
 __device__ __forceinline__ void fix_add_t(unsigned long long *p, float x, const FixScale &f) {
     if (WIDE) { fix_add_wide(p, x, f); return; }
-    const int q = __float2int_rn(x * f.lo);
+    const int q = (int)(x * f.lo);  // truncation: <= 1 unit of 2^-shift (~4e-9 max|grad_out|) per add
     atomicAdd(p, (unsigned long long)(long long)q);  // ds_add_u64
 }
 __device__ __forceinline__ void fix_add(unsigned long long *p, float x, const FixScale &f) { fix_add_wide(p, x, f); }

@@ -42,7 +42,7 @@ constexpr int FEC_BWD = DR_FEC_BWD;      // (backward: the entry table also hold
 
 struct FlatLds {
     float4 *tf; float *box; unsigned long long *dbox; unsigned long long *dtf;
-    float4 *ray0;   // (t0, exit, (float)(n-1), unused)
+    float4 *ray0;   // (t0, exit, (float)(n-1), RN(1/(n-1)))
     float4 *ray1;   // (vx, vy, vz, bits(pixel index))
     float4 *pre, *go, *of;  // backward: composite before the segment, upstream gradient, forward output
     int *s_rel;     // first sample index of the segment minus its flat offset
@@ -210,7 +210,7 @@ __device__ __forceinline__ void flat_build_entries(const BrickParams<VT> &P, con
     nE = total;
     if (has) {
         const int slot = base + __popcll(hm & ((1ull << lane_) - 1ull));
-        L.ray0[slot] = make_float4(t0, exit_, nm1, 0.0f);
+        L.ray0[slot] = make_float4(t0, exit_, nm1, 1.0f / nm1);  // n >= 2 (ray_is_regular)
         L.ray1[slot] = make_float4(vd.x, vd.y, vd.z, __int_as_float(pl));
         L.s_rel[slot] = s0;           // turned into s0 - offs below
         L.offs[slot + 1] = s1 - s0;   // length; prefix-summed below
@@ -294,14 +294,39 @@ __device__ __forceinline__ bool scan_src_ok(int lane, int sl) {
     if (K == 4) return (lane & 16) && ((lane & ~15) - 1) >= sl;
     return lane >= 32 && 31 >= sl;
 }
+// DPP move whose lanes without a source read 0 (bound_ctrl): the destination needs no initial value, so the
+// compiler does not spend a v_mov on it. Every use below ignores what such lanes receive.
+template <int CTRL>
+__device__ __forceinline__ float dpp0_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ Over dpp0_over(const Over &v) {
+    Over r;
+    r.c0 = dpp0_f<CTRL>(v.c0); r.c1 = dpp0_f<CTRL>(v.c1); r.c2 = dpp0_f<CTRL>(v.c2); r.a = dpp0_f<CTRL>(v.a);
+    return r;
+}
+// x = T*x + o in x's own register (the compiler's choice, v_fmac into the DPP temporary, needs a move back per channel)
+__device__ __forceinline__ void fma_into(float &x, float T, float o) {
+#ifdef DR_NO_ASM_FMA
+    x = fmaf(T, x, o);
+#else
+    asm("v_fma_f32 %0, %1, %0, %2" : "+v"(x) : "v"(T), "v"(o));
+#endif
+}
 // segmented inclusive scan of "over": segments are runs of lanes sharing sl
 __device__ __forceinline__ Over seg_scan_over(Over v, int lane, int sl) {
-    { const Over o = dpp_over<0x111>(v); if (scan_src_ok<0>(lane, sl)) v = over(o, v); }
-    { const Over o = dpp_over<0x112>(v); if (scan_src_ok<1>(lane, sl)) v = over(o, v); }
-    { const Over o = dpp_over<0x114>(v); if (scan_src_ok<2>(lane, sl)) v = over(o, v); }
-    { const Over o = dpp_over<0x118>(v); if (scan_src_ok<3>(lane, sl)) v = over(o, v); }
-    { const Over o = dpp_over<0x142>(v); if (scan_src_ok<4>(lane, sl)) v = over(o, v); }
-    { const Over o = dpp_over<0x143>(v); if (scan_src_ok<5>(lane, sl)) v = over(o, v); }
+#define DR_OVER_STEP(CTRL, K)                                                                       \
+    {                                                                                               \
+        const Over o = dpp0_over<CTRL>(v);                                                          \
+        if (scan_src_ok<K>(lane, sl)) {                                                             \
+            const float T = 1.0f - o.a;                                                             \
+            fma_into(v.c0, T, o.c0); fma_into(v.c1, T, o.c1); fma_into(v.c2, T, o.c2); fma_into(v.a, T, o.a); \
+        }                                                                                           \
+    }
+    DR_OVER_STEP(0x111, 0) DR_OVER_STEP(0x112, 1) DR_OVER_STEP(0x114, 2) DR_OVER_STEP(0x118, 3)
+    DR_OVER_STEP(0x142, 4) DR_OVER_STEP(0x143, 5)
+#undef DR_OVER_STEP
     return v;
 }
 // segmented inclusive SUM of NV values (same segment convention)
@@ -366,13 +391,6 @@ __device__ __forceinline__ Over shfl_up1_over(const Over &v) {
     return r;
 }
 
-// adj * trilinear weight of each corner, order (x,y,z) = 000,100,010,110,001,101,011,111
-__device__ __forceinline__ void corner_weights(float fx, float fy, float fz, float adj, float (&w)[8]) {
-    const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;
-    const float a00 = gx * gy * adj, a10 = fx * gy * adj, a01 = gx * fy * adj, a11 = fx * fy * adj;
-    w[0] = a00 * gz; w[1] = a10 * gz; w[2] = a01 * gz; w[3] = a11 * gz;
-    w[4] = a00 * fz; w[5] = a10 * fz; w[6] = a01 * fz; w[7] = a11 * fz;
-}
 template <bool WIDE>
 __device__ __forceinline__ void scatter8(unsigned long long *dbox, int base, const float (&w)[8], const FixScale &f) {
     fix_add_t<WIDE>(dbox + base, w[0], f);
@@ -384,43 +402,66 @@ __device__ __forceinline__ void scatter8(unsigned long long *dbox, int base, con
     fix_add_t<WIDE>(dbox + base + BOX_SY + 1, w[6], f);
     fix_add_t<WIDE>(dbox + base + BOX_SX + BOX_SY + 1, w[7], f);
 }
+// the four voxels base + {0, SA, SB, SA+SB} receive c * w[0..3]
+template <bool WIDE, int SA, int SB>
+__device__ __forceinline__ void scatter4(unsigned long long *dbox, int base, float c, const float (&w)[4], const FixScale &f) {
+    fix_add_t<WIDE>(dbox + base, c * w[0], f);
+    fix_add_t<WIDE>(dbox + base + SA, c * w[1], f);
+    fix_add_t<WIDE>(dbox + base + SB, c * w[2], f);
+    fix_add_t<WIDE>(dbox + base + SA + SB, c * w[3], f);
+}
+// Adjoint of the two central-difference taps of one axis, reduced to coefficients along that axis over the box
+// planes l0-1 .. l0+2 (l0 = centre cell). The +delta tap sits in cell l0 or l0+1, the -delta tap in l0-1 or l0
+// (delta < 1 voxel, brick_path_supported); a tap in cell l spreads (1-f, f) over planes l, l+1. Times g.
+__device__ __forceinline__ void tap_line(int l0, int lp, int lm, float fp, float fm, float g, float (&cf)[4]) {
+    const bool in_p = lp == l0, in_m = lm == l0;
+    const float gp = 1.0f - fp, gm = 1.0f - fm;
+    cf[0] = in_m ? 0.0f : -gm * g;
+    cf[1] = ((in_p ? gp : 0.0f) - (in_m ? gm : fm)) * g;
+    cf[2] = ((in_p ? fp : gp) - (in_m ? fm : 0.0f)) * g;
+    cf[3] = in_p ? 0.0f : fp * g;
+}
 
-// d_volume scatter of one sample: in-cell normal taps folded into the centre's 8 corners, at most one tap per
-// axis leaves the centre cell while delta < 0.5 voxel (the rare second one under a wave-uniform branch).
+// d_volume scatter of one sample. Every tap is a product of per-axis weights, and the six normal taps differ from
+// the centre tap along ONE axis only, so their adjoint factors into a 4-plane line along that axis (tap_line)
+// times the centre's weights of the other two axes. Planes l0, l0+1 are the centre cell's own: everything that
+// lands there is summed into the centre's 8 corners first (8 LDS adds); what remains per axis is one outside
+// plane of 4 voxels (l0+2 or l0-1; both only when delta >= 0.5 voxel, i.e. dim > 1000: rare uniform branch).
+// 8 + 3*4 = 20 LDS adds per sample instead of 8 per tap.
 template <bool WIDE>
 __device__ __forceinline__ void scatter_sample(unsigned long long *dbox, const TapCoords &t, bool valid, int cbase_i,
                                                float I_bar, const float (&gq)[3], const FixScale &fs) {
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (valid) corner_weights(t.fx, t.fy, t.fz, I_bar, acc);
-    const int lcp[3] = {t.lxp, t.lyp, t.lzp}, lcm[3] = {t.lxm, t.lym, t.lzm}, lc0[3] = {t.lx, t.ly, t.lz};
-    const float fpv[3] = {t.fxp, t.fyp, t.fzp}, fmv[3] = {t.fxm, t.fym, t.fzm};
-    const int strd[3] = {BOX_SX, BOX_SY, 1};
+    const float X[2] = {1.0f - t.fx, t.fx}, Y[2] = {1.0f - t.fy, t.fy}, Z[2] = {1.0f - t.fz, t.fz};
+    const float YZ[4] = {Y[0] * Z[0], Y[1] * Z[0], Y[0] * Z[1], Y[1] * Z[1]};  // offsets {0, SY, 1, SY+1}
+    const float XZ[4] = {X[0] * Z[0], X[1] * Z[0], X[0] * Z[1], X[1] * Z[1]};  // offsets {0, SX, 1, SX+1}
+    const float XY[4] = {X[0] * Y[0], X[1] * Y[0], X[0] * Y[1], X[1] * Y[1]};  // offsets {0, SX, SY, SX+SY}
+    float cx[4], cy[4], cz[4];
+    tap_line(t.lx, t.lxp, t.lxm, t.fxp, t.fxm, gq[0], cx);
+    tap_line(t.ly, t.lyp, t.lym, t.fyp, t.fym, gq[1], cy);
+    tap_line(t.lz, t.lzp, t.lzm, t.fzp, t.fzm, gq[2], cz);
+    const float ax[2] = {fmaf(I_bar, X[0], cx[1]), fmaf(I_bar, X[1], cx[2])};
+    float acc[8];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const bool live_k = valid && gq[k] != 0.0f;
-        const bool in_p = lcp[k] == lc0[k], in_m = lcm[k] == lc0[k];
-        float fx = t.fx, fy = t.fy, fz = t.fz;
-        float wp[8], wm[8];
-        (k == 0 ? fx : k == 1 ? fy : fz) = fpv[k];
-        corner_weights(fx, fy, fz, gq[k], wp);    // +delta tap
-        (k == 0 ? fx : k == 1 ? fy : fz) = fmv[k];
-        corner_weights(fx, fy, fz, -gq[k], wm);   // -delta tap
-        const bool out_p = live_k && !in_p, out_m = live_k && !in_m;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) acc[q] += ((live_k && in_p) ? wp[q] : 0.0f) + ((live_k && in_m) ? wm[q] : 0.0f);
-        if (out_p || out_m) {  // one scatter serves whichever tap left the centre cell
-            float wo[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) wo[q] = out_p ? wp[q] : wm[q];
-            scatter8<WIDE>(dbox, cbase_i + ((out_p ? lcp[k] : lcm[k]) - lc0[k]) * strd[k], wo, fs);
-        }
-        if (__any(out_p && out_m)) {  // both left it: only when delta >= 0.5 voxel (dim > 1000)
-            if (out_p && out_m) scatter8<WIDE>(dbox, cbase_i + (lcm[k] - lc0[k]) * strd[k], wm, fs);
-        }
+    for (int q = 0; q < 8; ++q) {
+        const int ix = q & 1, iy = (q >> 1) & 1, iz = q >> 2;
+        acc[q] = fmaf(ax[ix], YZ[iy + 2 * iz], fmaf(cy[1 + iy], XZ[ix + 2 * iz], cz[1 + iz] * XY[ix + 2 * iy]));
     }
-    // centre corners (in-cell taps folded in). Lanes sharing a cell do collide here (~8 cycles per duplicate)
-    // but the LDS pipe has headroom while VALU does not: a cross-lane run reduction cost more than it saved.
     if (valid) scatter8<WIDE>(dbox, cbase_i, acc, fs);
+    {   // x: outside plane l0+2 (coefficient cx[3]) or l0-1 (cx[0])
+        const bool hi = cx[3] != 0.0f, lo = cx[0] != 0.0f;
+        if (valid && (hi || lo)) scatter4<WIDE, BOX_SY, 1>(dbox, cbase_i + (hi ? 2 * BOX_SX : -BOX_SX), hi ? cx[3] : cx[0], YZ, fs);
+        if (__any(valid && hi && lo)) { if (valid && hi && lo) scatter4<WIDE, BOX_SY, 1>(dbox, cbase_i - BOX_SX, cx[0], YZ, fs); }
+    }
+    {   // y
+        const bool hi = cy[3] != 0.0f, lo = cy[0] != 0.0f;
+        if (valid && (hi || lo)) scatter4<WIDE, BOX_SX, 1>(dbox, cbase_i + (hi ? 2 * BOX_SY : -BOX_SY), hi ? cy[3] : cy[0], XZ, fs);
+        if (__any(valid && hi && lo)) { if (valid && hi && lo) scatter4<WIDE, BOX_SX, 1>(dbox, cbase_i - BOX_SY, cy[0], XZ, fs); }
+    }
+    {   // z
+        const bool hi = cz[3] != 0.0f, lo = cz[0] != 0.0f;
+        if (valid && (hi || lo)) scatter4<WIDE, BOX_SX, BOX_SY>(dbox, cbase_i + (hi ? 2 : -1), hi ? cz[3] : cz[0], XY, fs);
+        if (__any(valid && hi && lo)) { if (valid && hi && lo) scatter4<WIDE, BOX_SX, BOX_SY>(dbox, cbase_i - 1, cz[0], XY, fs); }
+    }
 }
 
 // ALPHA (forward only): the alpha pre-pass -- centre tap + TF only, the partial of a segment is its accumulated alpha.
@@ -482,8 +523,6 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : 4) vo
             const int sl = max(lane - (f - eoff), 0);  // first lane of this lane's segment within the chunk
             const float4 r0 = L.ray0[e], r1 = L.ray1[e];
             const int s = f + L.s_rel[e];
-            RayGeom rg;
-            rg.t0 = r0.x; rg.exit_ = r0.y; rg.n = (int)r0.z + 1; rg.vx = r1.x; rg.vy = r1.y; rg.vz = r1.z;
             const f3 vd = make_f3(r1.x, r1.y, r1.z);
             if (ALPHA) {
                 // alpha pre-pass: position, centre cell, one tap, TF -> transmittance; nothing else
@@ -492,9 +531,10 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : 4) vo
                 float fx = 0.f, fy = 0.f, fz = 0.f;
                 bool va = act;
                 if (va) {
-                    sample_pos(rg, cam.x, cam.y, cam.z, s, sa.px, sa.py, sa.pz);
+                    sample_pos_rcp(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, cam.x, cam.y, cam.z, s, sa.px, sa.py, sa.pz);
                     axis_coord(sa.px, vol.scx, x0, fx); axis_coord(sa.py, vol.scy, y0, fy); axis_coord(sa.pz, vol.scz, z0, fz);
-                    va = x0 / BRK == c.bx && y0 / BRK == c.by && z0 / BRK == c.bz;
+                    va = (unsigned)(x0 - c.ox - 1) < (unsigned)BRK && (unsigned)(y0 - c.oy - 1) < (unsigned)BRK &&
+                         (unsigned)(z0 - c.oz - 1) < (unsigned)BRK;
                 }
                 float Tl = 1.0f;
                 if (va) {
@@ -525,7 +565,11 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : 4) vo
                 continue;
             }
             Sample sm; TapCoords t;
-            bool valid = act && sample_coords(vol, c, rg, cam, s, sm, t);
+            bool valid = false;
+            if (act) {
+                sample_pos_rcp(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, cam.x, cam.y, cam.z, s, sm.px, sm.py, sm.pz);
+                valid = sample_coords_at(vol, c, sm, t);
+            }
             float dx = 0.f, dy = 0.f, dz = 0.f;
             Over el = {0.f, 0.f, 0.f, 0.f};
             bool shaded = false;
@@ -579,9 +623,10 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : 4) vo
                 }
             } else {
                 SampleAdj ad;
-                ad.r_bar = ad.g_bar = ad.b_bar = ad.a_bar = 0.f; ad.gx = ad.gy = ad.gz = 0.f;
+                ad.r_bar = ad.g_bar = ad.b_bar = ad.a_bar = 0.f; ad.gx = ad.gy = ad.gz = 0.f; ad.Lop = 0.f;
+                float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (valid) {
-                    float4 pre, go, of;
+                    float4 pre, of;
                     if (BWD_TABLES_GLOBAL) {  // lanes of a chunk share a few rays: these are broadcast-like cached loads
                         const int plq = __float_as_int(r1.w);
                         pre = P.seg_rgba[seg_base + plq];
@@ -603,21 +648,24 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : 4) vo
                 if (WANT_TF) {
 #endif
                     // neighbouring lanes are consecutive samples of a ray: long runs fall between the same two
-                    // texels. Sum each run across lanes (DPP) and let its last lane do the eight LDS adds.
+                    // texels. Sum each run across lanes (DPP) and let its last lane do the eight LDS adds. Runs stop
+                    // at segment boundaries, so the upstream colour gradient go.xyz is constant over a run and
+                    // (r,g,b)_bar = (L*op*T) * go.xyz is applied to the run total: 4 scanned values, not 8.
                     const int key = valid ? sm.lo : -1 - lane;
                     const int key_prev = wave_up1(key, key);
-                    const int rs = scan_max((lane == 0 || key != key_prev) ? lane : 0, lane);
+                    const bool run_start = lane == 0 || key != key_prev || lane == sl;
+                    const int rs = scan_max(run_start ? lane : 0, lane);
                     const float w0 = 1.0f - sm.fr, w1 = sm.fr;
-                    float tv[8] = {w0 * ad.r_bar, w0 * ad.g_bar, w0 * ad.b_bar, w0 * ad.a_bar,
-                                   w1 * ad.r_bar, w1 * ad.g_bar, w1 * ad.b_bar, w1 * ad.a_bar};
-                    seg_scan_sum<8>(tv, lane, rs);
+                    float tv[4] = {w0 * ad.Lop, w1 * ad.Lop, w0 * ad.a_bar, w1 * ad.a_bar};
+                    seg_scan_sum<4>(tv, lane, rs);
                     const int key_next = wave_down1(key, key);
-                    if (valid && (lane == 63 || key_next != key)) {  // run totals may be large: exact wide adds
+                    const int sl_next = wave_down1(sl, -1);
+                    if (valid && (lane == 63 || key_next != key || sl_next != sl)) {  // run totals may be large: exact wide adds
                         unsigned long long *d0 = L.dtf + 4 * sm.lo, *d1 = L.dtf + 4 * sm.hi;
-                        fix_add(d0 + 0, fix_clamp(tv[0], fs), fs); fix_add(d0 + 1, fix_clamp(tv[1], fs), fs);
-                        fix_add(d0 + 2, fix_clamp(tv[2], fs), fs); fix_add(d0 + 3, fix_clamp(tv[3], fs), fs);
-                        fix_add(d1 + 0, fix_clamp(tv[4], fs), fs); fix_add(d1 + 1, fix_clamp(tv[5], fs), fs);
-                        fix_add(d1 + 2, fix_clamp(tv[6], fs), fs); fix_add(d1 + 3, fix_clamp(tv[7], fs), fs);
+                        fix_add(d0 + 0, fix_clamp(tv[0] * go.x, fs), fs); fix_add(d0 + 1, fix_clamp(tv[0] * go.y, fs), fs);
+                        fix_add(d0 + 2, fix_clamp(tv[0] * go.z, fs), fs); fix_add(d0 + 3, fix_clamp(tv[2], fs), fs);
+                        fix_add(d1 + 0, fix_clamp(tv[1] * go.x, fs), fs); fix_add(d1 + 1, fix_clamp(tv[1] * go.y, fs), fs);
+                        fix_add(d1 + 2, fix_clamp(tv[1] * go.z, fs), fs); fix_add(d1 + 3, fix_clamp(tv[3], fs), fs);
                     }
                 }
 #ifdef DR_ABL_NOSCATTER

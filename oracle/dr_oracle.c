@@ -63,3 +63,33 @@ void dro_tf_momentum_step_f32(float *tf, const float *g, float *mom, int n, floa
         tf[i] = fmaxf(tf[i] - m, 0.0f);
     }
 }
+
+/* Checks the identity the fast kernels rely on for sample positions (VR.py:279-280, s/(n-1)): with y = RN(1/d),
+ * q0 = RN(s*y), r = fma(-q0, d, s), RN(q0 + r*y) equals the IEEE quotient s/d. Exhaustive over d <= dmax
+ * (all 0 <= s <= d+3), plus `nrandom` pseudo-random pairs with d < 8e6. Returns the number of mismatches. */
+long dro_check_rcp_division(int dmax, long nrandom) {
+    long bad = 0;
+    for (int d = 1; d <= dmax; ++d) {
+        const float df = (float)d, y = 1.0f / df;
+        for (int s = 0; s <= d + 3; ++s) {
+            const float sf = (float)s;
+            float q = sf * y;
+            const float r = fmaf(-q, df, sf);
+            q = fmaf(r, y, q);
+            bad += (q != sf / df);
+        }
+    }
+    uint64_t st = 0x9E3779B97F4A7C15ull;
+    for (long k = 0; k < nrandom; ++k) {
+        st = st * 6364136223846793005ull + 1442695040888963407ull;
+        const int d = 1 + (int)((st >> 33) % 8000000u);
+        st = st * 6364136223846793005ull + 1442695040888963407ull;
+        const int s = (int)((st >> 33) % (uint64_t)(d + 1));
+        const float df = (float)d, y = 1.0f / df, sf = (float)s;
+        float q = sf * y;
+        const float r = fmaf(-q, df, sf);
+        q = fmaf(r, y, q);
+        bad += (q != sf / df);
+    }
+    return bad;
+}

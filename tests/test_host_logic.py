@@ -66,3 +66,13 @@ def test_tex_from_pts_is_piecewise_linear():
     assert t.shape == (4, 5)
     assert t[0].tolist() == pytest.approx([0, 0.5, 1, 0.5, 0]) and t[3].tolist() == pytest.approx([0, 0.5, 1, 0.5, 0])
     assert t[1].tolist() == pytest.approx([0, 0, 0, 0.5, 1])
+
+
+def test_reciprocal_division_identity(oracle):
+    """The fast kernels compute s/(n-1) from a per-ray reciprocal with one fma correction (dr_device.h
+    sample_pos_rcp); that must be the IEEE quotient bit for bit, or sample positions would drift from VR.py:279."""
+    import ctypes
+    fn = oracle.lib().dro_check_rcp_division
+    fn.restype = ctypes.c_long
+    fn.argtypes = [ctypes.c_int, ctypes.c_long]
+    assert fn(3072, 20_000_000) == 0

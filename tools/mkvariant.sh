@@ -1,0 +1,16 @@
+#!/bin/bash
+# Build a variant of libdifferender_hip.so into ab_libs/<name>.so with extra compiler flags (for tools/ab.sh).
+#   usage: tools/mkvariant.sh name [extra hipcc flags...]
+set -e
+name=$1; shift
+src=differender_amd/csrc; out=ab_libs/obj_$name
+mkdir -p $out
+COMMON="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -munsafe-fp-atomics -ffp-contract=off -fno-slp-vectorize"
+pids=()
+for f in capi ray_setup march_baseline march_brick march_flat epilogue; do
+  /opt/rocm/bin/hipcc $COMMON "$@" -c $src/$f.hip -o $out/$f.o & pids+=($!)
+done
+for p in "${pids[@]}"; do wait $p; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ab_libs/$name.so $out/*.o
+rm -rf $out
+echo built ab_libs/$name.so
