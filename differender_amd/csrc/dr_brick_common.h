@@ -23,6 +23,7 @@ struct BrickParams {
     unsigned int *stats; // [0] rays repaired by the count check, [1] bits of max|grad_out| (backward),
                          // [2 + view] 1 if some ray of the view may reach alpha >= 0.99 (alpha pre-pass ran)
     int use_live;        // forward: ws_steps holds each ray's exact live sample count (from the alpha pre-pass)
+    const struct BrickCtxRec *ctx;  // [view][brick]: brick geometry + pixel rectangle, filled once per forward call
     float *out; int32_t *steps;
     const float *grad_out, *out_fwd;
     GradView dvol; int64_t dvol_vs;
@@ -35,6 +36,22 @@ struct BrickCtx {
     float lo[3], hi[3];           // world AABB of the brick's cells, with slack
     int i0, i1, j0, j1;           // candidate pixel rectangle (inclusive); empty if i0 > i1
 };
+
+// BrickCtx as stored in the workspace (64 B): every workgroup of F1 / P1 / B1 reads its record with scalar loads
+// instead of re-deriving it (8 corner projections, ~700 VALU per wave).
+struct BrickCtxRec {
+    int bx, by, bz, layer;
+    float lo[3]; int i0;
+    float hi[3]; int i1;
+    int j0, j1, pad0, pad1;
+};
+__device__ __forceinline__ void brick_ctx_load(const BrickCtxRec *rec, BrickCtx &c) {
+    const BrickCtxRec r = *rec;
+    c.bx = r.bx; c.by = r.by; c.bz = r.bz; c.layer = r.layer;
+    c.ox = c.bx * BRK - 1; c.oy = c.by * BRK - 1; c.oz = c.bz * BRK - 1;
+    for (int k = 0; k < 3; ++k) { c.lo[k] = r.lo[k]; c.hi[k] = r.hi[k]; }
+    c.i0 = r.i0; c.i1 = r.i1; c.j0 = r.j0; c.j1 = r.j1;
+}
 
 __device__ __forceinline__ f3 cross3b(f3 a, f3 b) {
     return make_f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
@@ -80,6 +97,21 @@ __device__ __forceinline__ void brick_setup(const BrickParams<VT> &P, int b, f3 
     pxmax = fminf(pxmax, (float)P.W + 2.0f); pymax = fminf(pymax, (float)P.H + 2.0f);
     c.i0 = max(0, (int)floorf(pxmin) - 1); c.i1 = min(P.W - 1, (int)ceilf(pxmax) + 1);
     c.j0 = max(0, (int)floorf(pymin) - 1); c.j1 = min(P.H - 1, (int)ceilf(pymax) + 1);
+}
+
+// One thread per (brick, view): brick_setup once, for all passes of this forward/backward pair.
+template <typename VT>
+static __global__ __launch_bounds__(256) void brick_ctx_kernel(BrickParams<VT> P, BrickCtxRec *out, int nbricks) {
+    const int b = blockIdx.x * 256 + threadIdx.x, view = blockIdx.y;
+    if (b >= nbricks) return;
+    const f3 cam = make_f3(P.cam[3 * view], P.cam[3 * view + 1], P.cam[3 * view + 2]);
+    BrickCtx c;
+    brick_setup(P, b, cam, c);
+    BrickCtxRec r;
+    r.bx = c.bx; r.by = c.by; r.bz = c.bz; r.layer = c.layer;
+    for (int k = 0; k < 3; ++k) { r.lo[k] = c.lo[k]; r.hi[k] = c.hi[k]; }
+    r.i0 = c.i0; r.i1 = c.i1; r.j0 = c.j0; r.j1 = c.j1; r.pad0 = r.pad1 = 0;
+    out[(size_t)view * nbricks + b] = r;
 }
 
 // Conservative sample-index range [s0, s1) of ray p inside the brick (exact membership is decided per
@@ -315,7 +347,11 @@ __device__ __forceinline__ void fix_add_wide(unsigned long long *p, float x, con
     const float hf = floorf(t);
     const unsigned int lo = (unsigned int)((t - hf) * 4294967296.0f);  // fraction in [0,1): exact product
     const unsigned long long v = ((unsigned long long)(unsigned int)(int)hf << 32) | lo;
+#ifdef DR_ABL_NOATOMIC
+    asm volatile("" :: "v"(p), "v"(v));
+#else
     atomicAdd(p, v);  // ds_add_u64
+#endif
 }
 // Common case: |x * 2^shift| < 2^31 -- one multiply, one float->int conversion (exact to 2^-shift), a sign
 // extension. Callers test the magnitude once per sample (fix_fits) and pick WIDE under a wave-uniform branch.
@@ -324,7 +360,11 @@ template <bool WIDE>
 __device__ __forceinline__ void fix_add_t(unsigned long long *p, float x, const FixScale &f) {
     if (WIDE) { fix_add_wide(p, x, f); return; }
     const int q = (int)(x * f.lo);  // truncation: <= 1 unit of 2^-shift (~4e-9 max|grad_out|) per add
+#ifdef DR_ABL_NOATOMIC
+    asm volatile("" :: "v"(p), "v"((unsigned long long)(long long)q));
+#else
     atomicAdd(p, (unsigned long long)(long long)q);  // ds_add_u64
+#endif
 }
 __device__ __forceinline__ void fix_add(unsigned long long *p, float x, const FixScale &f) { fix_add_wide(p, x, f); }
 __device__ __forceinline__ float fix_to_float(unsigned long long v, const FixScale &f) {
@@ -378,10 +418,12 @@ static __global__ __launch_bounds__(256) void absmax_kernel(const float *x, size
 // ------------------------------------------------------------------------------------------------ host
 struct Workspace {
     float4 *seg_rgba; int32_t *seg_cnt; int32_t *ws_steps; uint8_t *rayflag; unsigned int *stats;
+    BrickCtxRec *ctx;
     size_t cnt_bytes;
 };
-static inline size_t ws_layout(void *base, int n_views, int NP, int NL, Workspace *w) {
+static inline size_t ws_layout(void *base, int n_views, int NP, const BrickGrid &g, Workspace *w) {
     size_t o = 0;
+    const int NL = g.NL;
     const size_t nseg = (size_t)n_views * NL * NP;
     unsigned char *b = static_cast<unsigned char *>(base);
     if (w) w->stats = reinterpret_cast<unsigned int *>(b + o);
@@ -394,6 +436,8 @@ static inline size_t ws_layout(void *base, int n_views, int NP, int NL, Workspac
     o += align16((size_t)n_views * NP * 4);
     if (w) w->rayflag = reinterpret_cast<uint8_t *>(b + o);
     o += align16((size_t)n_views * NP);
+    if (w) w->ctx = reinterpret_cast<BrickCtxRec *>(b + o);
+    o += (size_t)n_views * g.NBx * g.NBy * g.NBz * sizeof(BrickCtxRec);
     return o;
 }
 
@@ -416,7 +460,7 @@ static inline BrickParams<VT> make_brick_params(const MarchArgs &a, const Worksp
     P.near_ = (float)a.near_plane; P.near_h = (float)near_h; P.near_w = (float)(near_h * ((double)a.W / (double)a.H));
     P.g = make_brick_grid(a.VX, a.VY, a.VZ);
     P.seg_rgba = w.seg_rgba; P.seg_cnt = w.seg_cnt; P.rayflag = w.rayflag; P.stats = w.stats; P.ws_steps = w.ws_steps;
-    P.use_live = a.use_live;
+    P.use_live = a.use_live; P.ctx = w.ctx;
     P.out = a.out; P.steps = a.steps;
     P.grad_out = a.grad_out; P.out_fwd = a.out_fwd;
     P.dvol.p = a.d_vol; P.dvol.sx = a.dsx; P.dvol.sy = a.dsy; P.dvol.sz = a.dsz; P.dvol_vs = a.dvol_vs;

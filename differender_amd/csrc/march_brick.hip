@@ -381,7 +381,7 @@ bool brick_path_supported(int VX, int VY, int VZ, int R) {
 
 size_t brick_workspace_bytes(int n_views, int W, int H, int VX, int VY, int VZ) {
     const BrickGrid g = make_brick_grid(VX, VY, VZ);
-    return ws_layout(nullptr, n_views, W * H, g.NL, nullptr);
+    return ws_layout(nullptr, n_views, W * H, g, nullptr);
 }
 
 template <typename VT>
@@ -389,7 +389,7 @@ static int brick_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     const BrickGrid g = make_brick_grid(a.VX, a.VY, a.VZ);
     const int NP = a.W * a.H;
     Workspace w;
-    const size_t need = ws_layout(a.workspace, a.n_views, NP, g.NL, &w);
+    const size_t need = ws_layout(a.workspace, a.n_views, NP, g, &w);
     if (!a.workspace || a.workspace_bytes < need) return DR_EINVAL;
     BrickParams<VT> P = make_brick_params<VT>(a, w);
     hipError_t e = hipMemsetAsync(w.stats, 0, 256, stream);
@@ -415,7 +415,7 @@ static int ray_compose_dispatch(const MarchArgs &a, hipStream_t stream) {
     const BrickGrid g = make_brick_grid(a.VX, a.VY, a.VZ);
     const int NP = a.W * a.H;
     Workspace w;
-    ws_layout(a.workspace, a.n_views, NP, g.NL, &w);
+    ws_layout(a.workspace, a.n_views, NP, g, &w);
     BrickParams<VT> P = make_brick_params<VT>(a, w);
     const dim3 grid2((NP + 255) / 256, a.n_views);
     const size_t lds2 = (size_t)a.R * 16;
@@ -435,7 +435,7 @@ static int ray_alpha_dispatch(const MarchArgs &a, hipStream_t stream) {
     const BrickGrid g = make_brick_grid(a.VX, a.VY, a.VZ);
     const int NP = a.W * a.H;
     Workspace w;
-    ws_layout(a.workspace, a.n_views, NP, g.NL, &w);
+    ws_layout(a.workspace, a.n_views, NP, g, &w);
     BrickParams<VT> P = make_brick_params<VT>(a, w);
     const dim3 grid2((NP + 255) / 256, a.n_views);
     const size_t lds2 = (size_t)a.R * 16;
@@ -459,7 +459,7 @@ static int brick_bwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     const BrickGrid g = make_brick_grid(a.VX, a.VY, a.VZ);
     const int NP = a.W * a.H;
     Workspace w;
-    const size_t need = ws_layout(a.workspace, a.n_views, NP, g.NL, &w);
+    const size_t need = ws_layout(a.workspace, a.n_views, NP, g, &w);
     if (!a.workspace || a.workspace_bytes < need) return DR_EINVAL;
     BrickParams<VT> P = make_brick_params<VT>(a, w);
     const bool wv = a.d_vol != nullptr, wt = a.d_tf != nullptr;

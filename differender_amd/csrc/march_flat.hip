@@ -36,6 +36,12 @@ constexpr int FNT_BWD = DR_FNT_BWD;     // (backward: 118 KB of LDS -> one workg
 #ifndef DR_BWD_TABLES_GLOBAL
 #define DR_BWD_TABLES_GLOBAL 1
 #endif
+#ifndef DR_RUN_REDUCE
+#define DR_RUN_REDUCE 0
+#endif
+#ifndef DR_BWD_REBUILD_TAPS
+#define DR_BWD_REBUILD_TAPS 0
+#endif
 constexpr bool BWD_TABLES_GLOBAL = DR_BWD_TABLES_GLOBAL != 0;  // per-ray backward inputs from global memory, not LDS
 constexpr int FEC_FWD = DR_FEC_FWD;      // ray segments listed per round (<= threads: one candidate per thread)
 constexpr int FEC_BWD = DR_FEC_BWD;      // (backward: the entry table also holds prefix / gradient / output)
@@ -446,7 +452,6 @@ __device__ __forceinline__ void scatter_sample(unsigned long long *dbox, const T
         const int ix = q & 1, iy = (q >> 1) & 1, iz = q >> 2;
         acc[q] = fmaf(ax[ix], YZ[iy + 2 * iz], fmaf(cy[1 + iy], XZ[ix + 2 * iz], cz[1 + iz] * XY[ix + 2 * iy]));
     }
-    if (valid) scatter8<WIDE>(dbox, cbase_i, acc, fs);
     {   // x: outside plane l0+2 (coefficient cx[3]) or l0-1 (cx[0])
         const bool hi = cx[3] != 0.0f, lo = cx[0] != 0.0f;
         if (valid && (hi || lo)) scatter4<WIDE, BOX_SY, 1>(dbox, cbase_i + (hi ? 2 * BOX_SX : -BOX_SX), hi ? cx[3] : cx[0], YZ, fs);
@@ -462,6 +467,35 @@ __device__ __forceinline__ void scatter_sample(unsigned long long *dbox, const T
         if (valid && (hi || lo)) scatter4<WIDE, BOX_SX, BOX_SY>(dbox, cbase_i + (hi ? 2 : -1), hi ? cz[3] : cz[0], XY, fs);
         if (__any(valid && hi && lo)) { if (valid && hi && lo) scatter4<WIDE, BOX_SX, BOX_SY>(dbox, cbase_i - 1, cz[0], XY, fs); }
     }
+    // Consecutive lanes are consecutive samples of a ray, ~3.5 per cell at sampling rate 1: their adds hit the same
+    // eight addresses, and the LDS serialises equal addresses (~7 cycles per duplicate, profiles/r01_microbench_*).
+    // Sum each run of lanes that share the cell first (runs are cut at 8-lane groups: three row_shr steps) and let
+    // the last lane of the run do the adds.
+    {
+        const int lane = threadIdx.x & 63, p = lane & 7;
+        const int ckey = valid ? cbase_i : -1 - lane;
+        const int kprev = __builtin_amdgcn_update_dpp(0, ckey, 0x111, 0xf, 0xf, true);  // row_shr:1
+        const unsigned long long starts = __ballot(p == 0 || ckey != kprev);
+        const unsigned int g = (unsigned int)(starts >> (lane & ~7)) & 0xffu;   // this 8-lane group's run starts
+        const int dist = p - (31 - __clz((int)(g & ((2u << p) - 1u))));        // lanes since the run start
+        const bool run_end = p == 7 || ((g >> (p + 1)) & 1u);
+#define DR_RUN_STEP(CTRL, D)                                                       \
+        {                                                                          \
+            const bool ok = dist >= D;                                             \
+            _Pragma("unroll") for (int q = 0; q < 8; ++q) {                        \
+                const float o = dpp0_f<CTRL>(acc[q]);                              \
+                acc[q] = ok ? acc[q] + o : acc[q];                                 \
+            }                                                                      \
+        }
+#if DR_RUN_REDUCE
+        DR_RUN_STEP(0x111, 1) DR_RUN_STEP(0x112, 2) DR_RUN_STEP(0x114, 4)
+        if (valid && run_end) scatter8<WIDE>(dbox, cbase_i, acc, fs);
+#else
+        (void)dist; (void)run_end;
+        if (valid) scatter8<WIDE>(dbox, cbase_i, acc, fs);
+#endif
+#undef DR_RUN_STEP
+    }
 }
 
 // ALPHA (forward only): the alpha pre-pass -- centre tap + TF only, the partial of a segment is its accumulated alpha.
@@ -475,7 +509,7 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : 4) vo
     const int view = blockIdx.y;
     const f3 cam = make_f3(P.cam[3 * view], P.cam[3 * view + 1], P.cam[3 * view + 2]);
     BrickCtx c;
-    brick_setup(P, blockIdx.x, cam, c);
+    brick_ctx_load(P.ctx + (size_t)view * gridDim.x + blockIdx.x, c);  // uniform address: scalar loads
     if (c.i0 > c.i1 || c.j0 > c.j1) return;  // uniform: the brick projects outside the image
 
     FlatLds L = flat_carve<BWD, WANT_VOL, WANT_TF>(smem, P.R);
@@ -654,18 +688,37 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : 4) vo
                     const int key = valid ? sm.lo : -1 - lane;
                     const int key_prev = wave_up1(key, key);
                     const bool run_start = lane == 0 || key != key_prev || lane == sl;
-                    const int rs = scan_max(run_start ? lane : 0, lane);
+                    // first lane of this lane's run = highest run-start bit at or below the lane (lane 0 always starts one)
+                    const unsigned long long starts = __ballot(run_start);
+                    const unsigned long long upto = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+                    const int rs = 63 - __clzll((long long)(starts & upto));
                     const float w0 = 1.0f - sm.fr, w1 = sm.fr;
                     float tv[4] = {w0 * ad.Lop, w1 * ad.Lop, w0 * ad.a_bar, w1 * ad.a_bar};
                     seg_scan_sum<4>(tv, lane, rs);
-                    const int key_next = wave_down1(key, key);
-                    const int sl_next = wave_down1(sl, -1);
-                    if (valid && (lane == 63 || key_next != key || sl_next != sl)) {  // run totals may be large: exact wide adds
+                    const bool run_end = lane == 63 || ((starts >> (lane + 1)) & 1ull);
+                    const bool emit = valid && run_end;
+                    const float v8[8] = {tv[0] * go.x, tv[0] * go.y, tv[0] * go.z, tv[2],
+                                         tv[1] * go.x, tv[1] * go.y, tv[1] * go.z, tv[3]};
+                    // sum of magnitudes (>= the largest one; full-rate adds, and a NaN propagates into the test)
+                    const float vmax = ((fabsf(v8[0]) + fabsf(v8[1])) + (fabsf(v8[2]) + fabsf(v8[3]))) +
+                                       ((fabsf(v8[4]) + fabsf(v8[5])) + (fabsf(v8[6]) + fabsf(v8[7])));
+                    // run totals normally fit the 32-bit addend; NaN or a huge total takes the exact clamped path
+                    if (__any(emit && !fix_fits(vmax, fs))) {
+                        if (emit) {
+                            unsigned long long *d0 = L.dtf + 4 * sm.lo, *d1 = L.dtf + 4 * sm.hi;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                fix_add(d0 + q, fix_clamp(v8[q], fs), fs);
+                                fix_add(d1 + q, fix_clamp(v8[4 + q], fs), fs);
+                            }
+                        }
+                    } else if (emit) {
                         unsigned long long *d0 = L.dtf + 4 * sm.lo, *d1 = L.dtf + 4 * sm.hi;
-                        fix_add(d0 + 0, fix_clamp(tv[0] * go.x, fs), fs); fix_add(d0 + 1, fix_clamp(tv[0] * go.y, fs), fs);
-                        fix_add(d0 + 2, fix_clamp(tv[0] * go.z, fs), fs); fix_add(d0 + 3, fix_clamp(tv[2], fs), fs);
-                        fix_add(d1 + 0, fix_clamp(tv[1] * go.x, fs), fs); fix_add(d1 + 1, fix_clamp(tv[1] * go.y, fs), fs);
-                        fix_add(d1 + 2, fix_clamp(tv[1] * go.z, fs), fs); fix_add(d1 + 3, fix_clamp(tv[3], fs), fs);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            fix_add_t<false>(d0 + q, v8[q], fs);
+                            fix_add_t<false>(d1 + q, v8[4 + q], fs);
+                        }
                     }
                 }
 #ifdef DR_ABL_NOSCATTER
@@ -677,11 +730,13 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : 4) vo
                     // suffices unless some adjoint of the wave exceeds 2^31 / 2^shift (then: exact wide path).
                     // the 24 tap coordinates are cheap to rebuild from the position (45 VALU) and expensive to keep
                     // alive across shading and the adjoint (the kernel is register-bound: spills go to scratch)
+#if DR_BWD_REBUILD_TAPS
                     {
                         float qx = sm.px, qy = sm.py, qz = sm.pz;
                         asm volatile("" : "+v"(qx), "+v"(qy), "+v"(qz));
                         if (valid) tap_coords(vol, c, qx, qy, qz, t);
                     }
+#endif
                     const int cbase_i = valid ? (t.lx * BOX_SX + t.ly * BOX_SY + t.lz) : 0;
                     float I_bar = 0.f;
                     float gq[3] = {0.f, 0.f, 0.f};
@@ -689,7 +744,7 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : 4) vo
                         I_bar = fix_clamp(intensity_adjoint(sm, L.tf[sm.lo], L.tf[sm.hi], ad, P.tf_len), fs);
                         if (!sm.flat) { gq[0] = fix_clamp(ad.gx, fs); gq[1] = fix_clamp(ad.gy, fs); gq[2] = fix_clamp(ad.gz, fs); }
                     }
-                    const float bound = fabsf(I_bar) + 2.0f * (fabsf(gq[0]) + fabsf(gq[1]) + fabsf(gq[2]));
+                    const float bound = (DR_RUN_REDUCE ? 8.0f : 1.0f) * (fabsf(I_bar) + (fabsf(gq[0]) + fabsf(gq[1]) + fabsf(gq[2])));
                     if (__any(!fix_fits(bound, fs))) scatter_sample<true>(L.dbox, t, valid, cbase_i, I_bar, gq, fs);
                     else scatter_sample<false>(L.dbox, t, valid, cbase_i, I_bar, gq, fs);
                 }
@@ -742,7 +797,7 @@ static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     const BrickGrid g = make_brick_grid(a.VX, a.VY, a.VZ);
     const int NP = a.W * a.H;
     Workspace w;
-    const size_t need = ws_layout(a.workspace, a.n_views, NP, g.NL, &w);
+    const size_t need = ws_layout(a.workspace, a.n_views, NP, g, &w);
     if (!a.workspace || a.workspace_bytes < need) return DR_EINVAL;
     BrickParams<VT> P = make_brick_params<VT>(a, w);
     hipError_t e = hipMemsetAsync(w.stats, 0, 256, stream);
@@ -750,7 +805,9 @@ static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     e = hipMemsetAsync(w.seg_cnt, 0, w.cnt_bytes, stream);
     if (e != hipSuccess) return (int)e;
     const size_t lds = flat_lds_bytes<false>(a.R, false, false);
-    const dim3 grid1(g.NBx * g.NBy * g.NBz, a.n_views);
+    const int nbricks = g.NBx * g.NBy * g.NBz;
+    const dim3 grid1(nbricks, a.n_views);
+    hipLaunchKernelGGL(brick_ctx_kernel<VT>, dim3((nbricks + 255) / 256, a.n_views), dim3(256), 0, stream, P, w.ctx, nbricks);
     // Alpha pre-pass (early-termination culling): only if the TF can make some ray reach alpha >= 0.99 -- decided on
     // the device from max(alpha), the kernels of the pre-pass return at once otherwise.
     const bool prepass = a.n_views <= 48;
@@ -795,7 +852,7 @@ static int flat_bwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     const BrickGrid g = make_brick_grid(a.VX, a.VY, a.VZ);
     const int NP = a.W * a.H;
     Workspace w;
-    const size_t need = ws_layout(a.workspace, a.n_views, NP, g.NL, &w);
+    const size_t need = ws_layout(a.workspace, a.n_views, NP, g, &w);
     if (!a.workspace || a.workspace_bytes < need) return DR_EINVAL;
     BrickParams<VT> P = make_brick_params<VT>(a, w);
     const bool wv = a.d_vol != nullptr, wt = a.d_tf != nullptr;
