@@ -72,7 +72,8 @@ int dr_march_fwd(const void *vol, int vol_dtype, int VX, int VY, int VZ, int64_t
     a.fov_rad = fov_rad; a.near_plane = near_plane; a.workspace = workspace; a.workspace_bytes = workspace_bytes;
     if (variant != DR_VARIANT_BASELINE && workspace && brick_path_supported(VX, VY, VZ, R)) {
         if (workspace_bytes < brick_workspace_bytes(n_views, W, H, VX, VY, VZ)) return DR_EINVAL;
-        if (variant == DR_VARIANT_AUTO && flat_path_supported(VX, VY, VZ, R)) return launch_march_fwd_flat(a, (hipStream_t)stream);
+        if (variant == DR_VARIANT_AUTO && flat_path_supported(VX, VY, VZ, R) && flat_strides_ok(sx, sy, sz))
+            return launch_march_fwd_flat(a, (hipStream_t)stream);
         return launch_march_fwd_brick(a, (hipStream_t)stream);
     }
     return launch_march_fwd_baseline(a, (hipStream_t)stream);
@@ -100,7 +101,9 @@ int dr_march_bwd(const void *vol, int vol_dtype, int VX, int VY, int VZ, int64_t
     a.fov_rad = fov_rad; a.near_plane = near_plane; a.workspace = workspace; a.workspace_bytes = workspace_bytes;
     if (variant != DR_VARIANT_BASELINE && workspace && brick_path_supported(VX, VY, VZ, R)) {
         if (workspace_bytes < brick_workspace_bytes(n_views, W, H, VX, VY, VZ)) return DR_EINVAL;
-        if (variant == DR_VARIANT_AUTO && flat_path_supported(VX, VY, VZ, R)) return launch_march_bwd_flat(a, (hipStream_t)stream);
+        if (variant == DR_VARIANT_AUTO && flat_path_supported(VX, VY, VZ, R) && flat_strides_ok(sx, sy, sz) &&
+            (!d_vol || flat_strides_ok(dsx, dsy, dsz)))
+            return launch_march_bwd_flat(a, (hipStream_t)stream);
         return launch_march_bwd_brick(a, (hipStream_t)stream);
     }
     return launch_march_bwd_baseline(a, (hipStream_t)stream);

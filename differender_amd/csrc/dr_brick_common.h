@@ -124,7 +124,7 @@ __device__ __forceinline__ bool segment_range(const BrickCtx &c, f3 cam, f3 vd, 
         if (fabsf(d[k]) < 1e-12f) {
             if (o[k] < c.lo[k] || o[k] > c.hi[k]) return false;
         } else {
-            const float inv = 1.0f / d[k];
+            const float inv = __builtin_amdgcn_rcpf(d[k]);  // 1 ulp: the range is conservative (BRICK_EPS, +1 sample)
             const float t1 = (c.lo[k] - o[k]) * inv, t2 = (c.hi[k] - o[k]) * inv;
             ta = fmaxf(ta, fminf(t1, t2)); tb = fminf(tb, fmaxf(t1, t2));
         }

@@ -39,6 +39,7 @@ int launch_march_bwd_brick(const MarchArgs &a, hipStream_t stream);
 int launch_ray_compose(const MarchArgs &a, hipStream_t stream);      // F2, shared by the brick pipelines
 int launch_ray_alpha(const MarchArgs &a, hipStream_t stream);        // alpha pre-pass composition (exact termination)
 bool flat_path_supported(int VX, int VY, int VZ, int R);
+bool flat_strides_ok(int64_t sx, int64_t sy, int64_t sz);  // 32-bit in-box offsets
 int launch_march_fwd_flat(const MarchArgs &a, hipStream_t stream);   // one lane per sample
 int launch_march_bwd_flat(const MarchArgs &a, hipStream_t stream);
 

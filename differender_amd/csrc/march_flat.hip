@@ -97,44 +97,71 @@ __device__ __forceinline__ FlatLds flat_carve(unsigned char *smem, int R) {
     return L;
 }
 
-// Stage TF and the brick's voxel box in LDS. All global loads are issued first (into registers), the LDS stores
-// follow: one memory latency per brick instead of one per loop iteration. Reads walk the smallest-stride axis.
+// Walk of the brick's BOX^3 voxel box by a workgroup: 16 lanes per row of BOX (= 15) elements along the axis
+// with the smallest global stride ("a"), FNT/16 rows per pass; rows are numbered r = b + BOX*d over the other two
+// axes. All index arithmetic is 32-bit: the brick origin is folded into a uniform base pointer, in-box offsets
+// stay below 2^31 (strides are checked on the host, flat_strides_ok).
+struct BoxWalk {
+    int la, lb, ld;        // LDS strides of (a, b, d)
+    int ga, gb, gd;        // global strides of (a, b, d), elements
+    int oa, ob, od;        // global index of box element 0 along (a, b, d)
+    int Va, Vb, Vd;        // volume extents along (a, b, d)
+    long long base;        // element offset of box element (0,0,0) from the volume pointer (may be negative)
+};
+__device__ __forceinline__ BoxWalk make_box_walk(long long sx, long long sy, long long sz, int VX, int VY, int VZ,
+                                                 const BrickCtx &c) {
+    const int fast = (sx <= sy && sx <= sz) ? 0 : ((sy <= sz) ? 1 : 2);
+    BoxWalk w;
+    if (fast == 0) { w.la = BOX_SX; w.lb = BOX_SY; w.ld = 1; w.ga = (int)sx; w.gb = (int)sy; w.gd = (int)sz;
+                     w.oa = c.ox; w.ob = c.oy; w.od = c.oz; w.Va = VX; w.Vb = VY; w.Vd = VZ; }
+    else if (fast == 1) { w.la = BOX_SY; w.lb = BOX_SX; w.ld = 1; w.ga = (int)sy; w.gb = (int)sx; w.gd = (int)sz;
+                          w.oa = c.oy; w.ob = c.ox; w.od = c.oz; w.Va = VY; w.Vb = VX; w.Vd = VZ; }
+    else { w.la = 1; w.lb = BOX_SY; w.ld = BOX_SX; w.ga = (int)sz; w.gb = (int)sy; w.gd = (int)sx;
+           w.oa = c.oz; w.ob = c.oy; w.od = c.ox; w.Va = VZ; w.Vb = VY; w.Vd = VX; }
+    w.base = (long long)c.ox * sx + (long long)c.oy * sy + (long long)c.oz * sz;
+    return w;
+}
+// row r (0 .. BOX*BOX-1) -> (b, d): r / 15 == (r * 4370) >> 16 for r < 4000 (checked exhaustively)
+__device__ __forceinline__ void box_row(int r, int &b, int &d) { static_assert(BOX == 15, "magic divisor"); d = (r * 4370) >> 16; b = r - d * BOX; }
+
+// Stage TF and the brick's voxel box in LDS. BATCH: all global loads are issued first (into registers), the LDS
+// stores follow: one memory latency per brick instead of one per pass.
 template <typename VT, int FNT, bool BATCH>
 __device__ __forceinline__ void flat_load_tf_and_box(const BrickParams<VT> &P, const VolView<VT> &vol,
                                                      const BrickCtx &c, const float4 *tfg, FlatLds &L) {
-    constexpr int NLD = (BOX_VOX + FNT - 1) / FNT;
-    const int fast = (vol.sx <= vol.sy && vol.sx <= vol.sz) ? 0 : ((vol.sy <= vol.sz) ? 1 : 2);
-    if (!BATCH) {  // register-bound callers: load and store element by element
+    constexpr int RP = FNT / 16, NPASS = (BOX * BOX + RP - 1) / RP;
+    const BoxWalk w = make_box_walk(vol.sx, vol.sy, vol.sz, vol.VX, vol.VY, vol.VZ, c);
+    const VT *base = vol.p + w.base;
+    const int a = threadIdx.x & 15, row = threadIdx.x >> 4;
+    const bool a_ok = a < BOX && (unsigned)(w.oa + a) < (unsigned)w.Va;
+    const int a_lds = a * w.la, a_off = a * w.ga;
+    if (!BATCH) {  // register-bound callers: load and store pass by pass
         for (int k = threadIdx.x; k < P.R; k += FNT) L.tf[k] = tfg[k];
-        for (int idx = threadIdx.x; idx < BOX_VOX; idx += FNT) {
-            const int a = idx % BOX, b = (idx / BOX) % BOX, d = idx / (BOX * BOX);
-            int lx, ly, lz;
-            if (fast == 0) { lx = a; ly = b; lz = d; } else if (fast == 1) { ly = a; lx = b; lz = d; } else { lz = a; ly = b; lx = d; }
-            const int gx = c.ox + lx, gy = c.oy + ly, gz = c.oz + lz;
+        for (int r = row; r < BOX * BOX; r += RP) {
+            int b, d;
+            box_row(r, b, d);
             float v = 0.0f;
-            if (gx >= 0 && gx < vol.VX && gy >= 0 && gy < vol.VY && gz >= 0 && gz < vol.VZ)
-                v = ld_voxel(vol.p + gx * vol.sx + gy * vol.sy + gz * vol.sz);
-            L.box[lx * BOX_SX + ly * BOX_SY + lz] = v;
+            if (a_ok && (unsigned)(w.ob + b) < (unsigned)w.Vb && (unsigned)(w.od + d) < (unsigned)w.Vd)
+                v = ld_voxel(base + (a_off + b * w.gb + d * w.gd));
+            if (a < BOX) L.box[a_lds + b * w.lb + d * w.ld] = v;
         }
         return;
     }
-    float bv[NLD];
-    int ba[NLD];
+    float bv[NPASS];
+    int ba[NPASS];
 #pragma unroll
-    for (int k = 0; k < NLD; ++k) {
-        const int idx = threadIdx.x + k * FNT;
-        const int a = idx % BOX, b = (idx / BOX) % BOX, d = idx / (BOX * BOX);
-        int lx, ly, lz;
-        if (fast == 0) { lx = a; ly = b; lz = d; } else if (fast == 1) { ly = a; lx = b; lz = d; } else { lz = a; ly = b; lx = d; }
-        const int gx = c.ox + lx, gy = c.oy + ly, gz = c.oz + lz;
+    for (int k = 0; k < NPASS; ++k) {
+        const int r = row + k * RP;
+        int b, d;
+        box_row(r, b, d);
         bv[k] = 0.0f;
-        ba[k] = (idx < BOX_VOX) ? lx * BOX_SX + ly * BOX_SY + lz : -1;
-        if (idx < BOX_VOX && gx >= 0 && gx < vol.VX && gy >= 0 && gy < vol.VY && gz >= 0 && gz < vol.VZ)
-            bv[k] = ld_voxel(vol.p + gx * vol.sx + gy * vol.sy + gz * vol.sz);
+        ba[k] = (a < BOX && r < BOX * BOX) ? a_lds + b * w.lb + d * w.ld : -1;
+        if (a_ok && r < BOX * BOX && (unsigned)(w.ob + b) < (unsigned)w.Vb && (unsigned)(w.od + d) < (unsigned)w.Vd)
+            bv[k] = ld_voxel(base + (a_off + b * w.gb + d * w.gd));
     }
     for (int k = threadIdx.x; k < P.R; k += FNT) L.tf[k] = tfg[k];
 #pragma unroll
-    for (int k = 0; k < NLD; ++k)
+    for (int k = 0; k < NPASS; ++k)
         if (ba[k] >= 0) L.box[ba[k]] = bv[k];
 }
 
@@ -765,15 +792,16 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : 4) vo
     if (WANT_VOL) {
         GradView dv = P.dvol;
         dv.p += view * P.dvol_vs;
-        const int fast = (dv.sx <= dv.sy && dv.sx <= dv.sz) ? 0 : ((dv.sy <= dv.sz) ? 1 : 2);
-        for (int idx = threadIdx.x; idx < BOX_VOX; idx += FNT) {
-            const int a = idx % BOX, b = (idx / BOX) % BOX, d = idx / (BOX * BOX);
-            int lx, ly, lz;
-            if (fast == 0) { lx = a; ly = b; lz = d; } else if (fast == 1) { ly = a; lx = b; lz = d; } else { lz = a; ly = b; lx = d; }
-            const unsigned long long raw = L.dbox[lx * BOX_SX + ly * BOX_SY + lz];
-            if (raw != 0ull) {
-                const int gx = c.ox + lx, gy = c.oy + ly, gz = c.oz + lz;  // in range whenever raw != 0
-                unsafeAtomicAdd(dv.p + gx * dv.sx + gy * dv.sy + gz * dv.sz, fix_to_float(raw, fs));
+        const BoxWalk w = make_box_walk(dv.sx, dv.sy, dv.sz, vol.VX, vol.VY, vol.VZ, c);
+        float *base = dv.p + w.base;
+        const int a = threadIdx.x & 15, row = threadIdx.x >> 4;
+        if (a < BOX) {
+            for (int r = row; r < BOX * BOX; r += FNT / 16) {
+                int b, d;
+                box_row(r, b, d);
+                const unsigned long long raw = L.dbox[a * w.la + b * w.lb + d * w.ld];
+                if (raw != 0ull)  // in range whenever raw != 0
+                    unsafeAtomicAdd(base + (a * w.ga + b * w.gb + d * w.gd), fix_to_float(raw, fs));
             }
         }
     }
@@ -787,6 +815,11 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : 4) vo
 }
 
 // ------------------------------------------------------------------------------------------------ host
+// in-box element offsets are computed in 32 bits: 3 * (BOX-1) * max|stride| must stay below 2^31
+bool flat_strides_ok(int64_t sx, int64_t sy, int64_t sz) {
+    const int64_t lim = ((int64_t)1 << 31) / (3 * BOX);
+    return sx >= 0 && sy >= 0 && sz >= 0 && sx < lim && sy < lim && sz < lim;
+}
 bool flat_path_supported(int VX, int VY, int VZ, int R) {
     if (!brick_path_supported(VX, VY, VZ, R)) return false;
     return flat_lds_bytes<true>(R, true, true) <= 160 * 1024;
