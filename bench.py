@@ -133,21 +133,22 @@ def main():
     def step(k, timed):
         cam = cams_all[k]
         e, x, r, n = F.ray_setup(cam, (IMG, IMG), (N, N, N), sr)
-        if timed:
-            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a0.record()
+        # (warm-up steps run the very same host code, events included: their first use has a one-time host cost)
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a0.record()
         out, steps = F.march_fwd(vol, tf, cam, e, x, r, n, S, sr, variant=args.variant, workspace=ws)
+        a1.record()
         if timed:
-            a1.record(); ev["fwd"].append((a0, a1))
+            ev["fwd"].append((a0, a1))
         if want_bwd:
             _, grad_out = F.mse_loss_grad(out, target, loss=loss_acc)  # loss + d(loss)/d(out) in one pass
-            if timed:
-                b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                b0.record()
+            b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            b0.record()
             dv, dt = F.march_bwd(vol, tf, cam, e, x, r, n, S, sr, grad_out, out, want_vol=want_vol, want_tf=want_tf,
                                  variant=args.variant, workspace=ws)
+            b1.record()
             if timed:
-                b1.record(); ev["bwd"].append((b0, b1))
+                ev["bwd"].append((b0, b1))
             if world > 1:
                 # RCCL sum of the shared gradients on its own stream: it overlaps the next step's forward; the
                 # previous step's reduction is awaited first so at most one is in flight (and all before timing ends)
@@ -157,6 +158,8 @@ def main():
                 keep_alive[:] = [dv, dt]
         if timed:
             total_steps.add_(steps.sum())
+        else:
+            steps.sum()  # same launches as a timed step
 
     pending, keep_alive = [], []
 

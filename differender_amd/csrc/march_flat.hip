@@ -22,6 +22,9 @@ namespace dr {
 #ifndef DR_BWD_WAVES
 #define DR_BWD_WAVES 4
 #endif
+#ifndef DR_FWD_WAVES
+#define DR_FWD_WAVES 5
+#endif
 #ifndef DR_FNT_FWD
 #define DR_FNT_FWD 256
 #endif
@@ -527,7 +530,7 @@ __device__ __forceinline__ void scatter_sample(unsigned long long *dbox, const T
 
 // ALPHA (forward only): the alpha pre-pass -- centre tap + TF only, the partial of a segment is its accumulated alpha.
 template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, bool ALPHA = false>
-__global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : 4) void brick_flat_kernel(BrickParams<VT> P) {
+__global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FWD_WAVES) void brick_flat_kernel(BrickParams<VT> P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (ALPHA && P.stats[2 + blockIdx.y] == 0u) return;  // uniform: no ray of this view can terminate early
     constexpr int EC = BWD ? FEC_BWD : FEC_FWD;
