@@ -39,6 +39,9 @@ constexpr int FNT_BWD = DR_FNT_BWD;     // (backward: 118 KB of LDS -> one workg
 #ifndef DR_BWD_TABLES_GLOBAL
 #define DR_BWD_TABLES_GLOBAL 1
 #endif
+#ifndef DR_BWD_PREFETCH
+#define DR_BWD_PREFETCH 1
+#endif
 #ifndef DR_RUN_REDUCE
 #define DR_RUN_REDUCE 0
 #endif
@@ -588,6 +591,16 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
             const float4 r0 = L.ray0[e], r1 = L.ray1[e];
             const int s = f + L.s_rel[e];
             const f3 vd = make_f3(r1.x, r1.y, r1.z);
+#if DR_BWD_PREFETCH
+            // backward: the per-ray inputs of the adjoint are requested now and consumed ~800 issue cycles later
+            float4 pf_pre = make_float4(0.f, 0.f, 0.f, 0.f), pf_go = pf_pre, pf_of = pf_pre;
+            if (BWD && BWD_TABLES_GLOBAL && act) {
+                const int plq = __float_as_int(r1.w);
+                pf_pre = P.seg_rgba[seg_base + plq];
+                pf_go = reinterpret_cast<const float4 *>(P.grad_out)[(size_t)view * NP + plq];
+                pf_of = reinterpret_cast<const float4 *>(P.out_fwd)[(size_t)view * NP + plq];
+            }
+#endif
             if (ALPHA) {
                 // alpha pre-pass: position, centre cell, one tap, TF -> transmittance; nothing else
                 Sample sa;
@@ -691,6 +704,9 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
                 float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (valid) {
                     float4 pre, of;
+#if DR_BWD_PREFETCH
+                    if (BWD_TABLES_GLOBAL) { pre = pf_pre; go = pf_go; of = pf_of; } else
+#endif
                     if (BWD_TABLES_GLOBAL) {  // lanes of a chunk share a few rays: these are broadcast-like cached loads
                         const int plq = __float_as_int(r1.w);
                         pre = P.seg_rgba[seg_base + plq];

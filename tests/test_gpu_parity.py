@@ -434,3 +434,30 @@ def test_high_sampling_rate_with_termination(oracle, F, mode):
     assert same.mean() > 0.995
     assert np.abs(out - ref).max(-1)[same].max() <= FWD_TOL
     assert np.abs(out - ref).max() <= 2e-3
+
+
+def test_huge_strides_take_the_64bit_path(oracle, hiplib):
+    """The flat kernels address the brick box with 32-bit in-box offsets (flat_strides_ok); a volume view whose
+    strides exceed that (a slice of a much larger allocation) must still render and differentiate correctly."""
+    from differender_amd import functional as Fn
+    vol_h, tf_h, cam_h = scene(oracle, N=16, R=16, alpha=0.05)
+    WH = (24, 24)
+    big = 48_000_000                                     # elements between x-planes: 3 * 14 * big >= 2^31
+    store = torch.zeros(16 * big, dtype=torch.float32, device=dev())
+    vol_v = store.as_strided((16, 16, 16), (big, 16, 1))
+    vol_v.copy_(T(vol_h))
+    tf, cam = T(tf_h), T(np.atleast_2d(cam_h))
+    e, x, r, n = Fn.ray_setup(cam, WH, vol_v.shape, 1.0)
+    ws = Fn.alloc_workspace(1, WH, vol_v.shape, tf.shape[0], dev())
+    out_v, _ = Fn.march_fwd(vol_v, tf, cam, e, x, r, n, 4096, 1.0, workspace=ws)
+    g = torch.ones_like(out_v)
+    dv_v, dt_v = Fn.march_bwd(vol_v, tf, cam, e, x, r, n, 4096, 1.0, g, out_v, workspace=ws)
+    vol_c = T(vol_h)
+    ws2 = Fn.alloc_workspace(1, WH, vol_c.shape, tf.shape[0], dev())
+    out_c, _ = Fn.march_fwd(vol_c, tf, cam, e, x, r, n, 4096, 1.0, workspace=ws2)
+    dv_c, dt_c = Fn.march_bwd(vol_c, tf, cam, e, x, r, n, 4096, 1.0, g, out_c, workspace=ws2)
+    assert float((out_v - out_c).abs().max()) <= FWD_TOL
+    ok, err = grad_close(dv_v.cpu().numpy(), dv_c.cpu().numpy())
+    assert ok, err
+    ok, err = grad_close(dt_v.cpu().numpy(), dt_c.cpu().numpy())
+    assert ok, err
