@@ -39,6 +39,12 @@ constexpr int FNT_BWD = DR_FNT_BWD;     // (backward: 118 KB of LDS -> one workg
 #ifndef DR_BWD_TABLES_GLOBAL
 #define DR_BWD_TABLES_GLOBAL 1
 #endif
+#ifndef DR_FWD_K
+#define DR_FWD_K 2      // forward: samples per lane at sampling rates below 3
+#endif
+#ifndef DR_FWD_K_HI
+#define DR_FWD_K_HI 4   // ... and at 3 and above
+#endif
 #ifndef DR_BWD_PREFETCH
 #define DR_BWD_PREFETCH 1
 #endif
@@ -60,6 +66,7 @@ struct FlatLds {
     int *s_rel;     // first sample index of the segment minus its flat offset
     int *offs;      // [EC+1] exclusive prefix of the segment lengths (flat index of each segment's first sample)
     int *valid;     // in-brick samples of each segment (forward)
+    int *slen;      // forward: true length of the segment (its flat extent is padded to a multiple of FWD_K)
     int *live;      // backward: live sample count of the ray
     int *misc;
 };
@@ -71,7 +78,7 @@ __host__ __device__ constexpr size_t flat_fixed_bytes(bool want_vol) {
     size_t s = ((size_t)BOX_LDS * 4 + 15) / 16 * 16;
     if (BWD && want_vol) s += ((size_t)BOX_LDS * 8 + 15) / 16 * 16;
     s += (size_t)EC * 32 + ((BWD && !BWD_TABLES_GLOBAL) ? (size_t)EC * 48 : 0);
-    s += (size_t)EC * 4 + (((size_t)EC + 1) * 4 + 15) / 16 * 16 + (size_t)EC * 4 + (BWD ? (size_t)EC * 4 : 0) + 128;
+    s += (size_t)EC * 4 + (((size_t)EC + 1) * 4 + 15) / 16 * 16 + (size_t)EC * 4 + (size_t)EC * 4 + 128;  // (live | slen)
     return s;
 }
 template <bool BWD>
@@ -96,7 +103,9 @@ __device__ __forceinline__ FlatLds flat_carve(unsigned char *smem, int R) {
     L.s_rel = reinterpret_cast<int *>(smem + o); o += (size_t)EC * 4;
     L.offs = reinterpret_cast<int *>(smem + o); o += align16((EC + 1) * 4);
     L.valid = reinterpret_cast<int *>(smem + o); o += (size_t)EC * 4;
+    L.slen = nullptr;
     if (BWD) { L.live = reinterpret_cast<int *>(smem + o); o += (size_t)EC * 4; }
+    else { L.slen = reinterpret_cast<int *>(smem + o); o += (size_t)EC * 4; }
     L.misc = reinterpret_cast<int *>(smem + o); o += 128;  // 32 ints: [1] M, [4 + wave] per-wave entry counts
     L.tf = reinterpret_cast<float4 *>(smem + o); o += (size_t)R * 16;
     if (BWD && WANT_TF) L.dtf = reinterpret_cast<unsigned long long *>(smem + o);
@@ -205,7 +214,7 @@ __device__ __forceinline__ void cand_load(const BrickParams<VT> &P, const BrickC
 }
 
 // List the ray segments of the round's candidates and their flat offsets. Returns (nE, M).
-template <typename VT, int MODE, bool BWD, int FNT, bool ALPHA = false>
+template <typename VT, int MODE, bool BWD, int FNT, bool ALPHA = false, int KS = 1>
 __device__ __forceinline__ void flat_build_entries(const BrickParams<VT> &P, const BrickCtx &c, f3 cam, int view,
                                                    const CandData &d, size_t seg_base, FlatLds &L, int &nE, int &M) {
     constexpr int EC = BWD ? FEC_BWD : FEC_FWD;
@@ -252,7 +261,8 @@ __device__ __forceinline__ void flat_build_entries(const BrickParams<VT> &P, con
         L.ray0[slot] = make_float4(t0, exit_, nm1, 1.0f / nm1);  // n >= 2 (ray_is_regular)
         L.ray1[slot] = make_float4(vd.x, vd.y, vd.z, __int_as_float(pl));
         L.s_rel[slot] = s0;           // turned into s0 - offs below
-        L.offs[slot + 1] = s1 - s0;   // length; prefix-summed below
+        L.offs[slot + 1] = (s1 - s0 + KS - 1) / KS * KS;   // flat length (a multiple of KS); prefix-summed below
+        if (!BWD) L.slen[slot] = s1 - s0;
         L.valid[slot] = 0;
         if (BWD) {
             if (!BWD_TABLES_GLOBAL) {
@@ -532,13 +542,14 @@ __device__ __forceinline__ void scatter_sample(unsigned long long *dbox, const T
 }
 
 // ALPHA (forward only): the alpha pre-pass -- centre tap + TF only, the partial of a segment is its accumulated alpha.
-template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, bool ALPHA = false>
+template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, bool ALPHA = false, int KF = 1>
 __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FWD_WAVES) void brick_flat_kernel(BrickParams<VT> P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (ALPHA && P.stats[2 + blockIdx.y] == 0u) return;  // uniform: no ray of this view can terminate early
     constexpr int EC = BWD ? FEC_BWD : FEC_FWD;
     constexpr int FNT = BWD ? FNT_BWD : FNT_FWD;
     constexpr int FNW = FNT / 64;
+    constexpr int KS = (!BWD && !ALPHA) ? KF : 1;  // consecutive samples per lane (forward only)
     const int view = blockIdx.y;
     const f3 cam = make_f3(P.cam[3 * view], P.cam[3 * view + 1], P.cam[3 * view + 2]);
     BrickCtx c;
@@ -567,7 +578,7 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
     for (int cbase = 0; cbase < ncand; cbase += EC) {
         int nE, M;
         if (cbase > 0) cand_load<VT, MODE, BWD, ALPHA>(P, c, view, cbase, ncand, seg_base, cd);
-        flat_build_entries<VT, MODE, BWD, FNT, ALPHA>(P, c, cam, view, cd, seg_base, L, nE, M);  // syncs inside
+        flat_build_entries<VT, MODE, BWD, FNT, ALPHA, KS>(P, c, cam, view, cd, seg_base, L, nE, M);  // syncs inside
         any = any || nE > 0;
         // this wave owns the contiguous entry range [ea, eb): segments never straddle two waves
         const int ea = lower_bound_offs(L.offs, nE, (int)(((long long)M * wave) / FNW));
@@ -577,17 +588,17 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
         int carry_e = -1;  // entry whose composite so far is in `carry` (continues into the next chunk)
         int e_cur = ea;
 #ifdef DR_ABL_NOLOOP
-        for (int f0 = fa; f0 < fa; f0 += 64) {
+        for (int f0 = fa; f0 < fa; f0 += 64 * KS) {
 #else
-        for (int f0 = fa; f0 < fb; f0 += 64) {
+        for (int f0 = fa; f0 < fb; f0 += 64 * KS) {
 #endif
-            const int f = f0 + lane;
+            const int f = f0 + KS * lane;
             const bool act = f < fb;
             // entry of this lane: advance from the previous chunk's entry (flat order is entry order)
             if (act) { while (f >= L.offs[e_cur + 1]) ++e_cur; }
             const int e = act ? e_cur : eb - 1;
             const int eoff = L.offs[e];
-            const int sl = max(lane - (f - eoff), 0);  // first lane of this lane's segment within the chunk
+            const int sl = max(lane - (f - eoff) / KS, 0);  // first lane of this lane's segment within the chunk
             const float4 r0 = L.ray0[e], r1 = L.ray1[e];
             const int s = f + L.s_rel[e];
             const f3 vd = make_f3(r1.x, r1.y, r1.z);
@@ -643,28 +654,58 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
             }
             Sample sm; TapCoords t;
             bool valid = false;
-            if (act) {
-                sample_pos_rcp(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, cam.x, cam.y, cam.z, s, sm.px, sm.py, sm.pz);
-                valid = sample_coords_at(vol, c, sm, t);
-            }
             float dx = 0.f, dy = 0.f, dz = 0.f;
             Over el = {0.f, 0.f, 0.f, 0.f};
-            bool shaded = false;
-            if (valid) {
-                sm.I = sample_centre_lds(L.box, t);
-                classify_from_I(L.tf, P.R, P.tf_len, P.inv_sr, sm);
-            }
+            unsigned long long vm_fwd[KS];  // forward: which lanes hold an in-brick sample, per sub-sample
             // Lighting only matters where the sample has opacity: c = L*rgb*op is exactly 0 for op == 0 whatever L
             // is (the nondiff path skips alpha <= 1e-3 by definition, VR.py:334). Lanes are consecutive samples of a
             // ray, so empty stretches of the transfer function are wave-uniform: skip the six normal taps (48 of the
             // 56 LDS reads) and the shading for the whole wave. The backward always needs L (d/d alpha).
-            const bool lit = !ALPHA && valid && (BWD || (MODE == DR_MODE_NONDIFF ? (sm.a > 1e-3f) : (sm.op != 0.0f)));
-            if (BWD || __any(lit)) {
-                if (lit) {
-                    sample_normal_taps_lds(L.box, t, dx, dy, dz);
-                    shade_from_grad<true>(dx, dy, dz, light, vd, MODE == DR_MODE_DIFF, sm);
-                    el.c0 = sm.L * sm.r * sm.op; el.c1 = sm.L * sm.g * sm.op; el.c2 = sm.L * sm.b * sm.op; el.a = sm.op;
-                    shaded = true;
+            if (KS == 1) {
+                if (act) {
+                    sample_pos_rcp(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, cam.x, cam.y, cam.z, s, sm.px, sm.py, sm.pz);
+                    valid = sample_coords_at(vol, c, sm, t);
+                }
+                if (valid) {
+                    sm.I = sample_centre_lds(L.box, t);
+                    classify_from_I(L.tf, P.R, P.tf_len, P.inv_sr, sm);
+                }
+                const bool lit = !ALPHA && valid && (BWD || (MODE == DR_MODE_NONDIFF ? (sm.a > 1e-3f) : (sm.op != 0.0f)));
+                if (BWD || __any(lit)) {
+                    if (lit) {
+                        sample_normal_taps_lds(L.box, t, dx, dy, dz);
+                        shade_from_grad<true>(dx, dy, dz, light, vd, MODE == DR_MODE_DIFF, sm);
+                        el.c0 = sm.L * sm.r * sm.op; el.c1 = sm.L * sm.g * sm.op; el.c2 = sm.L * sm.b * sm.op; el.a = sm.op;
+                    }
+                }
+                vm_fwd[0] = BWD ? 0ull : __ballot(valid);
+            } else {
+                // forward, KS consecutive samples per lane: composited in registers, so that the cross-lane scan and
+                // the per-chunk bookkeeping below are paid once per KS*64 samples
+                const int slen = L.slen[e];
+#pragma unroll
+                for (int j = 0; j < KS; ++j) {
+                    const bool actj = act && (f + j - eoff) < slen;
+                    bool vj = false;
+                    if (actj) {
+                        sample_pos_rcp(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, cam.x, cam.y, cam.z, s + j, sm.px, sm.py, sm.pz);
+                        vj = sample_coords_at(vol, c, sm, t);
+                    }
+                    if (vj) {
+                        sm.I = sample_centre_lds(L.box, t);
+                        classify_from_I(L.tf, P.R, P.tf_len, P.inv_sr, sm);
+                    }
+                    const bool lit = vj && (MODE == DR_MODE_NONDIFF ? (sm.a > 1e-3f) : (sm.op != 0.0f));
+                    Over ej = {0.f, 0.f, 0.f, 0.f};
+                    if (__any(lit)) {
+                        if (lit) {
+                            sample_normal_taps_lds(L.box, t, dx, dy, dz);
+                            shade_from_grad<true>(dx, dy, dz, light, vd, MODE == DR_MODE_DIFF, sm);
+                            ej.c0 = sm.L * sm.r * sm.op; ej.c1 = sm.L * sm.g * sm.op; ej.c2 = sm.L * sm.b * sm.op; ej.a = sm.op;
+                        }
+                    }
+                    vm_fwd[j] = __ballot(vj);
+                    el = (j == 0) ? ej : over(el, ej);  // over(x, 0) == x exactly
                 }
             }
             // segmented inclusive scan of "over" across the wave (segments = entries)
@@ -680,18 +721,19 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
             {
                 const int e_last = __builtin_amdgcn_readlane(e, 63);
                 const Over last = readlane_over(inc, 63);
-                const bool more = (f0 + 64 < fb) && (L.offs[e_last + 1] > f0 + 64);
+                const bool more = (f0 + 64 * KS < fb) && (L.offs[e_last + 1] > f0 + 64 * KS);
                 carry = last; carry_e = more ? e_last : -1;
             }
-            const bool seg_end = act && (f == L.offs[e + 1] - 1);
+            const bool seg_end = act && (f + KS >= L.offs[e + 1]);
             if (!BWD) {
                 // count the in-brick samples of each segment piece, store finished segments
-                const unsigned long long vm = __ballot(valid);
-                const bool piece_end = act && (seg_end || lane == 63 || f == fb - 1);
+                const bool piece_end = act && (seg_end || lane == 63 || f + KS >= fb);
                 if (piece_end) {
                     const unsigned long long below = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
                     const unsigned long long from = ~((1ull << sl) - 1ull);
-                    const int cntp = __popcll(vm & below & from);
+                    int cntp = 0;
+#pragma unroll
+                    for (int j = 0; j < KS; ++j) cntp += __popcll(vm_fwd[j] & below & from);
                     const int before = cntp ? atomicAdd(&L.valid[e], cntp) : L.valid[e];
                     // a (ray, layer) slot belongs to the one brick that holds samples of the ray: a candidate
                     // segment without any in-brick sample must not touch it
@@ -795,7 +837,6 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
                     else scatter_sample<false>(L.dbox, t, valid, cbase_i, I_bar, gq, fs);
                 }
             }
-            (void)shaded;
         }
         if (!BWD) {
             // sample counts of the segments this wave owns (only this wave added to them)
@@ -884,13 +925,18 @@ static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     MarchArgs b = a;
     b.use_live = prepass ? 1 : 0;
     P.use_live = b.use_live;
-    if (a.mode == DR_MODE_DIFF) {
-        if ((e = allow_lds(brick_flat_kernel<VT, DR_MODE_DIFF, false, false, false>, lds)) != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((brick_flat_kernel<VT, DR_MODE_DIFF, false, false, false>), grid1, dim3(FNT_FWD), lds, stream, P);
-    } else {
-        if ((e = allow_lds(brick_flat_kernel<VT, DR_MODE_NONDIFF, false, false, false>, lds)) != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((brick_flat_kernel<VT, DR_MODE_NONDIFF, false, false, false>), grid1, dim3(FNT_FWD), lds, stream, P);
+    // Samples per lane: the cross-lane scan and the chunk bookkeeping are paid once per K*64 samples, but lanes K
+    // samples apart share fewer LDS words (more read cycles, more bank conflicts). Measured at 512^3: K = 2 wins up
+    // to sampling rate ~3 (-3 % at 1, -10 % at 2), K = 4 beyond (-6 % at 4, -8 % at 8: samples are closer together).
+#define DR_LAUNCH_F1(MODE_, K_)                                                                                      \
+    {                                                                                                                \
+        if ((e = allow_lds(brick_flat_kernel<VT, MODE_, false, false, false, false, K_>, lds)) != hipSuccess) return (int)e; \
+        hipLaunchKernelGGL((brick_flat_kernel<VT, MODE_, false, false, false, false, K_>), grid1, dim3(FNT_FWD), lds, stream, P); \
     }
+    const bool k_hi = a.sr >= 3.0f;
+    if (a.mode == DR_MODE_DIFF) { if (k_hi) DR_LAUNCH_F1(DR_MODE_DIFF, DR_FWD_K_HI) else DR_LAUNCH_F1(DR_MODE_DIFF, DR_FWD_K) }
+    else { if (k_hi) DR_LAUNCH_F1(DR_MODE_NONDIFF, DR_FWD_K_HI) else DR_LAUNCH_F1(DR_MODE_NONDIFF, DR_FWD_K) }
+#undef DR_LAUNCH_F1
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
     return launch_ray_compose(b, stream);
 }
