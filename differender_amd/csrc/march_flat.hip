@@ -39,6 +39,9 @@ constexpr int FNT_BWD = DR_FNT_BWD;     // (backward: 118 KB of LDS -> one workg
 #ifndef DR_BWD_TABLES_GLOBAL
 #define DR_BWD_TABLES_GLOBAL 1
 #endif
+#ifndef DR_PHASE_TIMING
+#define DR_PHASE_TIMING 0
+#endif
 #ifndef DR_FWD_K
 #define DR_FWD_K 2      // forward: samples per lane at sampling rates below 3
 #endif
@@ -139,45 +142,55 @@ __device__ __forceinline__ BoxWalk make_box_walk(long long sx, long long sy, lon
 // row r (0 .. BOX*BOX-1) -> (b, d): r / 15 == (r * 4370) >> 16 for r < 4000 (checked exhaustively)
 __device__ __forceinline__ void box_row(int r, int &b, int &d) { static_assert(BOX == 15, "magic divisor"); d = (r * 4370) >> 16; b = r - d * BOX; }
 
-// Stage TF and the brick's voxel box in LDS. BATCH: all global loads are issued first (into registers), the LDS
-// stores follow: one memory latency per brick instead of one per pass.
-template <typename VT, int FNT, bool BATCH>
-__device__ __forceinline__ void flat_load_tf_and_box(const BrickParams<VT> &P, const VolView<VT> &vol,
-                                                     const BrickCtx &c, const float4 *tfg, FlatLds &L) {
-    constexpr int RP = FNT / 16, NPASS = (BOX * BOX + RP - 1) / RP;
+// Staging of the brick's voxel box (and the TF) in LDS, in two halves: box_issue() puts all global loads in flight
+// (one register per pass), box_commit() stores them to LDS. The caller lists the brick's ray segments in between,
+// which needs neither: the memory latency of the box is covered by that work. (16-byte loads of 4 voxels per lane
+// were tried instead of 15 x 4-byte passes: no gain in the forward, -2.5 % in the backward.)
+template <int FNT>
+struct BoxStage {
+    static constexpr int RP = FNT / 16, NPASS = (BOX * BOX + RP - 1) / RP;
+    float bv[NPASS];
+    float4 tfv;
+};
+template <typename VT, int FNT>
+__device__ __forceinline__ void box_issue(const BrickParams<VT> &P, const VolView<VT> &vol, const BrickCtx &c,
+                                          const float4 *tfg, BoxStage<FNT> &st) {
+    using S = BoxStage<FNT>;
     const BoxWalk w = make_box_walk(vol.sx, vol.sy, vol.sz, vol.VX, vol.VY, vol.VZ, c);
     const VT *base = vol.p + w.base;
     const int a = threadIdx.x & 15, row = threadIdx.x >> 4;
     const bool a_ok = a < BOX && (unsigned)(w.oa + a) < (unsigned)w.Va;
-    const int a_lds = a * w.la, a_off = a * w.ga;
-    if (!BATCH) {  // register-bound callers: load and store pass by pass
-        for (int k = threadIdx.x; k < P.R; k += FNT) L.tf[k] = tfg[k];
-        for (int r = row; r < BOX * BOX; r += RP) {
-            int b, d;
-            box_row(r, b, d);
-            float v = 0.0f;
-            if (a_ok && (unsigned)(w.ob + b) < (unsigned)w.Vb && (unsigned)(w.od + d) < (unsigned)w.Vd)
-                v = ld_voxel(base + (a_off + b * w.gb + d * w.gd));
-            if (a < BOX) L.box[a_lds + b * w.lb + d * w.ld] = v;
-        }
-        return;
-    }
-    float bv[NPASS];
-    int ba[NPASS];
+    const int a_off = a * w.ga;
 #pragma unroll
-    for (int k = 0; k < NPASS; ++k) {
-        const int r = row + k * RP;
+    for (int k = 0; k < S::NPASS; ++k) {
+        const int r = row + k * S::RP;
         int b, d;
         box_row(r, b, d);
-        bv[k] = 0.0f;
-        ba[k] = (a < BOX && r < BOX * BOX) ? a_lds + b * w.lb + d * w.ld : -1;
+        st.bv[k] = 0.0f;
         if (a_ok && r < BOX * BOX && (unsigned)(w.ob + b) < (unsigned)w.Vb && (unsigned)(w.od + d) < (unsigned)w.Vd)
-            bv[k] = ld_voxel(base + (a_off + b * w.gb + d * w.gd));
+            st.bv[k] = ld_voxel(base + (a_off + b * w.gb + d * w.gd));
     }
-    for (int k = threadIdx.x; k < P.R; k += FNT) L.tf[k] = tfg[k];
+    st.tfv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (P.R <= FNT) { if ((int)threadIdx.x < P.R) st.tfv = tfg[threadIdx.x]; }  // uniform: the usual one texel per thread
+}
+template <typename VT, int FNT>
+__device__ __forceinline__ void box_commit(const BrickParams<VT> &P, const VolView<VT> &vol, const BrickCtx &c,
+                                           const float4 *tfg, const BoxStage<FNT> &st, FlatLds &L) {
+    using S = BoxStage<FNT>;
+    const BoxWalk w = make_box_walk(vol.sx, vol.sy, vol.sz, vol.VX, vol.VY, vol.VZ, c);
+    const int a = threadIdx.x & 15, row = threadIdx.x >> 4;
+    const int a_lds = a * w.la;
+    if (a < BOX) {
 #pragma unroll
-    for (int k = 0; k < NPASS; ++k)
-        if (ba[k] >= 0) L.box[ba[k]] = bv[k];
+        for (int k = 0; k < S::NPASS; ++k) {
+            const int r = row + k * S::RP;
+            int b, d;
+            box_row(r, b, d);
+            if (r < BOX * BOX) L.box[a_lds + b * w.lb + d * w.ld] = st.bv[k];
+        }
+    }
+    if (P.R <= FNT) { if ((int)threadIdx.x < P.R) L.tf[threadIdx.x] = st.tfv; }
+    else { for (int k = threadIdx.x; k < P.R; k += FNT) L.tf[k] = tfg[k]; }
 }
 
 // What a thread reads from global memory for its candidate pixel of a round -- issued as ONE batch of loads (the
@@ -562,28 +575,45 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
     const int NP = P.W * P.H;
     const size_t seg_base = ((size_t)view * P.g.NL + c.layer) * NP;
     const int ncand = (c.i1 - c.i0 + 1) * (c.j1 - c.j0 + 1);
+#if DR_PHASE_TIMING
+    const long long tk0 = clock64();
+    long long tk2 = 0;
+#endif
     CandData cd;
-    cand_load<VT, MODE, BWD, ALPHA>(P, c, view, 0, ncand, seg_base, cd);  // in flight while the box is staged
-    flat_load_tf_and_box<VT, FNT, !BWD>(P, vol, c, P.tf + view * P.tf_vs, L);
+    cand_load<VT, MODE, BWD, ALPHA>(P, c, view, 0, ncand, seg_base, cd);  // ray buffers of the first round's candidates
+    BoxStage<FNT> stage;
+    box_issue<VT, FNT>(P, vol, c, P.tf + view * P.tf_vs, stage);          // voxel box + TF: in flight ...
     FixScale fs;
     if (BWD) {
         if (WANT_VOL) for (int k = threadIdx.x; k < BOX_LDS; k += FNT) L.dbox[k] = 0ull;
         if (WANT_TF) for (int k = threadIdx.x; k < 4 * P.R; k += FNT) L.dtf[k] = 0ull;
         fs = make_fix_scale(P.stats[1]);
     }
+    int nE0, M0;
+    flat_build_entries<VT, MODE, BWD, FNT, ALPHA, KS>(P, c, cam, view, cd, seg_base, L, nE0, M0);  // ... while the segments are listed
+    box_commit<VT, FNT>(P, vol, c, P.tf + view * P.tf_vs, stage, L);
+    __syncthreads();
+#if DR_PHASE_TIMING
+    const long long tk1 = clock64();
+#endif
     const f3 light = make_f3(cam.x + 0.0f, cam.y + 1.0f, cam.z + 0.0f);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     bool any = false;
 
     for (int cbase = 0; cbase < ncand; cbase += EC) {
-        int nE, M;
-        if (cbase > 0) cand_load<VT, MODE, BWD, ALPHA>(P, c, view, cbase, ncand, seg_base, cd);
-        flat_build_entries<VT, MODE, BWD, FNT, ALPHA, KS>(P, c, cam, view, cd, seg_base, L, nE, M);  // syncs inside
+        int nE = nE0, M = M0;
+        if (cbase > 0) {
+            cand_load<VT, MODE, BWD, ALPHA>(P, c, view, cbase, ncand, seg_base, cd);
+            flat_build_entries<VT, MODE, BWD, FNT, ALPHA, KS>(P, c, cam, view, cd, seg_base, L, nE, M);  // syncs inside
+        }
         any = any || nE > 0;
         // this wave owns the contiguous entry range [ea, eb): segments never straddle two waves
         const int ea = lower_bound_offs(L.offs, nE, (int)(((long long)M * wave) / FNW));
         const int eb = (wave == FNW - 1) ? nE : lower_bound_offs(L.offs, nE, (int)(((long long)M * (wave + 1)) / FNW));
         const int fa = L.offs[ea], fb = L.offs[eb];
+#if DR_PHASE_TIMING
+        if (cbase == 0) { asm volatile("" :: "v"(fa), "v"(fb)); tk2 = clock64(); }
+#endif
         Over carry = {0.f, 0.f, 0.f, 0.f};
         int carry_e = -1;  // entry whose composite so far is in `carry` (continues into the next chunk)
         int e_cur = ea;
@@ -847,6 +877,15 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
         }
         __syncthreads();
     }
+#if DR_PHASE_TIMING
+    if (!ALPHA && threadIdx.x == 0) {  // per-phase clocks of this workgroup, summed over the grid (tools/phase_times.py)
+        const long long tk3 = clock64();
+        unsigned long long *tt = reinterpret_cast<unsigned long long *>(P.stats + (BWD ? 58 : 52));
+        atomicAdd(tt + 0, (unsigned long long)(tk1 - tk0));   // staging: candidate + box loads, first segment listing
+        atomicAdd(tt + 1, (unsigned long long)(tk2 - tk1));   // wave split
+        atomicAdd(tt + 2, (unsigned long long)(tk3 - tk2));   // sample loop (+ further rounds)
+    }
+#endif
     if (!BWD || !any) return;  // uniform
     // flush: one pass of global float atomics per brick, walking the gradient's fastest axis
     if (WANT_VOL) {

@@ -1,0 +1,25 @@
+"""Per-workgroup phase times of the flat kernels (library built with -DDR_PHASE_TIMING=1)."""
+import sys, os
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from differender_amd import functional as F
+from bench import synth_volume_torch, bench_tf_torch, in_circles
+dev = torch.device("cuda:0")
+N, IMG, R = 512, 512, 256
+vol = synth_volume_torch(N, dev); tf = bench_tf_torch(R, 1e-3, dev)
+ws = F.alloc_workspace(1, (IMG, IMG), (N,) * 3, R, dev)
+cam = torch.tensor([in_circles(0.3)], dtype=torch.float32, device=dev)
+e, x, r, n = F.ray_setup(cam, (IMG, IMG), (N,) * 3, 1.0)
+for it in range(3):
+    out, steps = F.march_fwd(vol, tf, cam, e, x, r, n, 1 << 20, 1.0, workspace=ws)
+    g = torch.ones_like(out)
+    dv, dt = F.march_bwd(vol, tf, cam, e, x, r, n, 1 << 20, 1.0, g, out, workspace=ws)
+torch.cuda.synchronize()
+t = ws[:256].view(torch.int64).cpu().numpy()
+nb = 43 ** 3
+clk = 100e6  # clock64() = s_memrealtime? print raw too
+print("raw fwd", t[26:29], "bwd", t[29:32])
+for name, v in (("fwd", t[26:29]), ("bwd", t[29:32])):
+    tot = v.sum()
+    print(name, "per brick (ticks): staging %.0f entries %.0f loop %.0f  -> shares %.1f%% %.1f%% %.1f%%" % (
+        v[0] / nb, v[1] / nb, v[2] / nb, 100 * v[0] / tot, 100 * v[1] / tot, 100 * v[2] / tot))
