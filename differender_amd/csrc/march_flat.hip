@@ -1,16 +1,18 @@
 // march_flat.hip -- brick-centric march with ONE LANE PER SAMPLE (DR_VARIANT_AUTO fast path, gfx950).
 //
-// Same pipeline as march_brick.hip (LDS-staged 16^3-cell bricks, per-(ray,layer) partial composites, F2
+// Same pipeline as march_brick.hip (LDS-staged 12^3-cell bricks, per-(ray,layer) partial composites, F2
 // per-ray composition, fixed-point LDS gradient boxes), but the work items of a brick are the SAMPLES of all
-// ray segments that cross it, laid out back to back ("flat" index): a wave takes 64 consecutive samples.
+// ray segments that cross it, laid out back to back ("flat" index): a wave takes 64 consecutive lanes' worth.
 //   * every lane is busy whatever the lengths of the individual segments (a brick holds only ~170 segments
-//     but ~7800 samples), so a 512-thread workgroup fills a CU even when the LDS footprint allows one
-//     workgroup per CU (backward: 27 KB voxel box + 55 KB 64-bit gradient box);
-//   * the 64 lanes of a load walk along one or two rays: ~19 distinct cells per instruction on odd LDS
-//     strides, i.e. conflict-free reads, and neighbouring lanes that share a cell are LDS broadcasts;
+//     but ~7800 samples);
+//   * the 64 lanes of a load walk along one or two rays: few distinct cells per instruction on odd LDS
+//     strides, i.e. mostly conflict-free reads, and neighbouring lanes that share a cell are LDS broadcasts;
 //   * front-to-back compositing inside a segment becomes a segmented wave scan of the associative "over"
-//     operator (DPP/shuffle, no LDS traffic); the running composite of a segment that spans several
-//     64-sample chunks is carried in registers by the wave that owns it.
+//     operator (DPP, no LDS traffic); the running composite of a segment that spans several chunks is carried
+//     in registers by the wave that owns it. The forward composites K (2 or 4) consecutive samples per lane in
+//     registers first, so scan and bookkeeping are paid once per K*64 samples.
+// Tuned against the measured VALU cost table of gfx950 (profiles/r01_microbench_oprate.txt): only f32
+// add/mul/fma, v_mov and v_add_u32 issue in 2 cycles, everything else in 4 (rcp/rsq 8).
 // Reference functions replaced: VR.py:261-372 and the autodiff twins VR.py:460-461,470-471.
 #include "dr_brick_common.h"
 
@@ -28,8 +30,8 @@ namespace dr {
 #ifndef DR_FNT_FWD
 #define DR_FNT_FWD 256
 #endif
-constexpr int FNT_FWD = DR_FNT_FWD;      // threads per workgroup (forward: 43 KB of LDS -> 3 workgroups per CU)
-constexpr int FNT_BWD = DR_FNT_BWD;     // (backward: 118 KB of LDS -> one workgroup per CU, so make it 8 waves)
+constexpr int FNT_FWD = DR_FNT_FWD;      // threads per workgroup (forward: 30 KB of LDS, 96 VGPRs -> 5 workgroups per CU)
+constexpr int FNT_BWD = DR_FNT_BWD;     // (backward: 66 KB of LDS, 128 VGPRs -> two 8-wave workgroups per CU)
 #ifndef DR_FEC_FWD
 #define DR_FEC_FWD 256
 #endif
