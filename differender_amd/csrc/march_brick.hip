@@ -82,6 +82,20 @@ __global__ __launch_bounds__(256) void brick_fwd_kernel(BrickParams<VT> P) {
 }
 
 // ------------------------------------------------------------------------------------------------ F2
+// Layer (dr_brick.h) of the brick that holds sample s of a ray. Layers grow monotonically along a ray, so the
+// bricks of samples [0, n) all have layers between those of sample 0 and sample n-1: the per-ray passes only look
+// at that range of the [layer][pixel] workspace (typically 45-60 of 127 layers at 512^3).
+template <typename VT>
+__device__ __forceinline__ int sample_layer(const BrickParams<VT> &P, const RayGeom &rg, f3 cam, int s) {
+    float px, py, pz, fr;
+    int x0, y0, z0;
+    sample_pos(rg, cam.x, cam.y, cam.z, s, px, py, pz);
+    axis_coord(px, P.vol.scx, x0, fr); axis_coord(py, P.vol.scy, y0, fr); axis_coord(pz, P.vol.scz, z0, fr);
+    const int cbx = cam_brick(cam.x, P.vol.scx), cby = cam_brick(cam.y, P.vol.scy), cbz = cam_brick(cam.z, P.vol.scz);
+    const int lmin = axis_layer_min(cbx, P.g.NBx) + axis_layer_min(cby, P.g.NBy) + axis_layer_min(cbz, P.g.NBz);
+    return abs(x0 / BRK - cbx) + abs(y0 / BRK - cby) + abs(z0 / BRK - cbz) - lmin;
+}
+
 template <typename VT, int MODE>
 __global__ __launch_bounds__(256) void ray_compose_kernel(BrickParams<VT> P) {
     extern __shared__ __attribute__((aligned(16))) float4 lds_tf[];
@@ -111,10 +125,15 @@ __global__ __launch_bounds__(256) void ray_compose_kernel(BrickParams<VT> P) {
         // with an alpha pre-pass the bricks marched exactly the live samples of the ray: no crossing to look for
         const bool use_live = P.use_live && P.stats[2 + view] != 0u;
         if (regular && use_live) nmarch = min(nmarch, P.ws_steps[p]);
+        int l_lo = 0, l_hi = P.g.NL - 1;
+        if (regular && nmarch > 0) {
+            l_lo = max(sample_layer(P, rg, cam, 0), 0);
+            l_hi = min(sample_layer(P, rg, cam, nmarch - 1), P.g.NL - 1);
+        }
         if (regular) {
             // safety net: the segments must account for every sample, else march this ray whole
             int total = 0;
-            for (int l = 0; l < P.g.NL; ++l) total += P.seg_cnt[seg0 + (size_t)l * NP];
+            for (int l = l_lo; l <= l_hi; ++l) total += P.seg_cnt[seg0 + (size_t)l * NP];
             if (total != nmarch) { regular = false; nmarch = nfull; atomicAdd(&P.stats[0], 1u); }
         }
         int s_from = 0, s_to = 0;  // samples to march one by one with early termination
@@ -123,7 +142,7 @@ __global__ __launch_bounds__(256) void ray_compose_kernel(BrickParams<VT> P) {
         } else {
             int sacc = 0;
             steps = nmarch;
-            for (int l = 0; l < P.g.NL; ++l) {
+            for (int l = l_lo; l <= l_hi; ++l) {
                 const size_t si = seg0 + (size_t)l * NP;
                 const int cnt = P.seg_cnt[si];
                 if (cnt == 0) continue;
@@ -212,15 +231,17 @@ __global__ __launch_bounds__(256) void ray_alpha_kernel(BrickParams<VT> P) {
     int live = nmarch;
     if (ray_is_regular(rg.n, rg.entry)) {
         const size_t seg0 = (size_t)view * P.g.NL * NP + pl;
+        const f3 cam = make_f3(P.cam[3 * view], P.cam[3 * view + 1], P.cam[3 * view + 2]);
+        const int l_lo = max(sample_layer(P, rg, cam, 0), 0);
+        const int l_hi = min(sample_layer(P, rg, cam, nmarch - 1), P.g.NL - 1);
         int total = 0;
-        for (int l = 0; l < P.g.NL; ++l) total += P.seg_cnt[seg0 + (size_t)l * NP];
+        for (int l = l_lo; l <= l_hi; ++l) total += P.seg_cnt[seg0 + (size_t)l * NP];
         if (total == nmarch) {  // otherwise: no culling for this ray, F2 will sort it out
             VolView<VT> vol = P.vol;
             vol.p += view * P.vol_vs;
-            const f3 cam = make_f3(P.cam[3 * view], P.cam[3 * view + 1], P.cam[3 * view + 2]);
             float A = 0.f;
             int sacc = 0;
-            for (int l = 0; l < P.g.NL; ++l) {
+            for (int l = l_lo; l <= l_hi; ++l) {
                 const size_t si = seg0 + (size_t)l * NP;
                 const int cnt = P.seg_cnt[si];
                 if (cnt == 0) continue;
