@@ -111,7 +111,7 @@ __device__ __forceinline__ FlatLds flat_carve(unsigned char *smem, int R) {
     L.slen = nullptr;
     if (BWD) { L.live = reinterpret_cast<int *>(smem + o); o += (size_t)EC * 4; }
     else { L.slen = reinterpret_cast<int *>(smem + o); o += (size_t)EC * 4; }
-    L.misc = reinterpret_cast<int *>(smem + o); o += 128;  // 32 ints: [1] M, [4 + wave] per-wave entry counts
+    L.misc = reinterpret_cast<int *>(smem + o); o += 128;  // 32 ints: [1] M, [4 + wave] per-wave entry counts, [16 + wave] first entry of a wave
     L.tf = reinterpret_cast<float4 *>(smem + o); o += (size_t)R * 16;
     if (BWD && WANT_TF) L.dtf = reinterpret_cast<unsigned long long *>(smem + o);
     return L;
@@ -313,19 +313,28 @@ __device__ __forceinline__ void flat_build_entries(const BrickParams<VT> &P, con
             run += loc[k];
         }
         if (threadIdx.x == 63) { L.offs[nE] = run; L.misc[1] = run; }
+        // wave split: wave w starts at the first entry whose flat offset is >= M*w/FNW, i.e. at the NUMBER of
+        // entries below that target (offsets are sorted). Found here from the registers of the scan instead of a
+        // binary search over LDS by every wave (16 dependent LDS round trips per workgroup).
+        const int Mtot = __builtin_amdgcn_readlane(run, 63);
+        int first = run;  // recomputed below: offset of this lane's first entry
+#pragma unroll
+        for (int k = 0; k < PER; ++k) first -= loc[k];
+#pragma unroll
+        for (int w = 1; w < FNW; ++w) {
+            const int target = (int)(((long long)Mtot * w) / FNW);
+            int c = 0, o = first;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                c += ((int)threadIdx.x * PER + k < nE && o < target) ? 1 : 0;
+                o += loc[k];
+            }
+            const int nfull = __popcll(__ballot(c == PER));  // lanes entirely below the target form a prefix
+            if ((int)threadIdx.x == min(nfull, 63)) L.misc[16 + w] = (nfull == 64) ? 64 * PER : nfull * PER + c;
+        }
     }
     __syncthreads();
     M = L.misc[1];
-}
-
-// first index e in [0, nE] with offs[e] >= target (offs is non-decreasing, offs[nE] = M)
-__device__ __forceinline__ int lower_bound_offs(const int *offs, int nE, int target) {
-    int lo = 0, hi = nE;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (offs[mid] < target) lo = mid + 1; else hi = mid;
-    }
-    return lo;
 }
 
 struct Over { float c0, c1, c2, a; };  // premultiplied composite element
@@ -610,8 +619,8 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
         }
         any = any || nE > 0;
         // this wave owns the contiguous entry range [ea, eb): segments never straddle two waves
-        const int ea = lower_bound_offs(L.offs, nE, (int)(((long long)M * wave) / FNW));
-        const int eb = (wave == FNW - 1) ? nE : lower_bound_offs(L.offs, nE, (int)(((long long)M * (wave + 1)) / FNW));
+        const int ea = (wave == 0) ? 0 : L.misc[16 + wave];
+        const int eb = (wave == FNW - 1) ? nE : L.misc[16 + wave + 1];
         const int fa = L.offs[ea], fb = L.offs[eb];
 #if DR_PHASE_TIMING
         if (cbase == 0) { asm volatile("" :: "v"(fa), "v"(fb)); tk2 = clock64(); }
@@ -913,6 +922,11 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
             if (raw != 0ull) unsafeAtomicAdd(dtf + k, fix_to_float(raw, fs));
         }
     }
+#if DR_PHASE_TIMING
+    __syncthreads();
+    if (threadIdx.x == 0)  // whole lifetime of a backward workgroup, gradient flush included
+        atomicAdd(reinterpret_cast<unsigned long long *>(P.stats + 50), (unsigned long long)(clock64() - tk0));
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ host

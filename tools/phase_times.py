@@ -1,4 +1,4 @@
-"""Per-workgroup phase times of the flat kernels (library built with -DDR_PHASE_TIMING=1)."""
+"""Per-workgroup phase times of the flat kernels (library built with -DDR_PHASE_TIMING=1: tools/mkvariant.sh)."""
 import sys, os
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,11 +15,9 @@ for it in range(3):
     g = torch.ones_like(out)
     dv, dt = F.march_bwd(vol, tf, cam, e, x, r, n, 1 << 20, 1.0, g, out, workspace=ws)
 torch.cuda.synchronize()
-t = ws[:256].view(torch.int64).cpu().numpy()
-nb = 43 ** 3
-clk = 100e6  # clock64() = s_memrealtime? print raw too
-print("raw fwd", t[26:29], "bwd", t[29:32])
-for name, v in (("fwd", t[26:29]), ("bwd", t[29:32])):
-    tot = v.sum()
-    print(name, "per brick (ticks): staging %.0f entries %.0f loop %.0f  -> shares %.1f%% %.1f%% %.1f%%" % (
-        v[0] / nb, v[1] / nb, v[2] / nb, 100 * v[0] / tot, 100 * v[1] / tot, 100 * v[2] / tot))
+t = ws[:256].view(torch.int64).cpu().numpy().astype(float)
+nb = (N - 1 + 11) // 12
+nb = nb ** 3
+print("clock ticks per workgroup (sum over the grid / bricks)")
+print("fwd: staging+listing %.0f  wave split %.0f  sample loop %.0f" % tuple(t[26:29] / nb))
+print("bwd: staging+listing %.0f  wave split %.0f  sample loop %.0f  | whole workgroup incl. flush %.0f" % (t[29] / nb, t[30] / nb, t[31] / nb, t[25] / nb))
