@@ -215,12 +215,8 @@ __global__ __launch_bounds__(256) void ray_compose_kernel(BrickParams<VT> P) {
 // same arithmetic, as ray_compose_kernel would take. Writes ws_steps[p] = exact number of live samples.
 template <typename VT, int MODE>
 __global__ __launch_bounds__(256) void ray_alpha_kernel(BrickParams<VT> P) {
-    extern __shared__ __attribute__((aligned(16))) float4 lds_tf[];
     const int view = blockIdx.y;
     if (P.stats[2 + view] == 0u) return;  // uniform: no ray of this view can terminate, nothing to find
-    const float4 *tfg = P.tf + view * P.tf_vs;
-    for (int k = threadIdx.x; k < P.R; k += 256) lds_tf[k] = tfg[k];
-    __syncthreads();
     const int NP = P.W * P.H;
     const int pl = blockIdx.x * 256 + threadIdx.x;
     if (pl >= NP) return;
@@ -237,8 +233,6 @@ __global__ __launch_bounds__(256) void ray_alpha_kernel(BrickParams<VT> P) {
         int total = 0;
         for (int l = l_lo; l <= l_hi; ++l) total += P.seg_cnt[seg0 + (size_t)l * NP];
         if (total == nmarch) {  // otherwise: no culling for this ray, F2 will sort it out
-            VolView<VT> vol = P.vol;
-            vol.p += view * P.vol_vs;
             float A = 0.f;
             int sacc = 0;
             for (int l = l_lo; l <= l_hi; ++l) {
@@ -246,17 +240,9 @@ __global__ __launch_bounds__(256) void ray_alpha_kernel(BrickParams<VT> P) {
                 const int cnt = P.seg_cnt[si];
                 if (cnt == 0) continue;
                 const float A_after = fmaf(1.0f - A, P.seg_rgba[si].w, A);
-                if (!(A_after < 0.99f)) {  // the crossing segment: samples [sacc, sacc+cnt), then (rounding) beyond
-                    int s = sacc;
-                    for (; s < nmarch; ++s) {
-                        if (!(A < 0.99f)) break;
-                        Sample sm;
-                        sample_pos(rg, cam.x, cam.y, cam.z, s, sm.px, sm.py, sm.pz);
-                        classify(vol, lds_tf, P.R, P.tf_len, P.inv_sr, sm);
-                        if (MODE == DR_MODE_NONDIFF && !(sm.a > 1e-3f)) continue;
-                        A = fmaf(1.0f - A, sm.op, A);
-                    }
-                    live = s;
+                if (!(A_after < 0.99f)) {  // the crossing segment starts at sample sacc: resolved by ray_cross_kernel
+                    reinterpret_cast<float4 *>(P.out)[p] = make_float4(A, __int_as_float(sacc), 0.f, 0.f);
+                    live = -1;
                     break;
                 }
                 A = A_after;
@@ -265,6 +251,51 @@ __global__ __launch_bounds__(256) void ray_alpha_kernel(BrickParams<VT> P) {
         }
     }
     P.ws_steps[p] = live;
+}
+
+// P2b: the rays whose accumulated alpha crosses 0.99 (ws_steps == -1, crossing segment and alpha before it parked in
+// the not-yet-written output buffer). One WAVE per ray: 64 consecutive samples per pass -- positions, centre taps (the
+// lanes read neighbouring voxels) and TF lookups in parallel, then the exact sequential recurrence
+// A <- fma(1 - A, op_s, A) of VR.py:318-349 over the 64 opacities (a one-thread-per-ray loop spent ~370 dependent
+// global gathers per ray at sampling rate 8). Same decisions, same arithmetic as F2's own re-march.
+template <typename VT, int MODE>
+__global__ __launch_bounds__(256) void ray_cross_kernel(BrickParams<VT> P) {
+    const int view = blockIdx.y;
+    if (P.stats[2 + view] == 0u) return;  // uniform
+    const int NP = P.W * P.H;
+    const int pl = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (pl >= NP) return;  // wave-uniform
+    const size_t p = (size_t)view * NP + pl;
+    if (P.ws_steps[p] != -1) return;  // wave-uniform: no crossing to resolve
+    const float4 parked = reinterpret_cast<const float4 *>(P.out)[p];
+    RayGeom rg;
+    load_ray(P.entry, P.exit_, P.rays, P.nsamp, p, rg);
+    const int nmarch = (MODE == DR_MODE_DIFF && rg.n > P.S) ? P.S : rg.n;
+    VolView<VT> vol = P.vol;
+    vol.p += view * P.vol_vs;
+    const float4 *tfg = P.tf + view * P.tf_vs;
+    const f3 cam = make_f3(P.cam[3 * view], P.cam[3 * view + 1], P.cam[3 * view + 2]);
+    float A = parked.x;
+    int s = __float_as_int(parked.y);
+    bool done = false;
+    for (int base = s; base < nmarch && !done; base += 64) {
+        const int sl = base + lane;
+        float op = 0.0f;
+        if (sl < nmarch) {
+            Sample sm;
+            sample_pos(rg, cam.x, cam.y, cam.z, sl, sm.px, sm.py, sm.pz);
+            classify(vol, tfg, P.R, P.tf_len, P.inv_sr, sm);
+            op = (MODE == DR_MODE_NONDIFF && !(sm.a > 1e-3f)) ? 0.0f : sm.op;  // skipped sample: A unchanged (fma(T, 0, A) == A)
+        }
+        const int cnt = min(64, nmarch - base);
+        for (int i = 0; i < cnt; ++i) {  // uniform
+            if (!(A < 0.99f)) { done = true; break; }
+            const float opi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(op), i));
+            A = fmaf(1.0f - A, opi, A);
+            ++s;
+        }
+    }
+    if (lane == 0) P.ws_steps[p] = s;
 }
 
 // ------------------------------------------------------------------------------------------------ B1
@@ -459,11 +490,14 @@ static int ray_alpha_dispatch(const MarchArgs &a, hipStream_t stream) {
     ws_layout(a.workspace, a.n_views, NP, g, &w);
     BrickParams<VT> P = make_brick_params<VT>(a, w);
     const dim3 grid2((NP + 255) / 256, a.n_views);
-    const size_t lds2 = (size_t)a.R * 16;
-    if (a.mode == DR_MODE_DIFF)
-        hipLaunchKernelGGL((ray_alpha_kernel<VT, DR_MODE_DIFF>), grid2, dim3(256), lds2, stream, P);
-    else
-        hipLaunchKernelGGL((ray_alpha_kernel<VT, DR_MODE_NONDIFF>), grid2, dim3(256), lds2, stream, P);
+    const dim3 grid3((NP + 3) / 4, a.n_views);
+    if (a.mode == DR_MODE_DIFF) {
+        hipLaunchKernelGGL((ray_alpha_kernel<VT, DR_MODE_DIFF>), grid2, dim3(256), 0, stream, P);
+        hipLaunchKernelGGL((ray_cross_kernel<VT, DR_MODE_DIFF>), grid3, dim3(256), 0, stream, P);
+    } else {
+        hipLaunchKernelGGL((ray_alpha_kernel<VT, DR_MODE_NONDIFF>), grid2, dim3(256), 0, stream, P);
+        hipLaunchKernelGGL((ray_cross_kernel<VT, DR_MODE_NONDIFF>), grid3, dim3(256), 0, stream, P);
+    }
     return (int)hipGetLastError();
 }
 
