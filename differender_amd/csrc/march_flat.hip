@@ -47,6 +47,9 @@ constexpr int FNT_BWD = DR_FNT_BWD;     // (backward: 66 KB of LDS, 128 VGPRs ->
 #ifndef DR_FWD_K
 #define DR_FWD_K 2      // forward: samples per lane at sampling rates below 3
 #endif
+#ifndef DR_ALPHA_K
+#define DR_ALPHA_K 4    // alpha pre-pass
+#endif
 #ifndef DR_FWD_K_HI
 #define DR_FWD_K_HI 4   // ... and at 3 and above
 #endif
@@ -573,7 +576,7 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
     constexpr int EC = BWD ? FEC_BWD : FEC_FWD;
     constexpr int FNT = BWD ? FNT_BWD : FNT_FWD;
     constexpr int FNW = FNT / 64;
-    constexpr int KS = (!BWD && !ALPHA) ? KF : 1;  // consecutive samples per lane (forward only)
+    constexpr int KS = BWD ? 1 : KF;  // consecutive samples per lane (forward and alpha pre-pass)
     const int view = blockIdx.y;
     const f3 cam = make_f3(P.cam[3 * view], P.cam[3 * view + 1], P.cam[3 * view + 2]);
     BrickCtx c;
@@ -654,22 +657,29 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
             }
 #endif
             if (ALPHA) {
-                // alpha pre-pass: position, centre cell, one tap, TF -> transmittance; nothing else
-                Sample sa;
-                int x0 = 0, y0 = 0, z0 = 0;
-                float fx = 0.f, fy = 0.f, fz = 0.f;
-                bool va = act;
-                if (va) {
-                    sample_pos_rcp(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, cam.x, cam.y, cam.z, s, sa.px, sa.py, sa.pz);
-                    axis_coord(sa.px, vol.scx, x0, fx); axis_coord(sa.py, vol.scy, y0, fy); axis_coord(sa.pz, vol.scz, z0, fz);
-                    va = (unsigned)(x0 - c.ox - 1) < (unsigned)BRK && (unsigned)(y0 - c.oy - 1) < (unsigned)BRK &&
-                         (unsigned)(z0 - c.oz - 1) < (unsigned)BRK;
-                }
+                // alpha pre-pass: position, centre cell, one tap, TF -> transmittance; nothing else.
+                // KS consecutive samples per lane, multiplied up in registers before the cross-lane product scan.
+                const int slen = L.slen[e];
                 float Tl = 1.0f;
-                if (va) {
-                    sa.I = tri_lds(L.box, (x0 - c.ox) * BOX_SX + (y0 - c.oy) * BOX_SY + (z0 - c.oz), fx, fy, fz);
-                    classify_from_I(L.tf, P.R, P.tf_len, P.inv_sr, sa);
-                    if (!(MODE == DR_MODE_NONDIFF && !(sa.a > 1e-3f))) Tl = 1.0f - sa.op;
+                int cnt_lane = 0;  // in-brick samples of this lane
+#pragma unroll
+                for (int j = 0; j < KS; ++j) {
+                    Sample sa;
+                    int x0 = 0, y0 = 0, z0 = 0;
+                    float fx = 0.f, fy = 0.f, fz = 0.f;
+                    bool va = act && (f + j - eoff) < slen;
+                    if (va) {
+                        sample_pos_rcp(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, cam.x, cam.y, cam.z, s + j, sa.px, sa.py, sa.pz);
+                        axis_coord(sa.px, vol.scx, x0, fx); axis_coord(sa.py, vol.scy, y0, fy); axis_coord(sa.pz, vol.scz, z0, fz);
+                        va = (unsigned)(x0 - c.ox - 1) < (unsigned)BRK && (unsigned)(y0 - c.oy - 1) < (unsigned)BRK &&
+                             (unsigned)(z0 - c.oz - 1) < (unsigned)BRK;
+                    }
+                    if (va) {
+                        sa.I = tri_lds(L.box, (x0 - c.ox) * BOX_SX + (y0 - c.oy) * BOX_SY + (z0 - c.oz), fx, fy, fz);
+                        classify_from_I(L.tf, P.R, P.tf_len, P.inv_sr, sa);
+                        if (!(MODE == DR_MODE_NONDIFF && !(sa.a > 1e-3f))) Tl *= 1.0f - sa.op;
+                        ++cnt_lane;
+                    }
                 }
                 Tl = seg_scan_prod(Tl, lane, sl);
                 const int e_first = __builtin_amdgcn_readfirstlane(e);
@@ -677,16 +687,16 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
                 {
                     const int e_last = __builtin_amdgcn_readlane(e, 63);
                     const float lastT = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Tl), 63));
-                    const bool more = (f0 + 64 < fb) && (L.offs[e_last + 1] > f0 + 64);
+                    const bool more = (f0 + 64 * KS < fb) && (L.offs[e_last + 1] > f0 + 64 * KS);
                     carry.a = lastT; carry_e = more ? e_last : -1;
                 }
-                const bool seg_end = act && (f == L.offs[e + 1] - 1);
-                const unsigned long long vm = __ballot(va);
-                const bool piece_end = act && (seg_end || lane == 63 || f == fb - 1);
+                const bool seg_end = act && (f + KS >= L.offs[e + 1]);
+                // in-brick samples of the piece [sl, lane]: inclusive lane-sum of the per-lane counts
+                float cf[1] = {(float)cnt_lane};
+                seg_scan_sum<1>(cf, lane, sl);
+                const bool piece_end = act && (seg_end || lane == 63 || f + KS >= fb);
                 if (piece_end) {
-                    const unsigned long long below = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
-                    const unsigned long long from = ~((1ull << sl) - 1ull);
-                    const int cntp = __popcll(vm & below & from);
+                    const int cntp = (int)cf[0];
                     const int before = cntp ? atomicAdd(&L.valid[e], cntp) : L.valid[e];
                     if (seg_end && before + cntp > 0)
                         P.seg_rgba[seg_base + __float_as_int(r1.w)] = make_float4(0.f, 0.f, 0.f, 1.0f - Tl);
@@ -966,11 +976,11 @@ static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
         hipLaunchKernelGGL(may_terminate_kernel, dim3(a.n_views), dim3(64), 0, stream, reinterpret_cast<const float4 *>(a.tf),
                            (long)(a.tf_vs / 4), a.R, 1.0f / a.sr, (float)n_max, w.stats + 2);
         if (a.mode == DR_MODE_DIFF) {
-            if ((e = allow_lds(brick_flat_kernel<VT, DR_MODE_DIFF, false, false, false, true>, lds)) != hipSuccess) return (int)e;
-            hipLaunchKernelGGL((brick_flat_kernel<VT, DR_MODE_DIFF, false, false, false, true>), grid1, dim3(FNT_FWD), lds, stream, P);
+            if ((e = allow_lds(brick_flat_kernel<VT, DR_MODE_DIFF, false, false, false, true, DR_ALPHA_K>, lds)) != hipSuccess) return (int)e;
+            hipLaunchKernelGGL((brick_flat_kernel<VT, DR_MODE_DIFF, false, false, false, true, DR_ALPHA_K>), grid1, dim3(FNT_FWD), lds, stream, P);
         } else {
-            if ((e = allow_lds(brick_flat_kernel<VT, DR_MODE_NONDIFF, false, false, false, true>, lds)) != hipSuccess) return (int)e;
-            hipLaunchKernelGGL((brick_flat_kernel<VT, DR_MODE_NONDIFF, false, false, false, true>), grid1, dim3(FNT_FWD), lds, stream, P);
+            if ((e = allow_lds(brick_flat_kernel<VT, DR_MODE_NONDIFF, false, false, false, true, DR_ALPHA_K>, lds)) != hipSuccess) return (int)e;
+            hipLaunchKernelGGL((brick_flat_kernel<VT, DR_MODE_NONDIFF, false, false, false, true, DR_ALPHA_K>), grid1, dim3(FNT_FWD), lds, stream, P);
         }
         if ((e = hipGetLastError()) != hipSuccess) return (int)e;
         const int rc = launch_ray_alpha(a, stream);
