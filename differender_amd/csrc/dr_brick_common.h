@@ -23,6 +23,7 @@ struct BrickParams {
     unsigned int *stats; // [0] rays repaired by the count check, [1] bits of max|grad_out| (backward),
                          // [2 + view] 1 if some ray of the view may reach alpha >= 0.99 (alpha pre-pass ran)
     int use_live;        // forward: ws_steps holds each ray's exact live sample count (from the alpha pre-pass)
+    int pp_l0, pp_l1, pp_first;  // alpha pre-pass phase: brick layers [pp_l0, pp_l1); later phases skip terminated rays
     const struct BrickCtxRec *ctx;  // [view][brick]: brick geometry + pixel rectangle, filled once per forward call
     float *out; int32_t *steps;
     const float *grad_out, *out_fwd;
@@ -462,6 +463,7 @@ static inline BrickParams<VT> make_brick_params(const MarchArgs &a, const Worksp
     P.g = make_brick_grid(a.VX, a.VY, a.VZ);
     P.seg_rgba = w.seg_rgba; P.seg_cnt = w.seg_cnt; P.rayflag = w.rayflag; P.stats = w.stats; P.ws_steps = w.ws_steps;
     P.use_live = a.use_live; P.ctx = w.ctx;
+    P.pp_l0 = a.pp_l0; P.pp_l1 = a.pp_l1; P.pp_first = a.pp_first;
     P.out = a.out; P.steps = a.steps;
     P.grad_out = a.grad_out; P.out_fwd = a.out_fwd;
     P.dvol.p = a.d_vol; P.dvol.sx = a.dsx; P.dvol.sy = a.dsy; P.dvol.sz = a.dsz; P.dvol_vs = a.dvol_vs;

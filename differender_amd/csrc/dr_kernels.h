@@ -21,6 +21,7 @@ struct MarchArgs {
     void *workspace; size_t workspace_bytes;
     const uint8_t *only_flagged;  // baseline backward: restrict to rays with a non-zero flag (may be null)
     int use_live;                 // forward: per-ray live sample counts are available (alpha pre-pass)
+    int pp_l0, pp_l1, pp_first;   // alpha pre-pass phase: brick layers [pp_l0, pp_l1); pp_first: no earlier phase
 };
 
 hipError_t launch_ray_setup(const float *cam, int n_views, int W, int H, int VX, int VY, int VZ, double fov_rad,
@@ -37,7 +38,8 @@ size_t brick_workspace_bytes(int n_views, int W, int H, int VX, int VY, int VZ);
 int launch_march_fwd_brick(const MarchArgs &a, hipStream_t stream);  // one lane per ray segment
 int launch_march_bwd_brick(const MarchArgs &a, hipStream_t stream);
 int launch_ray_compose(const MarchArgs &a, hipStream_t stream);      // F2, shared by the brick pipelines
-int launch_ray_alpha(const MarchArgs &a, hipStream_t stream);        // alpha pre-pass composition (exact termination)
+int launch_ray_alpha(const MarchArgs &a, hipStream_t stream);        // alpha pre-pass: per-ray composition of one phase
+int launch_ray_cross(const MarchArgs &a, hipStream_t stream);        // alpha pre-pass: exact termination sample of crossing rays
 bool flat_path_supported(int VX, int VY, int VZ, int R);
 bool flat_strides_ok(int64_t sx, int64_t sy, int64_t sz);  // 32-bit in-box offsets
 int launch_march_fwd_flat(const MarchArgs &a, hipStream_t stream);   // one lane per sample

@@ -221,36 +221,36 @@ __global__ __launch_bounds__(256) void ray_alpha_kernel(BrickParams<VT> P) {
     const int pl = blockIdx.x * 256 + threadIdx.x;
     if (pl >= NP) return;
     const size_t p = (size_t)view * NP + pl;
+    if (!P.pp_first && P.ws_steps[p] == -1) return;  // crossing found in an earlier phase
     RayGeom rg;
     load_ray(P.entry, P.exit_, P.rays, P.nsamp, p, rg);
     const int nmarch = (MODE == DR_MODE_DIFF && rg.n > P.S) ? P.S : rg.n;
-    int live = nmarch;
     if (ray_is_regular(rg.n, rg.entry)) {
+        // state carried from phase to phase in the (not yet written) output buffer: alpha so far, samples so far
+        float4 *park = reinterpret_cast<float4 *>(P.out) + p;
+        float A = 0.f;
+        int sacc = 0;
+        if (!P.pp_first) { const float4 st = *park; A = st.x; sacc = __float_as_int(st.y); }
         const size_t seg0 = (size_t)view * P.g.NL * NP + pl;
         const f3 cam = make_f3(P.cam[3 * view], P.cam[3 * view + 1], P.cam[3 * view + 2]);
-        const int l_lo = max(sample_layer(P, rg, cam, 0), 0);
-        const int l_hi = min(sample_layer(P, rg, cam, nmarch - 1), P.g.NL - 1);
-        int total = 0;
-        for (int l = l_lo; l <= l_hi; ++l) total += P.seg_cnt[seg0 + (size_t)l * NP];
-        if (total == nmarch) {  // otherwise: no culling for this ray, F2 will sort it out
-            float A = 0.f;
-            int sacc = 0;
-            for (int l = l_lo; l <= l_hi; ++l) {
-                const size_t si = seg0 + (size_t)l * NP;
-                const int cnt = P.seg_cnt[si];
-                if (cnt == 0) continue;
-                const float A_after = fmaf(1.0f - A, P.seg_rgba[si].w, A);
-                if (!(A_after < 0.99f)) {  // the crossing segment starts at sample sacc: resolved by ray_cross_kernel
-                    reinterpret_cast<float4 *>(P.out)[p] = make_float4(A, __int_as_float(sacc), 0.f, 0.f);
-                    live = -1;
-                    break;
-                }
-                A = A_after;
-                sacc += cnt;
+        const int l_lo = max(max(sample_layer(P, rg, cam, 0), 0), P.pp_l0);
+        const int l_hi = min(min(sample_layer(P, rg, cam, nmarch - 1), P.g.NL - 1), P.pp_l1 - 1);
+        for (int l = l_lo; l <= l_hi; ++l) {
+            const size_t si = seg0 + (size_t)l * NP;
+            const int cnt = P.seg_cnt[si];
+            if (cnt == 0) continue;
+            const float A_after = fmaf(1.0f - A, P.seg_rgba[si].w, A);
+            if (!(A_after < 0.99f)) {  // the crossing segment starts at sample sacc: resolved by ray_cross_kernel
+                *park = make_float4(A, __int_as_float(sacc), 0.f, 0.f);
+                P.ws_steps[p] = -1;
+                return;
             }
+            A = A_after;
+            sacc += cnt;
         }
+        *park = make_float4(A, __int_as_float(sacc), 0.f, 0.f);
     }
-    P.ws_steps[p] = live;
+    if (P.pp_first) P.ws_steps[p] = nmarch;  // alive (so far): every planned sample is live
 }
 
 // P2b: the rays whose accumulated alpha crosses 0.99 (ws_steps == -1, crossing segment and alpha before it parked in
@@ -483,26 +483,28 @@ int launch_ray_compose(const MarchArgs &a, hipStream_t stream) {
 }
 
 template <typename VT>
-static int ray_alpha_dispatch(const MarchArgs &a, hipStream_t stream) {
+static int ray_alpha_dispatch(const MarchArgs &a, hipStream_t stream, bool cross) {
     const BrickGrid g = make_brick_grid(a.VX, a.VY, a.VZ);
     const int NP = a.W * a.H;
     Workspace w;
     ws_layout(a.workspace, a.n_views, NP, g, &w);
     BrickParams<VT> P = make_brick_params<VT>(a, w);
-    const dim3 grid2((NP + 255) / 256, a.n_views);
-    const dim3 grid3((NP + 3) / 4, a.n_views);
+    const dim3 grid2((NP + 255) / 256, a.n_views), grid3((NP + 3) / 4, a.n_views);
     if (a.mode == DR_MODE_DIFF) {
-        hipLaunchKernelGGL((ray_alpha_kernel<VT, DR_MODE_DIFF>), grid2, dim3(256), 0, stream, P);
-        hipLaunchKernelGGL((ray_cross_kernel<VT, DR_MODE_DIFF>), grid3, dim3(256), 0, stream, P);
+        if (!cross) hipLaunchKernelGGL((ray_alpha_kernel<VT, DR_MODE_DIFF>), grid2, dim3(256), 0, stream, P);
+        else hipLaunchKernelGGL((ray_cross_kernel<VT, DR_MODE_DIFF>), grid3, dim3(256), 0, stream, P);
     } else {
-        hipLaunchKernelGGL((ray_alpha_kernel<VT, DR_MODE_NONDIFF>), grid2, dim3(256), 0, stream, P);
-        hipLaunchKernelGGL((ray_cross_kernel<VT, DR_MODE_NONDIFF>), grid3, dim3(256), 0, stream, P);
+        if (!cross) hipLaunchKernelGGL((ray_alpha_kernel<VT, DR_MODE_NONDIFF>), grid2, dim3(256), 0, stream, P);
+        else hipLaunchKernelGGL((ray_cross_kernel<VT, DR_MODE_NONDIFF>), grid3, dim3(256), 0, stream, P);
     }
     return (int)hipGetLastError();
 }
 
 int launch_ray_alpha(const MarchArgs &a, hipStream_t stream) {
-    return a.vol_dtype == DR_F16 ? ray_alpha_dispatch<__half>(a, stream) : ray_alpha_dispatch<float>(a, stream);
+    return a.vol_dtype == DR_F16 ? ray_alpha_dispatch<__half>(a, stream, false) : ray_alpha_dispatch<float>(a, stream, false);
+}
+int launch_ray_cross(const MarchArgs &a, hipStream_t stream) {
+    return a.vol_dtype == DR_F16 ? ray_alpha_dispatch<__half>(a, stream, true) : ray_alpha_dispatch<float>(a, stream, true);
 }
 
 int launch_march_fwd_brick(const MarchArgs &a, hipStream_t stream) {

@@ -224,7 +224,7 @@ __device__ __forceinline__ void cand_load(const BrickParams<VT> &P, const BrickC
     d.entry = P.entry[d.p];
     d.exit_ = P.exit_[d.p];
     d.vx = P.rays[3 * d.p]; d.vy = P.rays[3 * d.p + 1]; d.vz = P.rays[3 * d.p + 2];
-    if (BWD || (!ALPHA && P.use_live)) d.live = P.ws_steps[d.p];
+    if (BWD || (!ALPHA && P.use_live) || (ALPHA && !P.pp_first)) d.live = P.ws_steps[d.p];
     if (BWD) {  // (the three float4 of the coarse tape / gradients are fetched when the entry is written: the
         d.rflag = P.rayflag[d.p];  //  backward kernel is register-bound and they would be held across the box staging)
         d.scnt = P.seg_cnt[seg_base + d.pl];
@@ -252,6 +252,7 @@ __device__ __forceinline__ void flat_build_entries(const BrickParams<VT> &P, con
         int nmarch = (MODE == DR_MODE_DIFF && n > P.S) ? P.S : n;
         if (!BWD && !ALPHA && ok && P.use_live && P.stats[2 + view] != 0u)
             nmarch = min(nmarch, live);  // exact live count from the alpha pre-pass: dead samples are not marched
+        if (ALPHA && !P.pp_first && live == -1) ok = false;  // terminated in an earlier phase of the pre-pass
         if (BWD && ok) {
             ok = !d.rflag && d.scnt != 0;  // irregular ray / no sample in this brick
             nmarch = min(nmarch, live);
@@ -582,6 +583,7 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
     BrickCtx c;
     brick_ctx_load(P.ctx + (size_t)view * gridDim.x + blockIdx.x, c);  // uniform address: scalar loads
     if (c.i0 > c.i1 || c.j0 > c.j1) return;  // uniform: the brick projects outside the image
+    if (ALPHA && (c.layer < P.pp_l0 || c.layer >= P.pp_l1)) return;  // uniform: not in this phase of the pre-pass
 
     FlatLds L = flat_carve<BWD, WANT_VOL, WANT_TF>(smem, P.R);
     VolView<VT> vol = P.vol;
@@ -975,16 +977,29 @@ static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
         if (a.mode == DR_MODE_DIFF && n_max > a.S) n_max = a.S;
         hipLaunchKernelGGL(may_terminate_kernel, dim3(a.n_views), dim3(64), 0, stream, reinterpret_cast<const float4 *>(a.tf),
                            (long)(a.tf_vs / 4), a.R, 1.0f / a.sr, (float)n_max, w.stats + 2);
-        if (a.mode == DR_MODE_DIFF) {
-            if ((e = allow_lds(brick_flat_kernel<VT, DR_MODE_DIFF, false, false, false, true, DR_ALPHA_K>, lds)) != hipSuccess) return (int)e;
-            hipLaunchKernelGGL((brick_flat_kernel<VT, DR_MODE_DIFF, false, false, false, true, DR_ALPHA_K>), grid1, dim3(FNT_FWD), lds, stream, P);
-        } else {
-            if ((e = allow_lds(brick_flat_kernel<VT, DR_MODE_NONDIFF, false, false, false, true, DR_ALPHA_K>, lds)) != hipSuccess) return (int)e;
-            hipLaunchKernelGGL((brick_flat_kernel<VT, DR_MODE_NONDIFF, false, false, false, true, DR_ALPHA_K>), grid1, dim3(FNT_FWD), lds, stream, P);
+        // The pre-pass runs front to back in G groups of brick layers; after each group the rays that have reached
+        // alpha >= 0.99 are known and the next group does not march them (with the reference's tf1 preset three
+        // quarters of all samples lie behind the termination point): ground-truth renders at sampling rate 8 take
+        // 11.0 instead of 15.0 ms (8 views, 256^3). Each extra group costs the non-terminating case two empty
+        // launches (~10 us: +0.7 % on the 512^3 headline at G = 2 for -2.5 % with tf1), so below sampling rate 3: G = 1.
+        const int G = (a.sr >= 3.0f) ? 4 : 1;
+        MarchArgs pa = a;
+        for (int gi = 0; gi < G; ++gi) {
+            pa.pp_l0 = g.NL * gi / G; pa.pp_l1 = g.NL * (gi + 1) / G; pa.pp_first = gi == 0;
+            P.pp_l0 = pa.pp_l0; P.pp_l1 = pa.pp_l1; P.pp_first = pa.pp_first;
+            if (a.mode == DR_MODE_DIFF) {
+                if ((e = allow_lds(brick_flat_kernel<VT, DR_MODE_DIFF, false, false, false, true, DR_ALPHA_K>, lds)) != hipSuccess) return (int)e;
+                hipLaunchKernelGGL((brick_flat_kernel<VT, DR_MODE_DIFF, false, false, false, true, DR_ALPHA_K>), grid1, dim3(FNT_FWD), lds, stream, P);
+            } else {
+                if ((e = allow_lds(brick_flat_kernel<VT, DR_MODE_NONDIFF, false, false, false, true, DR_ALPHA_K>, lds)) != hipSuccess) return (int)e;
+                hipLaunchKernelGGL((brick_flat_kernel<VT, DR_MODE_NONDIFF, false, false, false, true, DR_ALPHA_K>), grid1, dim3(FNT_FWD), lds, stream, P);
+            }
+            if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+            const int rc = launch_ray_alpha(pa, stream);
+            if (rc) return rc;
         }
-        if ((e = hipGetLastError()) != hipSuccess) return (int)e;
-        const int rc = launch_ray_alpha(a, stream);
-        if (rc) return rc;
+        const int rc2 = launch_ray_cross(a, stream);
+        if (rc2) return rc2;
         if ((e = hipMemsetAsync(w.seg_cnt, 0, w.cnt_bytes, stream)) != hipSuccess) return (int)e;
     }
     MarchArgs b = a;
