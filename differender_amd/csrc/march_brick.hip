@@ -257,7 +257,8 @@ __global__ __launch_bounds__(256) void ray_alpha_kernel(BrickParams<VT> P) {
 // the not-yet-written output buffer). One WAVE per ray: 64 consecutive samples per pass -- positions, centre taps (the
 // lanes read neighbouring voxels) and TF lookups in parallel, then the exact sequential recurrence
 // A <- fma(1 - A, op_s, A) of VR.py:318-349 over the 64 opacities (a one-thread-per-ray loop spent ~370 dependent
-// global gathers per ray at sampling rate 8). Same decisions, same arithmetic as F2's own re-march.
+// global gathers per ray at sampling rate 8). Passes whose total transmittance keeps alpha clear of the threshold are
+// skipped with the (re-associated) wave product; the pass that can cross is evaluated in F2's sequential arithmetic.
 template <typename VT, int MODE>
 __global__ __launch_bounds__(256) void ray_cross_kernel(BrickParams<VT> P) {
     const int view = blockIdx.y;
@@ -288,6 +289,12 @@ __global__ __launch_bounds__(256) void ray_cross_kernel(BrickParams<VT> P) {
             op = (MODE == DR_MODE_NONDIFF && !(sm.a > 1e-3f)) ? 0.0f : sm.op;  // skipped sample: A unchanged (fma(T, 0, A) == A)
         }
         const int cnt = min(64, nmarch - base);
+        // Transmittance of the whole pass (wave product): if even its end stays clear of the threshold (by far more
+        // than re-association can move it) no sample of the pass terminates the ray -- skip the sequential part.
+        float Tw = 1.0f - op;  // inactive lanes: op = 0
+        for (int o = 32; o > 0; o >>= 1) Tw *= __shfl_xor(Tw, o);
+        const float A_end = fmaf(1.0f - A, 1.0f - Tw, A);
+        if (A < 0.99f && A_end < 0.99f - 1e-4f) { A = A_end; s += cnt; continue; }  // uniform
         for (int i = 0; i < cnt; ++i) {  // uniform
             if (!(A < 0.99f)) { done = true; break; }
             const float opi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(op), i));
