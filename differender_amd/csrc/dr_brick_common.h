@@ -36,6 +36,7 @@ struct BrickCtx {
     int ox, oy, oz;               // voxel index of LDS box element 0 along each axis (16*b - 1)
     float lo[3], hi[3];           // world AABB of the brick's cells, with slack
     int i0, i1, j0, j1;           // candidate pixel rectangle (inclusive); empty if i0 > i1
+    int live;                     // from the workspace record (see BrickCtxRec)
 };
 
 // BrickCtx as stored in the workspace (64 B): every workgroup of F1 / P1 / B1 reads its record with scalar loads
@@ -44,14 +45,16 @@ struct BrickCtxRec {
     int bx, by, bz, layer;
     float lo[3]; int i0;
     float hi[3]; int i1;
-    int j0, j1, pad0, pad1;
+    int j0, j1;
+    int live;   // set by the flat forward when the brick marched at least one sample of the view (backward skips the others)
+    int pad1;
 };
 __device__ __forceinline__ void brick_ctx_load(const BrickCtxRec *rec, BrickCtx &c) {
     const BrickCtxRec r = *rec;
     c.bx = r.bx; c.by = r.by; c.bz = r.bz; c.layer = r.layer;
     c.ox = c.bx * BRK - 1; c.oy = c.by * BRK - 1; c.oz = c.bz * BRK - 1;
     for (int k = 0; k < 3; ++k) { c.lo[k] = r.lo[k]; c.hi[k] = r.hi[k]; }
-    c.i0 = r.i0; c.i1 = r.i1; c.j0 = r.j0; c.j1 = r.j1;
+    c.i0 = r.i0; c.i1 = r.i1; c.j0 = r.j0; c.j1 = r.j1; c.live = r.live;
 }
 
 __device__ __forceinline__ f3 cross3b(f3 a, f3 b) {
@@ -100,9 +103,13 @@ __device__ __forceinline__ void brick_setup(const BrickParams<VT> &P, int b, f3 
     c.j0 = max(0, (int)floorf(pymin) - 1); c.j1 = min(P.H - 1, (int)ceilf(pymax) + 1);
 }
 
-// One thread per (brick, view): brick_setup once, for all passes of this forward/backward pair.
+// One thread per (brick, view): brick_setup once, for all passes of a forward/backward pair. The forward launches it
+// with forward = 1 (live flags cleared, DR_CTX_MARK left in stats[51]: "records and live flags are the flat
+// forward's"); the backward recomputes the geometry (it may follow a forward of another kernel variant) and keeps
+// the live flags, which its kernels only trust when the mark is there.
+constexpr unsigned int DR_CTX_MARK = 0x600DF1A7u;
 template <typename VT>
-static __global__ __launch_bounds__(256) void brick_ctx_kernel(BrickParams<VT> P, BrickCtxRec *out, int nbricks) {
+static __global__ __launch_bounds__(256) void brick_ctx_kernel(BrickParams<VT> P, BrickCtxRec *out, int nbricks, int forward) {
     const int b = blockIdx.x * 256 + threadIdx.x, view = blockIdx.y;
     if (b >= nbricks) return;
     const f3 cam = make_f3(P.cam[3 * view], P.cam[3 * view + 1], P.cam[3 * view + 2]);
@@ -111,8 +118,10 @@ static __global__ __launch_bounds__(256) void brick_ctx_kernel(BrickParams<VT> P
     BrickCtxRec r;
     r.bx = c.bx; r.by = c.by; r.bz = c.bz; r.layer = c.layer;
     for (int k = 0; k < 3; ++k) { r.lo[k] = c.lo[k]; r.hi[k] = c.hi[k]; }
-    r.i0 = c.i0; r.i1 = c.i1; r.j0 = c.j0; r.j1 = c.j1; r.pad0 = r.pad1 = 0;
+    r.i0 = c.i0; r.i1 = c.i1; r.j0 = c.j0; r.j1 = c.j1; r.pad1 = 0;
+    r.live = forward ? 0 : out[(size_t)view * nbricks + b].live;
     out[(size_t)view * nbricks + b] = r;
+    if (forward && b == 0 && view == 0) P.stats[51] = DR_CTX_MARK;
 }
 
 // Conservative sample-index range [s0, s1) of ray p inside the brick (exact membership is decided per

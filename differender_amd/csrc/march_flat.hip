@@ -584,6 +584,8 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
     brick_ctx_load(P.ctx + (size_t)view * gridDim.x + blockIdx.x, c);  // uniform address: scalar loads
     if (c.i0 > c.i1 || c.j0 > c.j1) return;  // uniform: the brick projects outside the image
     if (ALPHA && (c.layer < P.pp_l0 || c.layer >= P.pp_l1)) return;  // uniform: not in this phase of the pre-pass
+    // backward after a flat forward: bricks in which the forward marched nothing (rays terminated before them) have no work
+    if (BWD && !DR_PHASE_TIMING && c.live == 0 && P.stats[51] == DR_CTX_MARK) return;  // uniform
 
     FlatLds L = flat_carve<BWD, WANT_VOL, WANT_TF>(smem, P.R);
     VolView<VT> vol = P.vol;
@@ -893,10 +895,13 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
         }
         if (!BWD) {
             // sample counts of the segments this wave owns (only this wave added to them)
+            bool some = false;
             for (int e = ea + lane; e < eb; e += 64) {
                 const int v = L.valid[e];
-                if (v > 0) P.seg_cnt[seg_base + __float_as_int(L.ray1[e].w)] = v;
+                if (v > 0) { P.seg_cnt[seg_base + __float_as_int(L.ray1[e].w)] = v; some = true; }
             }
+            if (!ALPHA && __any(some) && lane == 0)  // tell the backward that this brick holds live samples of the view
+                const_cast<BrickCtxRec *>(P.ctx)[(size_t)view * gridDim.x + blockIdx.x].live = 1;
         }
         __syncthreads();
     }
@@ -967,7 +972,7 @@ static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     const size_t lds = flat_lds_bytes<false>(a.R, false, false);
     const int nbricks = g.NBx * g.NBy * g.NBz;
     const dim3 grid1(nbricks, a.n_views);
-    hipLaunchKernelGGL(brick_ctx_kernel<VT>, dim3((nbricks + 255) / 256, a.n_views), dim3(256), 0, stream, P, w.ctx, nbricks);
+    hipLaunchKernelGGL(brick_ctx_kernel<VT>, dim3((nbricks + 255) / 256, a.n_views), dim3(256), 0, stream, P, w.ctx, nbricks, 1);
     // Alpha pre-pass (early-termination culling): only if the TF can make some ray reach alpha >= 0.99 -- decided on
     // the device from max(alpha), the kernels of the pre-pass return at once otherwise.
     const bool prepass = a.n_views <= 48;
@@ -1038,6 +1043,7 @@ static int flat_bwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     const dim3 grid1(g.NBx * g.NBy * g.NBz, a.n_views);
     hipError_t e = hipMemsetAsync(w.stats + 1, 0, 4, stream);
     if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(brick_ctx_kernel<VT>, dim3((grid1.x + 255) / 256, a.n_views), dim3(256), 0, stream, P, w.ctx, (int)grid1.x, 0);
     const size_t ng = (size_t)a.n_views * NP * 4;
     const size_t nb = (ng + 256 * 16 - 1) / (256 * 16);
     hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(nb > 1024 ? 1024 : nb)), dim3(256), 0, stream, a.grad_out, ng,

@@ -461,3 +461,25 @@ def test_huge_strides_take_the_64bit_path(oracle, hiplib):
     assert ok, err
     ok, err = grad_close(dt_v.cpu().numpy(), dt_c.cpu().numpy())
     assert ok, err
+
+
+@pytest.mark.parametrize("vf,vb", [(2, 0), (0, 2)], ids=["rayseg-fwd_flat-bwd", "flat-fwd_rayseg-bwd"])
+def test_mixed_variants_share_a_workspace(oracle, hiplib, vf, vb):
+    """The workspace is a contract between any forward and any backward of the brick pipelines: the flat backward
+    must not rely on records only the flat forward writes (brick contexts, live flags)."""
+    from differender_amd import functional as Fn
+    vol_h, tf_h, cam_h = scene(oracle, N=40, R=32, tf="peaks")
+    WH = (48, 40)
+    vol, tf, cam = T(vol_h), T(tf_h), T(np.atleast_2d(cam_h))
+    e, x, r, n = Fn.ray_setup(cam, WH, vol.shape, 1.0)
+    ws = Fn.alloc_workspace(1, WH, vol.shape, tf.shape[0], dev())
+    ws.fill_(0x5A)                                        # stale bytes from "another call"
+    out, _ = Fn.march_fwd(vol, tf, cam, e, x, r, n, 4096, 1.0, variant=vf, workspace=ws)
+    g = T(np.random.default_rng(3).standard_normal(out.shape).astype(np.float32))
+    dv, dt = Fn.march_bwd(vol, tf, cam, e, x, r, n, 4096, 1.0, g, out, variant=vb, workspace=ws)
+    eh, xh, rh, nh = (t[0].cpu().numpy() for t in (e, x, r, n))
+    dv_o, dt_o = oracle.march_bwd(vol_h, tf_h, cam_h, eh, xh, rh, nh, 4096, 1.0, g[0].cpu().numpy())
+    ok, err = grad_close(dv.cpu().numpy(), dv_o)
+    assert ok, err
+    ok, err = grad_close(dt.cpu().numpy(), dt_o)
+    assert ok, err
