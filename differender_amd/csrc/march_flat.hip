@@ -600,15 +600,25 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
     CandData cd;
     cand_load<VT, MODE, BWD, ALPHA>(P, c, view, 0, ncand, seg_base, cd);  // ray buffers of the first round's candidates
     BoxStage<FNT> stage;
-    box_issue<VT, FNT>(P, vol, c, P.tf + view * P.tf_vs, stage);          // voxel box + TF: in flight ...
     FixScale fs;
-    if (BWD) {
-        if (WANT_VOL) for (int k = threadIdx.x; k < BOX_LDS; k += FNT) L.dbox[k] = 0ull;
-        if (WANT_TF) for (int k = threadIdx.x; k < 4 * P.R; k += FNT) L.dtf[k] = 0ull;
-        fs = make_fix_scale(P.stats[1]);
-    }
     int nE0, M0;
-    flat_build_entries<VT, MODE, BWD, FNT, ALPHA, KS>(P, c, cam, view, cd, seg_base, L, nE0, M0);  // ... while the segments are listed
+    // Forward after an alpha pre-pass that found terminating rays: many bricks lie entirely behind the termination
+    // points (likewise in the later groups of the pre-pass itself). List the segments first and leave without staging
+    // anything when there are none.
+    const bool lazy = (!BWD && !ALPHA && P.use_live && P.stats[2 + view] != 0u) || (ALPHA && !P.pp_first);  // uniform
+    if (lazy) {
+        flat_build_entries<VT, MODE, BWD, FNT, ALPHA, KS>(P, c, cam, view, cd, seg_base, L, nE0, M0);
+        if (nE0 == 0 && ncand <= EC) return;  // uniform
+        box_issue<VT, FNT>(P, vol, c, P.tf + view * P.tf_vs, stage);
+    } else {
+        box_issue<VT, FNT>(P, vol, c, P.tf + view * P.tf_vs, stage);      // voxel box + TF: in flight ...
+        if (BWD) {
+            if (WANT_VOL) for (int k = threadIdx.x; k < BOX_LDS; k += FNT) L.dbox[k] = 0ull;
+            if (WANT_TF) for (int k = threadIdx.x; k < 4 * P.R; k += FNT) L.dtf[k] = 0ull;
+            fs = make_fix_scale(P.stats[1]);
+        }
+        flat_build_entries<VT, MODE, BWD, FNT, ALPHA, KS>(P, c, cam, view, cd, seg_base, L, nE0, M0);  // ... while the segments are listed
+    }
     box_commit<VT, FNT>(P, vol, c, P.tf + view * P.tf_vs, stage, L);
     __syncthreads();
 #if DR_PHASE_TIMING
