@@ -47,6 +47,9 @@ constexpr int FNT_BWD = DR_FNT_BWD;     // (backward: 66 KB of LDS, 128 VGPRs ->
 #ifndef DR_FWD_K
 #define DR_FWD_K 2      // forward: samples per lane at sampling rates below 3
 #endif
+#ifndef DR_PP_GROUPS
+#define DR_PP_GROUPS 6   // layer groups of the alpha pre-pass at sampling rates >= 3
+#endif
 #ifndef DR_ALPHA_K
 #define DR_ALPHA_K 4    // alpha pre-pass
 #endif
@@ -997,7 +1000,7 @@ static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
         // quarters of all samples lie behind the termination point): ground-truth renders at sampling rate 8 take
         // 11.0 instead of 15.0 ms (8 views, 256^3). Each extra group costs the non-terminating case two empty
         // launches (~10 us: +0.7 % on the 512^3 headline at G = 2 for -2.5 % with tf1), so below sampling rate 3: G = 1.
-        const int G = (a.sr >= 3.0f) ? 4 : 1;
+        const int G = (a.sr >= 3.0f) ? DR_PP_GROUPS : 1;
         MarchArgs pa = a;
         for (int gi = 0; gi < G; ++gi) {
             pa.pp_l0 = g.NL * gi / G; pa.pp_l1 = g.NL * (gi + 1) / G; pa.pp_first = gi == 0;
