@@ -45,7 +45,7 @@ constexpr int FNT_BWD = DR_FNT_BWD;     // (backward: 66 KB of LDS, 128 VGPRs ->
 #define DR_PHASE_TIMING 0
 #endif
 #ifndef DR_FWD_K
-#define DR_FWD_K 2      // forward: samples per lane at sampling rates below 3
+#define DR_FWD_K 2      // forward: samples per lane at sampling rates below 1.75
 #endif
 #ifndef DR_PP_GROUPS
 #define DR_PP_GROUPS 6   // layer groups of the alpha pre-pass at sampling rates >= 3
@@ -54,7 +54,7 @@ constexpr int FNT_BWD = DR_FNT_BWD;     // (backward: 66 KB of LDS, 128 VGPRs ->
 #define DR_ALPHA_K 4    // alpha pre-pass
 #endif
 #ifndef DR_FWD_K_HI
-#define DR_FWD_K_HI 4   // ... and at 3 and above
+#define DR_FWD_K_HI 4   // ... and at 1.75 and above
 #endif
 #ifndef DR_BWD_PREFETCH
 #define DR_BWD_PREFETCH 1
@@ -1025,13 +1025,13 @@ static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     P.use_live = b.use_live;
     // Samples per lane: the cross-lane scan and the chunk bookkeeping are paid once per K*64 samples, but lanes K
     // samples apart share fewer LDS words (more read cycles, more bank conflicts). Measured at 512^3: K = 2 wins up
-    // to sampling rate ~3 (-3 % at 1, -10 % at 2), K = 4 beyond (-6 % at 4, -8 % at 8: samples are closer together).
+    // at sampling rate 1 (-3 %), K = 4 from 2 on (-13 % at 2, -16 % at 4 and 8 vs K = 1: samples are closer together); K = 8 loses.
 #define DR_LAUNCH_F1(MODE_, K_)                                                                                      \
     {                                                                                                                \
         if ((e = allow_lds(brick_flat_kernel<VT, MODE_, false, false, false, false, K_>, lds)) != hipSuccess) return (int)e; \
         hipLaunchKernelGGL((brick_flat_kernel<VT, MODE_, false, false, false, false, K_>), grid1, dim3(FNT_FWD), lds, stream, P); \
     }
-    const bool k_hi = a.sr >= 3.0f;
+    const bool k_hi = a.sr >= 1.75f;
     if (a.mode == DR_MODE_DIFF) { if (k_hi) DR_LAUNCH_F1(DR_MODE_DIFF, DR_FWD_K_HI) else DR_LAUNCH_F1(DR_MODE_DIFF, DR_FWD_K) }
     else { if (k_hi) DR_LAUNCH_F1(DR_MODE_NONDIFF, DR_FWD_K_HI) else DR_LAUNCH_F1(DR_MODE_NONDIFF, DR_FWD_K) }
 #undef DR_LAUNCH_F1
