@@ -75,7 +75,7 @@ struct FlatLds {
     float4 *ray1;   // (vx, vy, vz, bits(pixel index))
     float4 *pre, *go, *of;  // backward: composite before the segment, upstream gradient, forward output
     int *s_rel;     // first sample index of the segment minus its flat offset
-    int *offs;      // [EC+1] exclusive prefix of the segment lengths (flat index of each segment's first sample)
+    int *offs;      // per wave: flat index of each segment's first sample, then the wave's total (index entry + wave)
     int *valid;     // in-brick samples of each segment (forward)
     int *slen;      // forward: true length of the segment (its flat extent is padded to a multiple of FWD_K)
     int *live;      // backward: live sample count of the ray
@@ -89,7 +89,7 @@ __host__ __device__ constexpr size_t flat_fixed_bytes(bool want_vol) {
     size_t s = ((size_t)BOX_LDS * 4 + 15) / 16 * 16;
     if (BWD && want_vol) s += ((size_t)BOX_LDS * 8 + 15) / 16 * 16;
     s += (size_t)EC * 32 + ((BWD && !BWD_TABLES_GLOBAL) ? (size_t)EC * 48 : 0);
-    s += (size_t)EC * 4 + (((size_t)EC + 1) * 4 + 15) / 16 * 16 + (size_t)EC * 4 + (size_t)EC * 4 + 128;  // (live | slen)
+    s += (size_t)EC * 4 + (((size_t)EC + 8) * 4 + 15) / 16 * 16 + (size_t)EC * 4 + (size_t)EC * 4 + 128;  // (live | slen)
     return s;
 }
 template <bool BWD>
@@ -112,7 +112,7 @@ __device__ __forceinline__ FlatLds flat_carve(unsigned char *smem, int R) {
         L.of = reinterpret_cast<float4 *>(smem + o); o += (size_t)EC * 16;
     }
     L.s_rel = reinterpret_cast<int *>(smem + o); o += (size_t)EC * 4;
-    L.offs = reinterpret_cast<int *>(smem + o); o += align16((EC + 1) * 4);
+    L.offs = reinterpret_cast<int *>(smem + o); o += align16((EC + 8) * 4);  // per wave: its entries' offsets + end marker
     L.valid = reinterpret_cast<int *>(smem + o); o += (size_t)EC * 4;
     L.slen = nullptr;
     if (BWD) { L.live = reinterpret_cast<int *>(smem + o); o += (size_t)EC * 4; }
@@ -213,10 +213,14 @@ template <typename VT, int MODE, bool BWD, bool ALPHA>
 __device__ __forceinline__ void cand_load(const BrickParams<VT> &P, const BrickCtx &c, int view, int cbase, int ncand,
                                           size_t seg_base, CandData &d) {
     constexpr int EC = BWD ? FEC_BWD : FEC_FWD;
+    constexpr int FNW = (BWD ? FNT_BWD : FNT_FWD) / 64, CW = EC / FNW;  // candidates per wave and round
     const int NP = P.W * P.H;
     const int nj = c.j1 - c.j0 + 1;
-    const int cc = cbase + threadIdx.x;
-    d.have = (int)threadIdx.x < EC && cc < ncand;
+    // wave w looks at the candidates cbase + w, cbase + w + FNW, ...: neighbouring pixels (similar segment lengths) go
+    // to different waves, so the waves of a workgroup get statistically equal shares of the brick's samples
+    const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
+    const int cc = cbase + lane_ * FNW + wave_;
+    d.have = lane_ < CW && cc < ncand;
     d.pl = 0; d.p = 0; d.n = 0; d.entry = -1.0f; d.exit_ = 0.f; d.vx = d.vy = d.vz = 0.f;
     d.live = 0; d.scnt = 0; d.rflag = 0;
     if (!d.have) return;
@@ -234,15 +238,28 @@ __device__ __forceinline__ void cand_load(const BrickParams<VT> &P, const BrickC
     }
 }
 
-// List the ray segments of the round's candidates and their flat offsets. Returns (nE, M).
+// inclusive sum of an int over the wave (DPP; lanes without a source add 0)
+__device__ __forceinline__ int wave_incl_sum(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+// List the ray segments of this WAVE's candidates of the round and their flat offsets: every wave keeps its own
+// segment table (entries [wave*CW, wave*CW + nE), offsets at index entry + wave so that each table has its end
+// marker) and its own flat sample space [0, M). No workgroup barrier, no serial phase: the compaction is a ballot,
+// the offsets a DPP scan. Slots follow the candidate order, so the flat sample order -- and with it every
+// rounding -- is reproducible.
 template <typename VT, int MODE, bool BWD, int FNT, bool ALPHA = false, int KS = 1>
 __device__ __forceinline__ void flat_build_entries(const BrickParams<VT> &P, const BrickCtx &c, f3 cam, int view,
                                                    const CandData &d, size_t seg_base, FlatLds &L, int &nE, int &M) {
     constexpr int EC = BWD ? FEC_BWD : FEC_FWD;
-    constexpr int FNW = FNT / 64;
-    static_assert(EC <= FNT, "one candidate per thread and round");
-    // each thread examines at most one candidate pixel; slots are handed out in candidate order
-    // (ballot compaction), so the flat sample order -- and with it every rounding -- is reproducible
+    constexpr int FNW = FNT / 64, CW = EC / FNW;
+    static_assert(CW <= 64 && CW * FNW == EC, "one candidate per lane and round");
     bool has = false;
     int s0 = 0, s1 = 0;
     float t0 = 0.f, nm1 = 0.f;
@@ -268,22 +285,17 @@ __device__ __forceinline__ void flat_build_entries(const BrickParams<VT> &P, con
     }
     const unsigned long long hm = __ballot(has);
     const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
-    if (lane_ == 0) L.misc[4 + wave_] = __popcll(hm);
-    __syncthreads();
-    int base = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < FNW; ++w) {
-        const int cw = L.misc[4 + w];
-        if (w < wave_) base += cw;
-        total += cw;
-    }
-    nE = total;
+    const int flen = has ? (s1 - s0 + KS - 1) / KS * KS : 0;  // flat length: a multiple of KS
+    const int incl = wave_incl_sum(flen);
+    nE = __popcll(hm);
+    M = __builtin_amdgcn_readlane(incl, 63);
     if (has) {
-        const int slot = base + __popcll(hm & ((1ull << lane_) - 1ull));
+        const int slot = wave_ * CW + __popcll(hm & ((1ull << lane_) - 1ull));
+        const int off = incl - flen;
         L.ray0[slot] = make_float4(t0, exit_, nm1, 1.0f / nm1);  // n >= 2 (ray_is_regular)
         L.ray1[slot] = make_float4(vd.x, vd.y, vd.z, __int_as_float(pl));
-        L.s_rel[slot] = s0;           // turned into s0 - offs below
-        L.offs[slot + 1] = (s1 - s0 + KS - 1) / KS * KS;   // flat length (a multiple of KS); prefix-summed below
+        L.s_rel[slot] = s0 - off;
+        L.offs[slot + wave_] = off;
         if (!BWD) L.slen[slot] = s1 - s0;
         L.valid[slot] = 0;
         if (BWD) {
@@ -295,53 +307,11 @@ __device__ __forceinline__ void flat_build_entries(const BrickParams<VT> &P, con
             L.live[slot] = live;
         }
     }
-    __syncthreads();
-    // exclusive prefix sum of the lengths by wave 0: each lane owns EC/64 consecutive entries
-    if (threadIdx.x < 64) {
-        constexpr int PER = EC / 64;
-        int loc[PER];
-        int sum = 0;
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int e = threadIdx.x * PER + k;
-            loc[k] = (e < nE) ? L.offs[e + 1] : 0;
-            sum += loc[k];
-        }
-        int incl = sum;
-        for (int d = 1; d < 64; d <<= 1) {
-            const int o = __shfl_up(incl, d);
-            if ((int)threadIdx.x >= d) incl += o;
-        }
-        int run = incl - sum;
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int e = threadIdx.x * PER + k;
-            if (e < nE) { L.offs[e] = run; L.s_rel[e] -= run; }
-            run += loc[k];
-        }
-        if (threadIdx.x == 63) { L.offs[nE] = run; L.misc[1] = run; }
-        // wave split: wave w starts at the first entry whose flat offset is >= M*w/FNW, i.e. at the NUMBER of
-        // entries below that target (offsets are sorted). Found here from the registers of the scan instead of a
-        // binary search over LDS by every wave (16 dependent LDS round trips per workgroup).
-        const int Mtot = __builtin_amdgcn_readlane(run, 63);
-        int first = run;  // recomputed below: offset of this lane's first entry
-#pragma unroll
-        for (int k = 0; k < PER; ++k) first -= loc[k];
-#pragma unroll
-        for (int w = 1; w < FNW; ++w) {
-            const int target = (int)(((long long)Mtot * w) / FNW);
-            int c = 0, o = first;
-#pragma unroll
-            for (int k = 0; k < PER; ++k) {
-                c += ((int)threadIdx.x * PER + k < nE && o < target) ? 1 : 0;
-                o += loc[k];
-            }
-            const int nfull = __popcll(__ballot(c == PER));  // lanes entirely below the target form a prefix
-            if ((int)threadIdx.x == min(nfull, 63)) L.misc[16 + w] = (nfull == 64) ? 64 * PER : nfull * PER + c;
-        }
-    }
-    __syncthreads();
-    M = L.misc[1];
+    if (lane_ == 0) L.offs[wave_ * CW + nE + wave_] = M;  // end marker of this wave's table
+    // the table is read back by other lanes of the SAME wave only: LDS operations of a wave complete in order
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 struct Over { float c0, c1, c2, a; };  // premultiplied composite element
@@ -611,7 +581,7 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
     const bool lazy = (!BWD && !ALPHA && P.use_live && P.stats[2 + view] != 0u) || (ALPHA && !P.pp_first);  // uniform
     if (lazy) {
         flat_build_entries<VT, MODE, BWD, FNT, ALPHA, KS>(P, c, cam, view, cd, seg_base, L, nE0, M0);
-        if (nE0 == 0 && ncand <= EC) return;  // uniform
+        if (!__syncthreads_or(nE0 > 0) && ncand <= EC) return;  // uniform: no wave found a segment
         box_issue<VT, FNT>(P, vol, c, P.tf + view * P.tf_vs, stage);
     } else {
         box_issue<VT, FNT>(P, vol, c, P.tf + view * P.tf_vs, stage);      // voxel box + TF: in flight ...
@@ -638,12 +608,12 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
             flat_build_entries<VT, MODE, BWD, FNT, ALPHA, KS>(P, c, cam, view, cd, seg_base, L, nE, M);  // syncs inside
         }
         any = any || nE > 0;
-        // this wave owns the contiguous entry range [ea, eb): segments never straddle two waves
-        const int ea = (wave == 0) ? 0 : L.misc[16 + wave];
-        const int eb = (wave == FNW - 1) ? nE : L.misc[16 + wave + 1];
-        const int fa = L.offs[ea], fb = L.offs[eb];
+        // this wave's own segment table: entries [ea, eb), flat samples [0, M); offsets live at index entry + wave
+        const int ea = wave * (EC / FNW), eb = ea + nE;
+        const int fa = 0, fb = M;
+        const int *offs = L.offs + wave;
 #if DR_PHASE_TIMING
-        if (cbase == 0) { asm volatile("" :: "v"(fa), "v"(fb)); tk2 = clock64(); }
+        if (cbase == 0) tk2 = clock64();
 #endif
         Over carry = {0.f, 0.f, 0.f, 0.f};
         int carry_e = -1;  // entry whose composite so far is in `carry` (continues into the next chunk)
@@ -656,9 +626,9 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
             const int f = f0 + KS * lane;
             const bool act = f < fb;
             // entry of this lane: advance from the previous chunk's entry (flat order is entry order)
-            if (act) { while (f >= L.offs[e_cur + 1]) ++e_cur; }
+            if (act) { while (f >= offs[e_cur + 1]) ++e_cur; }
             const int e = act ? e_cur : eb - 1;
-            const int eoff = L.offs[e];
+            const int eoff = offs[e];
             const int sl = max(lane - (f - eoff) / KS, 0);  // first lane of this lane's segment within the chunk
             const float4 r0 = L.ray0[e], r1 = L.ray1[e];
             const int s = f + L.s_rel[e];
@@ -704,10 +674,10 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
                 {
                     const int e_last = __builtin_amdgcn_readlane(e, 63);
                     const float lastT = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Tl), 63));
-                    const bool more = (f0 + 64 * KS < fb) && (L.offs[e_last + 1] > f0 + 64 * KS);
+                    const bool more = (f0 + 64 * KS < fb) && (offs[e_last + 1] > f0 + 64 * KS);
                     carry.a = lastT; carry_e = more ? e_last : -1;
                 }
-                const bool seg_end = act && (f + KS >= L.offs[e + 1]);
+                const bool seg_end = act && (f + KS >= offs[e + 1]);
                 // in-brick samples of the piece [sl, lane]: inclusive lane-sum of the per-lane counts
                 float cf[1] = {(float)cnt_lane};
                 seg_scan_sum<1>(cf, lane, sl);
@@ -789,10 +759,10 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
             {
                 const int e_last = __builtin_amdgcn_readlane(e, 63);
                 const Over last = readlane_over(inc, 63);
-                const bool more = (f0 + 64 * KS < fb) && (L.offs[e_last + 1] > f0 + 64 * KS);
+                const bool more = (f0 + 64 * KS < fb) && (offs[e_last + 1] > f0 + 64 * KS);
                 carry = last; carry_e = more ? e_last : -1;
             }
-            const bool seg_end = act && (f + KS >= L.offs[e + 1]);
+            const bool seg_end = act && (f + KS >= offs[e + 1]);
             if (!BWD) {
                 // count the in-brick samples of each segment piece, store finished segments
                 const bool piece_end = act && (seg_end || lane == 63 || f + KS >= fb);
@@ -916,7 +886,6 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
             if (!ALPHA && __any(some) && lane == 0)  // tell the backward that this brick holds live samples of the view
                 const_cast<BrickCtxRec *>(P.ctx)[(size_t)view * gridDim.x + blockIdx.x].live = 1;
         }
-        __syncthreads();
     }
 #if DR_PHASE_TIMING
     if (!ALPHA && threadIdx.x == 0) {  // per-phase clocks of this workgroup, summed over the grid (tools/phase_times.py)
@@ -927,7 +896,8 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
         atomicAdd(tt + 2, (unsigned long long)(tk3 - tk2));   // sample loop (+ further rounds)
     }
 #endif
-    if (!BWD || !any) return;  // uniform
+    if (!BWD) return;
+    if (!__syncthreads_or(any)) return;  // uniform; also: every wave's LDS adds are done before the flush
     // flush: one pass of global float atomics per brick, walking the gradient's fastest axis
     if (WANT_VOL) {
         GradView dv = P.dvol;
