@@ -79,7 +79,6 @@ struct FlatLds {
     int *valid;     // in-brick samples of each segment (forward)
     int *slen;      // forward: true length of the segment (its flat extent is padded to a multiple of FWD_K)
     int *live;      // backward: live sample count of the ray
-    int *misc;
 };
 // LDS layout: everything of compile-time size first (so every address below is an immediate), then the two
 // tables whose size depends on the run-time TF resolution R.
@@ -89,7 +88,7 @@ __host__ __device__ constexpr size_t flat_fixed_bytes(bool want_vol) {
     size_t s = ((size_t)BOX_LDS * 4 + 15) / 16 * 16;
     if (BWD && want_vol) s += ((size_t)BOX_LDS * 8 + 15) / 16 * 16;
     s += (size_t)EC * 32 + ((BWD && !BWD_TABLES_GLOBAL) ? (size_t)EC * 48 : 0);
-    s += (size_t)EC * 4 + (((size_t)EC + 8) * 4 + 15) / 16 * 16 + (size_t)EC * 4 + (size_t)EC * 4 + 128;  // (live | slen)
+    s += (size_t)EC * 4 + (((size_t)EC + 8) * 4 + 15) / 16 * 16 + (size_t)EC * 4 + (size_t)EC * 4;  // (live | slen)
     return s;
 }
 template <bool BWD>
@@ -117,7 +116,6 @@ __device__ __forceinline__ FlatLds flat_carve(unsigned char *smem, int R) {
     L.slen = nullptr;
     if (BWD) { L.live = reinterpret_cast<int *>(smem + o); o += (size_t)EC * 4; }
     else { L.slen = reinterpret_cast<int *>(smem + o); o += (size_t)EC * 4; }
-    L.misc = reinterpret_cast<int *>(smem + o); o += 128;  // 32 ints: [1] M, [4 + wave] per-wave entry counts, [16 + wave] first entry of a wave
     L.tf = reinterpret_cast<float4 *>(smem + o); o += (size_t)R * 16;
     if (BWD && WANT_TF) L.dtf = reinterpret_cast<unsigned long long *>(smem + o);
     return L;
