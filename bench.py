@@ -199,8 +199,11 @@ def main():
                 "bytes_per_voxel_step": bytes_per_step, "voxel_steps_per_launch": int(steps_per_launch)}
 
     # HBM bytes per launch from the latest committed PMC profile (collected with tools/profile_round.sh in
-    # separate --pmc passes: FETCH_SIZE, WRITE_SIZE). FETCH_SIZE is reported raw: the guide's x2 correction applies
-    # to 16-B-per-lane streaming reads, these kernels read 4-B elements in 19-element rows (uncalibrated width).
+    # separate --pmc passes: FETCH_SIZE, WRITE_SIZE). FETCH_SIZE counts 128-B fabric requests at 64 B on gfx950: it is
+    # doubled, as the MI355X guide prescribes. Calibrated on this access pattern (tools/microbench/fetch_calib.hip,
+    # profiles/r01_fetch_calibration.txt): a 512 MiB stream of 16-B loads reads exactly 1/2, and the brick staging
+    # pattern (15-float rows, 4 B per lane) tallies its 128-B line requests the same way. Memory-side requests
+    # include infinity-cache hits, so this is an upper bound on HBM bytes.
     traffic = {}
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_per_launch.json")))
@@ -209,7 +212,7 @@ def main():
                 targs = [t.strip(" >") for t in k.split("<")[1].split(",")]  # <VT, MODE, BWD, VOL, TF, ALPHA>
                 if len(targs) >= 6 and targs[5] == "true":
                     continue  # the (gated) alpha pre-pass
-                traffic["bwd" if targs[2] == "true" else "fwd"] = int((v["FETCH_SIZE"] + v.get("WRITE_SIZE", 0)) * 1024)
+                traffic["bwd" if targs[2] == "true" else "fwd"] = int((2.0 * v["FETCH_SIZE"] + v.get("WRITE_SIZE", 0)) * 1024)
     except Exception:
         pass
     roof_fwd = roof("march_fwd", fwd_ms, B_FWD)
