@@ -330,6 +330,9 @@ __device__ __forceinline__ void load_ray(const float *entry, const float *exit_,
 
 // ---- 64-bit fixed point for the LDS accumulators -------------------------------------------------------
 // value = x * 2^shift, stored as a two's-complement int64. fx_hi = 2^(shift-32) is passed around as a float.
+#ifndef DR_FIX_BITS
+#define DR_FIX_BITS 28
+#endif
 struct FixScale {
     float hi;    // 2^(shift-32): x*hi has the high word in its integer part, the low word in its fraction
     float lo;    // 2^shift
@@ -341,7 +344,7 @@ __device__ __forceinline__ FixScale make_fix_scale(unsigned int gmax_bits) {
     if (!(gmax > 0.0f) || !(gmax < 3.0e38f)) gmax = 1.0f;  // all-zero or non-finite upstream gradient
     int e;
     frexpf(gmax, &e);            // gmax < 2^e
-    const int shift = 28 - e;    // gmax * 2^shift < 2^28
+    const int shift = DR_FIX_BITS - e;    // gmax * 2^shift < 2^DR_FIX_BITS
     FixScale f;
     f.hi = ldexpf(1.0f, shift - 32);
     f.lo = ldexpf(1.0f, shift);
