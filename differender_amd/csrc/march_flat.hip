@@ -47,6 +47,9 @@ constexpr int FNT_BWD = DR_FNT_BWD;     // (backward: 66 KB of LDS, 128 VGPRs ->
 #ifndef DR_FWD_K
 #define DR_FWD_K 2      // forward: samples per lane at sampling rates below 1.75
 #endif
+#ifndef DR_SETPRIO
+#define DR_SETPRIO 1
+#endif
 #ifndef DR_PP_GROUPS
 #define DR_PP_GROUPS 6   // layer groups of the alpha pre-pass at sampling rates >= 3
 #endif
@@ -558,6 +561,9 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
     // backward after a flat forward: bricks in which the forward marched nothing (rays terminated before them) have no work
     if (BWD && !DR_PHASE_TIMING && c.live == 0 && P.stats[51] == DR_CTX_MARK) return;  // uniform
 
+#if DR_SETPRIO
+    __builtin_amdgcn_s_setprio(3);  // the staging / listing prologue is short and latency-bound: let it overtake sample loops
+#endif
     FlatLds L = flat_carve<BWD, WANT_VOL, WANT_TF>(smem, P.R);
     VolView<VT> vol = P.vol;
     vol.p += view * P.vol_vs;
@@ -594,6 +600,9 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
     __syncthreads();
 #if DR_PHASE_TIMING
     const long long tk1 = clock64();
+#endif
+#if DR_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
 #endif
     const f3 light = make_f3(cam.x + 0.0f, cam.y + 1.0f, cam.z + 0.0f);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
