@@ -38,9 +38,6 @@ constexpr int FNT_BWD = DR_FNT_BWD;     // (backward: 66 KB of LDS, 128 VGPRs ->
 #ifndef DR_FEC_BWD
 #define DR_FEC_BWD 256
 #endif
-#ifndef DR_BWD_TABLES_GLOBAL
-#define DR_BWD_TABLES_GLOBAL 1
-#endif
 #ifndef DR_PHASE_TIMING
 #define DR_PHASE_TIMING 0
 #endif
@@ -59,16 +56,6 @@ constexpr int FNT_BWD = DR_FNT_BWD;     // (backward: 66 KB of LDS, 128 VGPRs ->
 #ifndef DR_FWD_K_HI
 #define DR_FWD_K_HI 4   // ... and at 1.75 and above
 #endif
-#ifndef DR_BWD_PREFETCH
-#define DR_BWD_PREFETCH 1
-#endif
-#ifndef DR_RUN_REDUCE
-#define DR_RUN_REDUCE 0
-#endif
-#ifndef DR_BWD_REBUILD_TAPS
-#define DR_BWD_REBUILD_TAPS 0
-#endif
-constexpr bool BWD_TABLES_GLOBAL = DR_BWD_TABLES_GLOBAL != 0;  // per-ray backward inputs from global memory, not LDS
 constexpr int FEC_FWD = DR_FEC_FWD;      // ray segments listed per round (<= threads: one candidate per thread)
 constexpr int FEC_BWD = DR_FEC_BWD;      // (backward: the entry table also holds prefix / gradient / output)
 
@@ -76,7 +63,6 @@ struct FlatLds {
     float4 *tf; float *box; unsigned long long *dbox; unsigned long long *dtf;
     float4 *ray0;   // (t0, exit, (float)(n-1), RN(1/(n-1)))
     float4 *ray1;   // (vx, vy, vz, bits(pixel index))
-    float4 *pre, *go, *of;  // backward: composite before the segment, upstream gradient, forward output
     int *s_rel;     // first sample index of the segment minus its flat offset
     int *offs;      // per wave: flat index of each segment's first sample, then the wave's total (index entry + wave)
     int *valid;     // in-brick samples of each segment (forward)
@@ -90,7 +76,7 @@ __host__ __device__ constexpr size_t flat_fixed_bytes(bool want_vol) {
     constexpr int EC = BWD ? FEC_BWD : FEC_FWD;
     size_t s = ((size_t)BOX_LDS * 4 + 15) / 16 * 16;
     if (BWD && want_vol) s += ((size_t)BOX_LDS * 8 + 15) / 16 * 16;
-    s += (size_t)EC * 32 + ((BWD && !BWD_TABLES_GLOBAL) ? (size_t)EC * 48 : 0);
+    s += (size_t)EC * 32;
     s += (size_t)EC * 4 + (((size_t)EC + 8) * 4 + 15) / 16 * 16 + (size_t)EC * 4 + (size_t)EC * 4;  // (live | slen)
     return s;
 }
@@ -104,15 +90,10 @@ __device__ __forceinline__ FlatLds flat_carve(unsigned char *smem, int R) {
     FlatLds L;
     size_t o = 0;
     L.box = reinterpret_cast<float *>(smem + o); o += align16(BOX_LDS * 4);
-    L.dbox = nullptr; L.dtf = nullptr; L.pre = L.go = L.of = nullptr; L.live = nullptr;
+    L.dbox = nullptr; L.dtf = nullptr; L.live = nullptr;
     if (BWD && WANT_VOL) { L.dbox = reinterpret_cast<unsigned long long *>(smem + o); o += align16(BOX_LDS * 8); }
     L.ray0 = reinterpret_cast<float4 *>(smem + o); o += (size_t)EC * 16;
     L.ray1 = reinterpret_cast<float4 *>(smem + o); o += (size_t)EC * 16;
-    if (BWD && !BWD_TABLES_GLOBAL) {
-        L.pre = reinterpret_cast<float4 *>(smem + o); o += (size_t)EC * 16;
-        L.go = reinterpret_cast<float4 *>(smem + o); o += (size_t)EC * 16;
-        L.of = reinterpret_cast<float4 *>(smem + o); o += (size_t)EC * 16;
-    }
     L.s_rel = reinterpret_cast<int *>(smem + o); o += (size_t)EC * 4;
     L.offs = reinterpret_cast<int *>(smem + o); o += align16((EC + 8) * 4);  // per wave: its entries' offsets + end marker
     L.valid = reinterpret_cast<int *>(smem + o); o += (size_t)EC * 4;
@@ -299,14 +280,7 @@ __device__ __forceinline__ void flat_build_entries(const BrickParams<VT> &P, con
         L.offs[slot + wave_] = off;
         if (!BWD) L.slen[slot] = s1 - s0;
         L.valid[slot] = 0;
-        if (BWD) {
-            if (!BWD_TABLES_GLOBAL) {
-                L.pre[slot] = P.seg_rgba[seg_base + pl];
-                L.go[slot] = reinterpret_cast<const float4 *>(P.grad_out)[d.p];
-                L.of[slot] = reinterpret_cast<const float4 *>(P.out_fwd)[d.p];
-            }
-            L.live[slot] = live;
-        }
+        if (BWD) L.live[slot] = live;
     }
     if (lane_ == 0) L.offs[wave_ * CW + nE + wave_] = M;  // end marker of this wave's table
     // the table is read back by other lanes of the SAME wave only: LDS operations of a wave complete in order
@@ -359,11 +333,7 @@ __device__ __forceinline__ Over dpp0_over(const Over &v) {
 }
 // x = T*x + o in x's own register (the compiler's choice, v_fmac into the DPP temporary, needs a move back per channel)
 __device__ __forceinline__ void fma_into(float &x, float T, float o) {
-#ifdef DR_NO_ASM_FMA
-    x = fmaf(T, x, o);
-#else
     asm("v_fma_f32 %0, %1, %0, %2" : "+v"(x) : "v"(T), "v"(o));
-#endif
 }
 // segmented inclusive scan of "over": segments are runs of lanes sharing sl
 __device__ __forceinline__ Over seg_scan_over(Over v, int lane, int sl) {
@@ -425,17 +395,11 @@ __device__ __forceinline__ Over readlane_over(const Over &v, int lane) {
 }
 // whole-wave shifts by one lane with DPP (wave_shr:1 = 0x138, wave_shl:1 = 0x130; gfx9 family): lane 0 / lane 63
 // keep the `edge` value. No LDS crossbar traffic, unlike __shfl_up/__shfl_down (ds_bpermute).
-#ifdef DR_NO_WAVE_SHIFT
-__device__ __forceinline__ float wave_up1(float v, float edge) { const float r = __shfl_up(v, 1); return (threadIdx.x & 63) ? r : edge; }
-__device__ __forceinline__ int wave_up1(int v, int edge) { const int r = __shfl_up(v, 1); return (threadIdx.x & 63) ? r : edge; }
-__device__ __forceinline__ int wave_down1(int v, int edge) { const int r = __shfl_down(v, 1); return ((threadIdx.x & 63) != 63) ? r : edge; }
-#else
 __device__ __forceinline__ float wave_up1(float v, float edge) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), 0x138, 0xf, 0xf, false));
 }
 __device__ __forceinline__ int wave_up1(int v, int edge) { return __builtin_amdgcn_update_dpp(edge, v, 0x138, 0xf, 0xf, false); }
 __device__ __forceinline__ int wave_down1(int v, int edge) { return __builtin_amdgcn_update_dpp(edge, v, 0x130, 0xf, 0xf, false); }
-#endif
 __device__ __forceinline__ Over shfl_up1_over(const Over &v) {
     Over r;
     r.c0 = wave_up1(v.c0, 0.f); r.c1 = wave_up1(v.c1, 0.f); r.c2 = wave_up1(v.c2, 0.f); r.a = wave_up1(v.a, 0.f);
@@ -512,35 +476,9 @@ __device__ __forceinline__ void scatter_sample(unsigned long long *dbox, const T
         if (valid && (hi || lo)) scatter4<WIDE, BOX_SX, BOX_SY>(dbox, cbase_i + (hi ? 2 : -1), hi ? cz[3] : cz[0], XY, fs);
         if (__any(valid && hi && lo)) { if (valid && hi && lo) scatter4<WIDE, BOX_SX, BOX_SY>(dbox, cbase_i - 1, cz[0], XY, fs); }
     }
-    // Consecutive lanes are consecutive samples of a ray, ~3.5 per cell at sampling rate 1: their adds hit the same
-    // eight addresses, and the LDS serialises equal addresses (~7 cycles per duplicate, profiles/r01_microbench_*).
-    // Sum each run of lanes that share the cell first (runs are cut at 8-lane groups: three row_shr steps) and let
-    // the last lane of the run do the adds.
-    {
-        const int lane = threadIdx.x & 63, p = lane & 7;
-        const int ckey = valid ? cbase_i : -1 - lane;
-        const int kprev = __builtin_amdgcn_update_dpp(0, ckey, 0x111, 0xf, 0xf, true);  // row_shr:1
-        const unsigned long long starts = __ballot(p == 0 || ckey != kprev);
-        const unsigned int g = (unsigned int)(starts >> (lane & ~7)) & 0xffu;   // this 8-lane group's run starts
-        const int dist = p - (31 - __clz((int)(g & ((2u << p) - 1u))));        // lanes since the run start
-        const bool run_end = p == 7 || ((g >> (p + 1)) & 1u);
-#define DR_RUN_STEP(CTRL, D)                                                       \
-        {                                                                          \
-            const bool ok = dist >= D;                                             \
-            _Pragma("unroll") for (int q = 0; q < 8; ++q) {                        \
-                const float o = dpp0_f<CTRL>(acc[q]);                              \
-                acc[q] = ok ? acc[q] + o : acc[q];                                 \
-            }                                                                      \
-        }
-#if DR_RUN_REDUCE
-        DR_RUN_STEP(0x111, 1) DR_RUN_STEP(0x112, 2) DR_RUN_STEP(0x114, 4)
-        if (valid && run_end) scatter8<WIDE>(dbox, cbase_i, acc, fs);
-#else
-        (void)dist; (void)run_end;
-        if (valid) scatter8<WIDE>(dbox, cbase_i, acc, fs);
-#endif
-#undef DR_RUN_STEP
-    }
+    // (Consecutive lanes are consecutive samples of a ray, ~3.5 per cell: these eight adds collide in the LDS, ~7 cycles
+    // per duplicate address. Summing the runs across lanes first was tried twice: +1.0 ms of VALU for 0.4 ms of LDS.)
+    if (valid) scatter8<WIDE>(dbox, cbase_i, acc, fs);
 }
 
 // ALPHA (forward only): the alpha pre-pass -- centre tap + TF only, the partial of a segment is its accumulated alpha.
@@ -625,11 +563,7 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
         Over carry = {0.f, 0.f, 0.f, 0.f};
         int carry_e = -1;  // entry whose composite so far is in `carry` (continues into the next chunk)
         int e_cur = ea;
-#ifdef DR_ABL_NOLOOP
-        for (int f0 = fa; f0 < fa; f0 += 64 * KS) {
-#else
         for (int f0 = fa; f0 < fb; f0 += 64 * KS) {
-#endif
             const int f = f0 + KS * lane;
             const bool act = f < fb;
             // entry of this lane: advance from the previous chunk's entry (flat order is entry order)
@@ -640,16 +574,14 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
             const float4 r0 = L.ray0[e], r1 = L.ray1[e];
             const int s = f + L.s_rel[e];
             const f3 vd = make_f3(r1.x, r1.y, r1.z);
-#if DR_BWD_PREFETCH
             // backward: the per-ray inputs of the adjoint are requested now and consumed ~800 issue cycles later
             float4 pf_pre = make_float4(0.f, 0.f, 0.f, 0.f), pf_go = pf_pre, pf_of = pf_pre;
-            if (BWD && BWD_TABLES_GLOBAL && act) {
+            if (BWD && act) {
                 const int plq = __float_as_int(r1.w);
                 pf_pre = P.seg_rgba[seg_base + plq];
                 pf_go = reinterpret_cast<const float4 *>(P.grad_out)[(size_t)view * NP + plq];
                 pf_of = reinterpret_cast<const float4 *>(P.out_fwd)[(size_t)view * NP + plq];
             }
-#endif
             if (ALPHA) {
                 // alpha pre-pass: position, centre cell, one tap, TF -> transmittance; nothing else.
                 // KS consecutive samples per lane, multiplied up in registers before the cross-lane product scan.
@@ -790,16 +722,8 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
                 ad.r_bar = ad.g_bar = ad.b_bar = ad.a_bar = 0.f; ad.gx = ad.gy = ad.gz = 0.f; ad.Lop = 0.f;
                 float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (valid) {
-                    float4 pre, of;
-#if DR_BWD_PREFETCH
-                    if (BWD_TABLES_GLOBAL) { pre = pf_pre; go = pf_go; of = pf_of; } else
-#endif
-                    if (BWD_TABLES_GLOBAL) {  // lanes of a chunk share a few rays: these are broadcast-like cached loads
-                        const int plq = __float_as_int(r1.w);
-                        pre = P.seg_rgba[seg_base + plq];
-                        go = reinterpret_cast<const float4 *>(P.grad_out)[(size_t)view * NP + plq];
-                        of = reinterpret_cast<const float4 *>(P.out_fwd)[(size_t)view * NP + plq];
-                    } else { pre = L.pre[e]; go = L.go[e]; of = L.of[e]; }
+                    const float4 pre = pf_pre, of = pf_of;  // lanes of a chunk share a few rays: broadcast-like cached loads
+                    go = pf_go;
                     const Over preo = {pre.x, pre.y, pre.z, pre.w};
                     const Over absi = over(preo, inc);                       // composite up to and including s
                     const float T = (1.0f - pre.w) * (1.0f - exc.a);         // transmittance before s
@@ -863,13 +787,6 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
                     // suffices unless some adjoint of the wave exceeds 2^31 / 2^shift (then: exact wide path).
                     // the 24 tap coordinates are cheap to rebuild from the position (45 VALU) and expensive to keep
                     // alive across shading and the adjoint (the kernel is register-bound: spills go to scratch)
-#if DR_BWD_REBUILD_TAPS
-                    {
-                        float qx = sm.px, qy = sm.py, qz = sm.pz;
-                        asm volatile("" : "+v"(qx), "+v"(qy), "+v"(qz));
-                        if (valid) tap_coords(vol, c, qx, qy, qz, t);
-                    }
-#endif
                     const int cbase_i = valid ? (t.lx * BOX_SX + t.ly * BOX_SY + t.lz) : 0;
                     float I_bar = 0.f;
                     float gq[3] = {0.f, 0.f, 0.f};
@@ -877,7 +794,7 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
                         I_bar = fix_clamp(intensity_adjoint(sm, L.tf[sm.lo], L.tf[sm.hi], ad, P.tf_len), fs);
                         if (!sm.flat) { gq[0] = fix_clamp(ad.gx, fs); gq[1] = fix_clamp(ad.gy, fs); gq[2] = fix_clamp(ad.gz, fs); }
                     }
-                    const float bound = (DR_RUN_REDUCE ? 8.0f : 1.0f) * (fabsf(I_bar) + (fabsf(gq[0]) + fabsf(gq[1]) + fabsf(gq[2])));
+                    const float bound = fabsf(I_bar) + (fabsf(gq[0]) + fabsf(gq[1]) + fabsf(gq[2]));
                     if (__any(!fix_fits(bound, fs))) scatter_sample<true>(L.dbox, t, valid, cbase_i, I_bar, gq, fs);
                     else scatter_sample<false>(L.dbox, t, valid, cbase_i, I_bar, gq, fs);
                 }
