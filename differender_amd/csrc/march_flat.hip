@@ -129,8 +129,12 @@ __device__ __forceinline__ BoxWalk make_box_walk(long long sx, long long sy, lon
     w.base = (long long)c.ox * sx + (long long)c.oy * sy + (long long)c.oz * sz;
     return w;
 }
-// row r (0 .. BOX*BOX-1) -> (b, d): r / 15 == (r * 4370) >> 16 for r < 4000 (checked exhaustively)
-__device__ __forceinline__ void box_row(int r, int &b, int &d) { static_assert(BOX == 15, "magic divisor"); d = (r * 4370) >> 16; b = r - d * BOX; }
+// row r (0 .. BOX*BOX-1) -> (b, d): r / BOX == (r * (65536 / BOX + 1)) >> 16 for r < 4000 (checked exhaustively for
+// BOX = 15, 19, 23)
+__device__ __forceinline__ void box_row(int r, int &b, int &d) {
+    static_assert(BOX == 15 || BOX == 19 || BOX == 23, "magic divisor checked for these box edges only");
+    d = (r * (65536 / BOX + 1)) >> 16; b = r - d * BOX;
+}
 
 // Staging of the brick's voxel box (and the TF) in LDS, in two halves: box_issue() puts all global loads in flight
 // (one register per pass), box_commit() stores them to LDS. The caller lists the brick's ray segments in between,
