@@ -240,7 +240,8 @@ __global__ __launch_bounds__(256) void ray_alpha_kernel(BrickParams<VT> P) {
             const int cnt = P.seg_cnt[si];
             if (cnt == 0) continue;
             const float A_after = fmaf(1.0f - A, P.seg_rgba[si].w, A);
-            if (!(A_after < 0.99f)) {  // the crossing segment starts at sample sacc: resolved by ray_cross_kernel
+            if (!(A_after < 0.99f - 1e-5f)) {  // the crossing segment (with a margin for the re-associated partials)
+                                              // starts at sample sacc: resolved by ray_cross_kernel
                 *park = make_float4(A, __int_as_float(sacc), 0.f, 0.f);
                 P.ws_steps[p] = -1;
                 return;
@@ -276,31 +277,45 @@ __global__ __launch_bounds__(256) void ray_cross_kernel(BrickParams<VT> P) {
     vol.p += view * P.vol_vs;
     const float4 *tfg = P.tf + view * P.tf_vs;
     const f3 cam = make_f3(P.cam[3 * view], P.cam[3 * view + 1], P.cam[3 * view + 2]);
+    // Round 1 starts at the crossing segment with the alpha the (re-associated) partial composites give, ~1e-7 off
+    // the sequential value. If the decision it reaches is closer to the threshold than that error could matter
+    // (2e-6), round 2 repeats the recurrence from the first sample in exact sequential arithmetic -- the decision
+    // is then the oracle's, bit for bit (deviation D3 of DESIGN.md does not arise on this path).
     float A = parked.x;
     int s = __float_as_int(parked.y);
-    bool done = false;
-    for (int base = s; base < nmarch && !done; base += 64) {
-        const int sl = base + lane;
-        float op = 0.0f;
-        if (sl < nmarch) {
-            Sample sm;
-            sample_pos(rg, cam.x, cam.y, cam.z, sl, sm.px, sm.py, sm.pz);
-            classify(vol, tfg, P.R, P.tf_len, P.inv_sr, sm);
-            op = (MODE == DR_MODE_NONDIFF && !(sm.a > 1e-3f)) ? 0.0f : sm.op;  // skipped sample: A unchanged (fma(T, 0, A) == A)
+    for (int round = 0; round < 2; ++round) {
+        float A_prev = A;
+        bool done = false;
+        for (int base = s; base < nmarch && !done; base += 64) {
+            const int sl = base + lane;
+            float op = 0.0f;
+            if (sl < nmarch) {
+                Sample sm;
+                sample_pos(rg, cam.x, cam.y, cam.z, sl, sm.px, sm.py, sm.pz);
+                classify(vol, tfg, P.R, P.tf_len, P.inv_sr, sm);
+                op = (MODE == DR_MODE_NONDIFF && !(sm.a > 1e-3f)) ? 0.0f : sm.op;  // skipped sample: A unchanged (fma(T, 0, A) == A)
+            }
+            const int cnt = min(64, nmarch - base);
+            if (round == 0) {
+                // Transmittance of the whole pass (wave product): if even its end stays clear of the threshold (by far
+                // more than re-association can move it) no sample of the pass terminates the ray: skip the sequential part.
+                float Tw = 1.0f - op;  // inactive lanes: op = 0
+                for (int o = 32; o > 0; o >>= 1) Tw *= __shfl_xor(Tw, o);
+                const float A_end = fmaf(1.0f - A, 1.0f - Tw, A);
+                if (A < 0.99f && A_end < 0.99f - 1e-4f) { A_prev = A = A_end; s += cnt; continue; }  // uniform
+            }
+            for (int i = 0; i < cnt; ++i) {  // uniform
+                if (!(A < 0.99f)) { done = true; break; }
+                const float opi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(op), i));
+                A_prev = A;
+                A = fmaf(1.0f - A, opi, A);
+                ++s;
+            }
         }
-        const int cnt = min(64, nmarch - base);
-        // Transmittance of the whole pass (wave product): if even its end stays clear of the threshold (by far more
-        // than re-association can move it) no sample of the pass terminates the ray -- skip the sequential part.
-        float Tw = 1.0f - op;  // inactive lanes: op = 0
-        for (int o = 32; o > 0; o >>= 1) Tw *= __shfl_xor(Tw, o);
-        const float A_end = fmaf(1.0f - A, 1.0f - Tw, A);
-        if (A < 0.99f && A_end < 0.99f - 1e-4f) { A = A_end; s += cnt; continue; }  // uniform
-        for (int i = 0; i < cnt; ++i) {  // uniform
-            if (!(A < 0.99f)) { done = true; break; }
-            const float opi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(op), i));
-            A = fmaf(1.0f - A, opi, A);
-            ++s;
-        }
+        // decided at A (>= 0.99, or the ray ran out of samples) with A_prev (< 0.99) before it
+        const bool ambiguous = fabsf(A - 0.99f) < 2e-6f || fabsf(A_prev - 0.99f) < 2e-6f;
+        if (round == 1 || !ambiguous) break;  // uniform
+        A = 0.0f; s = 0;
     }
     if (lane == 0) P.ws_steps[p] = s;
 }

@@ -116,10 +116,30 @@ def test_early_termination_at_full_size(scene):
     outb, stepsb, _ = _fwd(scene, 1, tf=tf)
     n = scene["rays"][3]
     assert float((steps0 < n).float().mean()) > 0.5
-    same = steps0 == stepsb
-    assert float(same.float().mean()) > 0.999
-    assert float((out0 - outb).abs().amax(-1)[same].max()) <= 1e-5
-    assert float((out0 - outb).abs().max()) <= 2e-3
+    # decisions closer to the threshold than re-association can move alpha are re-taken in exact sequential
+    # arithmetic (ray_cross_kernel): every ray stops at the same sample as in the sequential kernels
+    assert torch.equal(steps0, stepsb), int((steps0 != stepsb).sum())
+    assert float((out0 - outb).abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize("mode,sr", [(0, 1.0), (1, 2.0)], ids=["diff_sr1", "nondiff_sr2"])
+def test_termination_decisions_match_sequential_kernels(scene, mode, sr):
+    """The reference's tf1 preset (most rays terminate) from three more cameras, differentiable and non-differentiable:
+    sample counts identical to the sequential (oracle-twin) kernels for every ray, images within 1e-5."""
+    from differender_amd.utils import get_tf
+    import bench
+    F = scene["F"]
+    tf = get_tf("tf1", R).t().contiguous().to(scene["dev"])
+    ws = F.alloc_workspace(1, (IMG, IMG), (N, N, N), R, scene["dev"])
+    for ci in (0.9, 2.3, 4.1):
+        cam = torch.tensor([bench.in_circles(ci)], dtype=torch.float32, device=scene["dev"])
+        rays = F.ray_setup(cam, (IMG, IMG), (N, N, N), sr)
+        out0, steps0 = F.march_fwd(scene["vol"], tf, cam, *rays, 1 << 20, sr, mode, workspace=ws)
+        outb, stepsb = F.march_fwd(scene["vol"], tf, cam, *rays, 1 << 20, sr, mode, variant=1)
+        assert int(F.workspace_stats(ws)[0]) == 0
+        assert float((steps0 < rays[3]).float().mean()) > 0.5
+        assert torch.equal(steps0, stepsb), (ci, int((steps0 != stepsb).sum()))
+        assert float((out0 - outb).abs().max()) <= 1e-5, ci
 
 
 def test_config_c2_256_forward_only(hiplib, oracle):
