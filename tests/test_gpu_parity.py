@@ -483,3 +483,33 @@ def test_mixed_variants_share_a_workspace(oracle, hiplib, vf, vb):
     assert ok, err
     ok, err = grad_close(dt.cpu().numpy(), dt_o)
     assert ok, err
+
+
+def test_many_views_without_prepass(oracle, hiplib):
+    """More than 48 views in one call: the per-view termination flags do not fit the workspace header, the alpha
+    pre-pass is skipped and F2 resolves early termination itself. Results must still match the oracle."""
+    from differender_amd import functional as Fn
+    vol_h = oracle.synth_volume(24)
+    tf_h = oracle.peaks_tf(32)
+    V, WH = 50, (12, 10)
+    cams_h = np.stack([oracle.in_circles(0.37 * v) for v in range(V)]).astype(np.float32)
+    vol, tf, cams = T(vol_h), T(tf_h), T(cams_h)
+    e, x, r, n = Fn.ray_setup(cams, WH, vol.shape, 1.0)
+    ws = Fn.alloc_workspace(V, WH, vol.shape, tf.shape[0], dev())
+    out, steps = Fn.march_fwd(vol, tf, cams, e, x, r, n, 4096, 1.0, workspace=ws)
+    g = torch.ones_like(out)
+    dv, dt = Fn.march_bwd(vol, tf, cams, e, x, r, n, 4096, 1.0, g, out, workspace=ws)
+    dv_ref = np.zeros_like(vol_h); dt_ref = np.zeros_like(tf_h)
+    for v in (0, 17, 49):
+        eh, xh, rh, nh = (t[v].cpu().numpy() for t in (e, x, r, n))
+        ref, sref = oracle.march_fwd(vol_h, tf_h, cams_h[v], eh, xh, rh, nh, 4096, 1.0, 0)
+        assert np.abs(out[v].cpu().numpy() - ref).max() <= FWD_TOL
+        assert np.array_equal(steps[v].cpu().numpy(), sref)
+    for v in range(V):
+        eh, xh, rh, nh = (t[v].cpu().numpy() for t in (e, x, r, n))
+        a, b = oracle.march_bwd(vol_h, tf_h, cams_h[v], eh, xh, rh, nh, 4096, 1.0, np.ones((WH[0], WH[1], 4), np.float32))
+        dv_ref += a; dt_ref += b
+    ok, err = grad_close(dv.cpu().numpy(), dv_ref)
+    assert ok, err
+    ok, err = grad_close(dt.cpu().numpy(), dt_ref)
+    assert ok, err
