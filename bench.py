@@ -73,6 +73,9 @@ def main():
                     help="bench: constant alpha (no early termination, the headline); tf1: the reference's preset "
                          "(UT.py:9-21) -- empty ranges and early termination, reported separately")
     ap.add_argument("--views", type=int, default=1, help="views per rank per step (one native batched launch)")
+    ap.add_argument("--split", default="views", choices=["views", "rows"],
+                    help="N > 1: 'views' = one view per rank per step (weak scaling, the default); 'rows' = ONE view per "
+                         "step split into N bands of image rows (strong scaling, SURVEY 8(e))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-img", type=int, default=224, help="image edge of the bounded CPU-baseline sample")
     args = ap.parse_args()
@@ -115,28 +118,32 @@ def main():
         tf = get_tf("tf1", R).t().contiguous().to(dev)
     gen = torch.Generator(device="cpu").manual_seed(4321)
     V = args.views
-    target = torch.rand((1, IMG, IMG, 4), generator=gen).to(dev).expand(V, IMG, IMG, 4).contiguous()
+    from differender_amd.distributed import shard_rows
+    bands = args.split == "rows" and world > 1
+    row0, ROWS = shard_rows(IMG, rank, world) if bands else (0, IMG)
+    rows_arg = (row0, IMG) if bands else None
+    target = torch.rand((1, IMG, IMG, 4), generator=gen).to(dev)[:, row0:row0 + ROWS].expand(V, ROWS, IMG, 4).contiguous()
     loss_acc = torch.zeros((), dtype=torch.float64, device=dev)
     S = 1 << 20  # tape-free: no depth limit needed
     sr = 1.0
     total_steps = torch.zeros((), dtype=torch.int64, device=dev)
     ev = {"fwd": [], "bwd": []}
     # scratch of the brick-centric kernels (coarse tape); allocated once, reused by every step
-    ws = F.alloc_workspace(V, (IMG, IMG), (N, N, N), R, dev) if args.variant == 0 else None
+    ws = F.alloc_workspace(V, (ROWS, IMG), (N, N, N), R, dev) if args.variant == 0 else None
 
     # all camera positions are uploaded before the timed region (a host->device copy inside the loop would
     # synchronise the stream every step)
     nstep_total = args.warmup + args.steps
-    cams_all = torch.tensor([[in_circles(0.1 * ((k * world + rank) * V + i)) for i in range(V)]
+    cams_all = torch.tensor([[in_circles(0.1 * ((k if bands else k * world + rank) * V + i)) for i in range(V)]
                              for k in range(nstep_total)], dtype=torch.float32, device=dev)
 
     def step(k, timed):
         cam = cams_all[k]
-        e, x, r, n = F.ray_setup(cam, (IMG, IMG), (N, N, N), sr)
+        e, x, r, n = F.ray_setup(cam, (ROWS, IMG), (N, N, N), sr, rows=rows_arg)
         # (warm-up steps run the very same host code, events included: their first use has a one-time host cost)
         a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a0.record()
-        out, steps = F.march_fwd(vol, tf, cam, e, x, r, n, S, sr, variant=args.variant, workspace=ws)
+        out, steps = F.march_fwd(vol, tf, cam, e, x, r, n, S, sr, variant=args.variant, workspace=ws, rows=rows_arg)
         a1.record()
         if timed:
             ev["fwd"].append((a0, a1))
@@ -145,7 +152,7 @@ def main():
             b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             b0.record()
             dv, dt = F.march_bwd(vol, tf, cam, e, x, r, n, S, sr, grad_out, out, want_vol=want_vol, want_tf=want_tf,
-                                 variant=args.variant, workspace=ws)
+                                 variant=args.variant, workspace=ws, rows=rows_arg)
             b1.record()
             if timed:
                 ev["bwd"].append((b0, b1))
@@ -238,12 +245,13 @@ def main():
             "unit": "Mvoxel-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if bands else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{workload}; {N}^3 f32 volume, {IMG}^2 image, {R}-entry TF, sr=1.0, "
                                    f"{V} view(s) per rank per step, orbit cameras in_circles(0.1*v), jitter off",
                        "volume": N, "image": IMG, "tf_res": R, "views_per_rank_per_step": V,
-                       "parallelism": f"view-sharded x{world}" + (" + RCCL all-reduce(d_vol,d_tf)" if world > 1 else ""),
+                       "parallelism": (f"one view in {world} row bands" if bands else f"view-sharded x{world}") +
+                                      (" + RCCL all-reduce(d_vol,d_tf)" if world > 1 else ""),
                        "passes_per_voxel_step": passes, "kernel_variant": args.variant, "tf": args.tf},
             "voxel_steps_per_step": int(vsteps / max(args.steps, 1)),
             "roofline": dominant, "roofline_fwd": roof_fwd, "roofline_bwd": roof_bwd,

@@ -26,6 +26,11 @@ SIGNATURES = {
                           _I, _I, _I, _I, _F, _D, _D, _I, _I, _P, _P, _P, _Z, _P]),
     "dr_march_bwd": (_I, [_P, _I, _I, _I, _I, _L, _L, _L, _L, _P, _I, _L, _P, _P, _P, _P, _P,
                           _I, _I, _I, _I, _F, _D, _D, _I, _P, _P, _P, _L, _L, _L, _L, _P, _L, _P, _Z, _P]),
+    "dr_ray_setup_rows": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _D, _D, _F, _U, _U, _P, _P, _P, _P, _P]),
+    "dr_march_fwd_rows": (_I, [_P, _I, _I, _I, _I, _L, _L, _L, _L, _P, _I, _L, _P, _P, _P, _P, _P,
+                               _I, _I, _I, _I, _F, _D, _D, _I, _I, _P, _P, _P, _Z, _I, _I, _P]),
+    "dr_march_bwd_rows": (_I, [_P, _I, _I, _I, _I, _L, _L, _L, _L, _P, _I, _L, _P, _P, _P, _P, _P,
+                               _I, _I, _I, _I, _F, _D, _D, _I, _P, _P, _P, _L, _L, _L, _L, _P, _L, _P, _Z, _I, _I, _P]),
     "dr_mse_loss_grad": (_I, [_P, _P, _L, _F, _P, _P, _P]),
     "dr_tf_momentum_step": (_I, [_P, _P, _P, _I, _F, _F, _F, _P]),
 }
@@ -46,7 +51,7 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.dr_abi_version() != 3:
+        if handle.dr_abi_version() != 4:
             raise ImportError("libdifferender_hip.so ABI version mismatch; rebuild it")
         _lib = handle
     return _lib

@@ -28,14 +28,22 @@ size_t dr_workspace_bytes(int n_views, int W, int H, int VX, int VY, int VZ, int
     return brick_workspace_bytes(n_views, W, H, VX, VY, VZ);
 }
 
-int dr_ray_setup(const float *cam, int n_views, int W, int H, int VX, int VY, int VZ, double fov_rad,
-                 double near_plane, float sampling_rate, uint32_t jitter_seed, uint32_t view_base, float *entry,
-                 float *exit_, float *rays, int32_t *nsamp, void *stream) {
+int dr_ray_setup_rows(const float *cam, int n_views, int W, int H, int img_W, int row0, int VX, int VY, int VZ,
+                      double fov_rad, double near_plane, float sampling_rate, uint32_t jitter_seed, uint32_t view_base,
+                      float *entry, float *exit_, float *rays, int32_t *nsamp, void *stream) {
     if (!cam || !entry || !exit_ || !rays || !nsamp) return DR_EINVAL;
     if (n_views <= 0 || W <= 0 || H <= 0 || VX < 2 || VY < 2 || VZ < 2) return DR_EINVAL;
     if (n_views > 65535 || !(sampling_rate > 0.0f)) return DR_EINVAL;
-    return (int)launch_ray_setup(cam, n_views, W, H, VX, VY, VZ, fov_rad, near_plane, sampling_rate, jitter_seed,
-                                 view_base, entry, exit_, rays, nsamp, (hipStream_t)stream);
+    if (row0 < 0 || img_W < W || row0 > img_W - W) return DR_EINVAL;
+    return (int)launch_ray_setup(cam, n_views, W, H, img_W, row0, VX, VY, VZ, fov_rad, near_plane, sampling_rate,
+                                 jitter_seed, view_base, entry, exit_, rays, nsamp, (hipStream_t)stream);
+}
+
+int dr_ray_setup(const float *cam, int n_views, int W, int H, int VX, int VY, int VZ, double fov_rad,
+                 double near_plane, float sampling_rate, uint32_t jitter_seed, uint32_t view_base, float *entry,
+                 float *exit_, float *rays, int32_t *nsamp, void *stream) {
+    return dr_ray_setup_rows(cam, n_views, W, H, W, 0, VX, VY, VZ, fov_rad, near_plane, sampling_rate, jitter_seed,
+                             view_base, entry, exit_, rays, nsamp, stream);
 }
 
 static int fill_common(MarchArgs &a, const void *vol, int vol_dtype, int VX, int VY, int VZ, int64_t sx, int64_t sy,
@@ -56,16 +64,19 @@ static int fill_common(MarchArgs &a, const void *vol, int vol_dtype, int VX, int
     return 0;
 }
 
-int dr_march_fwd(const void *vol, int vol_dtype, int VX, int VY, int VZ, int64_t sx, int64_t sy, int64_t sz,
+int dr_march_fwd_rows(const void *vol, int vol_dtype, int VX, int VY, int VZ, int64_t sx, int64_t sy, int64_t sz,
                  int64_t vol_view_stride, const float *tf, int R, int64_t tf_view_stride, const float *cam,
                  const float *entry, const float *exit_, const float *rays, const int32_t *nsamp, int n_views, int W,
                  int H, int max_samples, float sampling_rate, double fov_rad, double near_plane, int mode, int variant,
-                 float *out_rgba, int32_t *steps, void *workspace, size_t workspace_bytes, void *stream) {
+                 float *out_rgba, int32_t *steps, void *workspace, size_t workspace_bytes, int img_W, int row0,
+                      void *stream) {
     MarchArgs a;
     int rc = fill_common(a, vol, vol_dtype, VX, VY, VZ, sx, sy, sz, vol_view_stride, tf, R, tf_view_stride, cam,
                          entry, exit_, rays, nsamp, n_views, W, H, max_samples, sampling_rate);
     if (rc) return rc;
     if (!out_rgba) return DR_EINVAL;
+    if (row0 < 0 || img_W < W || row0 > img_W - W) return DR_EINVAL;
+    a.img_W = img_W; a.row0 = row0;
     if (mode != DR_MODE_DIFF && mode != DR_MODE_NONDIFF) return DR_EINVAL;
     if (variant < DR_VARIANT_AUTO || variant > DR_VARIANT_BRICK_RAYSEG) return DR_EINVAL;
     a.mode = mode; a.out = out_rgba; a.steps = steps;
@@ -79,18 +90,30 @@ int dr_march_fwd(const void *vol, int vol_dtype, int VX, int VY, int VZ, int64_t
     return launch_march_fwd_baseline(a, (hipStream_t)stream);
 }
 
-int dr_march_bwd(const void *vol, int vol_dtype, int VX, int VY, int VZ, int64_t sx, int64_t sy, int64_t sz,
+int dr_march_fwd(const void *vol, int vol_dtype, int VX, int VY, int VZ, int64_t sx, int64_t sy, int64_t sz,
+                 int64_t vol_view_stride, const float *tf, int R, int64_t tf_view_stride, const float *cam,
+                 const float *entry, const float *exit_, const float *rays, const int32_t *nsamp, int n_views, int W,
+                 int H, int max_samples, float sampling_rate, double fov_rad, double near_plane, int mode, int variant,
+                 float *out_rgba, int32_t *steps, void *workspace, size_t workspace_bytes, void *stream) {
+    return dr_march_fwd_rows(vol, vol_dtype, VX, VY, VZ, sx, sy, sz, vol_view_stride, tf, R, tf_view_stride, cam, entry,
+                             exit_, rays, nsamp, n_views, W, H, max_samples, sampling_rate, fov_rad, near_plane, mode,
+                             variant, out_rgba, steps, workspace, workspace_bytes, W, 0, stream);
+}
+
+int dr_march_bwd_rows(const void *vol, int vol_dtype, int VX, int VY, int VZ, int64_t sx, int64_t sy, int64_t sz,
                  int64_t vol_view_stride, const float *tf, int R, int64_t tf_view_stride, const float *cam,
                  const float *entry, const float *exit_, const float *rays, const int32_t *nsamp, int n_views, int W,
                  int H, int max_samples, float sampling_rate, double fov_rad, double near_plane, int variant,
                  const float *grad_out, const float *out_rgba, float *d_vol, int64_t dsx, int64_t dsy, int64_t dsz,
                  int64_t dvol_view_stride, float *d_tf, int64_t dtf_view_stride, void *workspace,
-                 size_t workspace_bytes, void *stream) {
+                 size_t workspace_bytes, int img_W, int row0, void *stream) {
     MarchArgs a;
     int rc = fill_common(a, vol, vol_dtype, VX, VY, VZ, sx, sy, sz, vol_view_stride, tf, R, tf_view_stride, cam,
                          entry, exit_, rays, nsamp, n_views, W, H, max_samples, sampling_rate);
     if (rc) return rc;
     if (!grad_out || !out_rgba) return DR_EINVAL;
+    if (row0 < 0 || img_W < W || row0 > img_W - W) return DR_EINVAL;
+    a.img_W = img_W; a.row0 = row0;
     if (variant < DR_VARIANT_AUTO || variant > DR_VARIANT_BRICK_RAYSEG) return DR_EINVAL;
     if (dtf_view_stride % 4 != 0) return DR_EINVAL;
     if (!d_vol && !d_tf) return 0;  // nothing requested
@@ -107,6 +130,19 @@ int dr_march_bwd(const void *vol, int vol_dtype, int VX, int VY, int VZ, int64_t
         return launch_march_bwd_brick(a, (hipStream_t)stream);
     }
     return launch_march_bwd_baseline(a, (hipStream_t)stream);
+}
+
+int dr_march_bwd(const void *vol, int vol_dtype, int VX, int VY, int VZ, int64_t sx, int64_t sy, int64_t sz,
+                 int64_t vol_view_stride, const float *tf, int R, int64_t tf_view_stride, const float *cam,
+                 const float *entry, const float *exit_, const float *rays, const int32_t *nsamp, int n_views, int W,
+                 int H, int max_samples, float sampling_rate, double fov_rad, double near_plane, int variant,
+                 const float *grad_out, const float *out_rgba, float *d_vol, int64_t dsx, int64_t dsy, int64_t dsz,
+                 int64_t dvol_view_stride, float *d_tf, int64_t dtf_view_stride, void *workspace,
+                 size_t workspace_bytes, void *stream) {
+    return dr_march_bwd_rows(vol, vol_dtype, VX, VY, VZ, sx, sy, sz, vol_view_stride, tf, R, tf_view_stride, cam, entry,
+                             exit_, rays, nsamp, n_views, W, H, max_samples, sampling_rate, fov_rad, near_plane, variant,
+                             grad_out, out_rgba, d_vol, dsx, dsy, dsz, dvol_view_stride, d_tf, dtf_view_stride,
+                             workspace, workspace_bytes, W, 0, stream);
 }
 
 int dr_mse_loss_grad(const float *out_rgba, const float *reference, int64_t n, float inv_norm, float *grad_out,

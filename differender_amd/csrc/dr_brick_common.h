@@ -14,6 +14,7 @@ struct BrickParams {
     const float4 *tf; int64_t tf_vs; int R; float tf_len;
     const float *cam, *entry, *exit_, *rays; const int32_t *nsamp;
     int W, H, S; float sr, inv_sr;
+    int imgW, row0;      // band of a wider image (see MarchArgs)
     float near_, near_w, near_h;
     BrickGrid g;
     float4 *seg_rgba;    // [view][NL][NP]: F1 partial composite, then (F2) prefix before the segment
@@ -93,13 +94,13 @@ __device__ __forceinline__ void brick_setup(const BrickParams<VT> &P, int b, f3 
         if (!(depth > 1e-3f)) { behind = true; continue; }
         const float u = dot3(d, right) / depth * (P.near_ / P.near_w);
         const float v = dot3(d, up) / depth * (P.near_ / P.near_h);
-        const float px = (u + 0.5f) * (float)P.W - 0.5f, py = (v + 0.5f) * (float)P.H - 0.5f;
+        const float px = (u + 0.5f) * (float)P.imgW - 0.5f, py = (v + 0.5f) * (float)P.H - 0.5f;  // full-image rows
         pxmin = fminf(pxmin, px); pxmax = fmaxf(pxmax, px); pymin = fminf(pymin, py); pymax = fmaxf(pymax, py);
     }
     if (behind) { c.i0 = 0; c.i1 = P.W - 1; c.j0 = 0; c.j1 = P.H - 1; return; }
     pxmin = fmaxf(pxmin, -2.0f); pymin = fmaxf(pymin, -2.0f);
-    pxmax = fminf(pxmax, (float)P.W + 2.0f); pymax = fminf(pymax, (float)P.H + 2.0f);
-    c.i0 = max(0, (int)floorf(pxmin) - 1); c.i1 = min(P.W - 1, (int)ceilf(pxmax) + 1);
+    pxmax = fminf(pxmax, (float)P.imgW + 2.0f); pymax = fminf(pymax, (float)P.H + 2.0f);
+    c.i0 = max(0, (int)floorf(pxmin) - 1 - P.row0); c.i1 = min(P.W - 1, (int)ceilf(pxmax) + 1 - P.row0);  // band rows
     c.j0 = max(0, (int)floorf(pymin) - 1); c.j1 = min(P.H - 1, (int)ceilf(pymax) + 1);
 }
 
@@ -470,8 +471,9 @@ static inline BrickParams<VT> make_brick_params(const MarchArgs &a, const Worksp
     P.tf = reinterpret_cast<const float4 *>(a.tf); P.tf_vs = a.tf_vs / 4; P.R = a.R; P.tf_len = (float)(a.R - 1);
     P.cam = a.cam; P.entry = a.entry; P.exit_ = a.exit_; P.rays = a.rays; P.nsamp = a.nsamp;
     P.W = a.W; P.H = a.H; P.S = a.S; P.sr = a.sr; P.inv_sr = 1.0f / a.sr;
+    P.imgW = a.img_W > 0 ? a.img_W : a.W; P.row0 = a.img_W > 0 ? a.row0 : 0;
     const double near_h = 2.0 * tan(a.fov_rad) * a.near_plane;
-    P.near_ = (float)a.near_plane; P.near_h = (float)near_h; P.near_w = (float)(near_h * ((double)a.W / (double)a.H));
+    P.near_ = (float)a.near_plane; P.near_h = (float)near_h; P.near_w = (float)(near_h * ((double)P.imgW / (double)a.H));
     P.g = make_brick_grid(a.VX, a.VY, a.VZ);
     P.seg_rgba = w.seg_rgba; P.seg_cnt = w.seg_cnt; P.rayflag = w.rayflag; P.stats = w.stats; P.ws_steps = w.ws_steps;
     P.use_live = a.use_live; P.ctx = w.ctx;

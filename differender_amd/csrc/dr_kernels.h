@@ -11,6 +11,7 @@ struct MarchArgs {
     const float *tf; int R; int64_t tf_vs;
     const float *cam, *entry, *exit_, *rays; const int32_t *nsamp;
     int n_views, W, H, S; float sr; int mode;
+    int img_W, row0;  // the W rows of the buffers are rows [row0, row0 + W) of an image img_W rows wide (bands)
     float *out; int32_t *steps;
     // backward only
     const float *grad_out; const float *out_fwd;
@@ -24,9 +25,9 @@ struct MarchArgs {
     int pp_l0, pp_l1, pp_first;   // alpha pre-pass phase: brick layers [pp_l0, pp_l1); pp_first: no earlier phase
 };
 
-hipError_t launch_ray_setup(const float *cam, int n_views, int W, int H, int VX, int VY, int VZ, double fov_rad,
-                            double near_plane, float sr, uint32_t jitter_seed, uint32_t view_base, float *entry,
-                            float *exit_, float *rays, int32_t *nsamp, hipStream_t stream);
+hipError_t launch_ray_setup(const float *cam, int n_views, int W, int H, int img_W, int row0, int VX, int VY, int VZ,
+                            double fov_rad, double near_plane, float sr, uint32_t jitter_seed, uint32_t view_base,
+                            float *entry, float *exit_, float *rays, int32_t *nsamp, hipStream_t stream);
 
 // Plain one-lane-per-ray kernels (DR_VARIANT_BASELINE): direct global gathers, global float atomics.
 int launch_march_fwd_baseline(const MarchArgs &a, hipStream_t stream);

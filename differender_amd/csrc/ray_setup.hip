@@ -14,6 +14,7 @@ namespace dr {
 struct RaySetupParams {
     const float *cam;  // [views][3]
     int n_views, W, H;
+    int img_W, row0;   // band: buffer row i is image row row0 + i of img_W
     float near_, near_w, near_h, vol_diag, sr;
     uint32_t jitter_seed, view_base;
     float *entry, *exit_, *rays;
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(256) void ray_setup_kernel(RaySetupParams P) {
     const float *cam = P.cam + 3 * view;
     const f3 lf = make_f3(cam[0], cam[1], cam[2]);
     const f3 view_dir = normalized3(make_f3(-lf.x, -lf.y, -lf.z));
-    const float x = ((float)i + 0.5f) / (float)P.W;
+    const float x = ((float)(i + P.row0) + 0.5f) / (float)P.img_W;
     const float y = ((float)j + 0.5f) / (float)P.H;
     const float u = x - 0.5f, v = y - 0.5f;
     f3 up = make_f3(0.f, 1.f, 0.f);
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(256) void ray_setup_kernel(RaySetupParams P) {
     const float n_samples = (hit ? 1.0f : 0.0f) * (floorf(P.sr * ray_len * P.vol_diag) + 1.0f);
     const size_t p = ((size_t)view * P.W + i) * P.H + j;
     if (P.jitter_seed != 0u) {
-        const float uu = jitter_u(P.jitter_seed, P.view_base + (uint32_t)view, (uint32_t)(i * P.H + j));
+        const float uu = jitter_u(P.jitter_seed, P.view_base + (uint32_t)view, (uint32_t)((i + P.row0) * P.H + j));
         tmin += uu * ray_len / n_samples;
     }
     P.entry[p] = tmin;
@@ -73,14 +74,14 @@ __global__ __launch_bounds__(256) void ray_setup_kernel(RaySetupParams P) {
     P.nsamp[p] = (int32_t)n_samples;
 }
 
-hipError_t launch_ray_setup(const float *cam, int n_views, int W, int H, int VX, int VY, int VZ, double fov_rad,
-                            double near_plane, float sr, uint32_t jitter_seed, uint32_t view_base, float *entry,
-                            float *exit_, float *rays, int32_t *nsamp, hipStream_t stream) {
+hipError_t launch_ray_setup(const float *cam, int n_views, int W, int H, int img_W, int row0, int VX, int VY, int VZ,
+                            double fov_rad, double near_plane, float sr, uint32_t jitter_seed, uint32_t view_base,
+                            float *entry, float *exit_, float *rays, int32_t *nsamp, hipStream_t stream) {
     RaySetupParams P;
     // VR.py:146-147: Python doubles, then rounded once (ti.tan of a Python float is math.tan)
     const double near_h = 2.0 * tan(fov_rad) * near_plane;
-    const double near_w = near_h * ((double)W / (double)H);
-    P.cam = cam; P.n_views = n_views; P.W = W; P.H = H;
+    const double near_w = near_h * ((double)img_W / (double)H);
+    P.cam = cam; P.n_views = n_views; P.W = W; P.H = H; P.img_W = img_W; P.row0 = row0;
     P.near_ = (float)near_plane; P.near_w = (float)near_w; P.near_h = (float)near_h;
     P.vol_diag = (float)sqrt((double)(VX - 1) * (VX - 1) + (double)(VY - 1) * (VY - 1) + (double)(VZ - 1) * (VZ - 1));
     P.sr = sr; P.jitter_seed = jitter_seed; P.view_base = view_base;

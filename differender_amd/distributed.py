@@ -1,13 +1,13 @@
 """Multi-GPU helpers (one process per GPU, torch.distributed; backend "nccl" is RCCL on ROCm).
 
-The hot path shards by VIEW: every rank holds a full replica of the volume and the transfer function
+The hot path shards by VIEW (or, for one view, by bands of image rows: shard_rows): every rank holds a full replica of the volume and the transfer function
 (512 MiB at 512^3 f32 -- small against 288 GB of HBM), renders its own views, and accumulates a local
 d_volume / d_tf over them. The only exchange step is one sum all-reduce of those two shared gradients
 (SURVEY section 8(e)); the forward path needs no collective at all. The reference has no counterpart.
 """
 import torch
 
-__all__ = ["shard_views", "all_reduce_gradients"]
+__all__ = ["shard_views", "shard_rows", "all_reduce_gradients"]
 
 
 def shard_views(n_views, rank=None, world_size=None):
@@ -16,6 +16,19 @@ def shard_views(n_views, rank=None, world_size=None):
         import torch.distributed as dist
         rank, world_size = dist.get_rank(), dist.get_world_size()
     return list(range(rank, n_views, world_size))
+
+
+def shard_rows(image_rows, rank=None, world_size=None):
+    """A single view split into `world_size` bands of image rows: returns (row0, n_rows) of
+    rank `rank`; the bands differ by at most one row and tile the image. Pass `rows=(row0, image_rows)` and an output
+    shape of (n_rows, H) to functional.ray_setup / march_fwd / march_bwd; the bands' gradients are summed with
+    all_reduce_gradients exactly like those of different views."""
+    if rank is None or world_size is None:
+        import torch.distributed as dist
+        rank, world_size = dist.get_rank(), dist.get_world_size()
+    base, extra = divmod(int(image_rows), int(world_size))
+    row0 = rank * base + min(rank, extra)
+    return row0, base + (1 if rank < extra else 0)
 
 
 def all_reduce_gradients(grads, group=None, async_op=False):

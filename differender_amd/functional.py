@@ -82,9 +82,19 @@ def _ws_args(workspace):
     return workspace.data_ptr(), workspace.numel()
 
 
-def ray_setup(cam, out_shape, vol_shape, sampling_rate, fov_deg=30.0, near=0.1, jitter_seed=0, view_base=0):
+def _rows(rows, W):
+    """rows = None (whole image) or (row0, image_rows): the W buffer rows are image rows [row0, row0 + W)."""
+    if rows is None:
+        return int(W), 0
+    row0, img_w = int(rows[0]), int(rows[1])
+    if row0 < 0 or img_w < W or row0 > img_w - W:
+        raise ValueError(f"band rows [{row0}, {row0 + W}) do not fit an image of {img_w} rows")
+    return img_w, row0
+
+
+def ray_setup(cam, out_shape, vol_shape, sampling_rate, fov_deg=30.0, near=0.1, jitter_seed=0, view_base=0, rows=None):
     """compute_entry_exit (VR.py:221-259) for cam (views,3) -> entry, exit (views,W,H), rays (views,W,H,3),
-    n (views,W,H) int32."""
+    n (views,W,H) int32. rows=(row0, image_rows) renders a band of a taller image (see distributed.shard_rows)."""
     _require_gpu(cam, "look_from")
     cam = cam.to(torch.float32).contiguous()
     V = cam.shape[0]
@@ -96,15 +106,16 @@ def ray_setup(cam, out_shape, vol_shape, sampling_rate, fov_deg=30.0, near=0.1, 
     n = torch.empty((V, W, H), dtype=torch.int32, device=dev)
     VX, VY, VZ = (int(s) for s in vol_shape)
     with torch.cuda.device(dev):
-        rc = N.lib().dr_ray_setup(cam.data_ptr(), V, W, H, VX, VY, VZ, float(np.radians(fov_deg)), float(near),
-                                  float(sampling_rate), int(jitter_seed) & 0xFFFFFFFF, int(view_base),
-                                  entry.data_ptr(), exit_.data_ptr(), rays.data_ptr(), n.data_ptr(), _stream())
-    N.check(rc, "dr_ray_setup")
+        rc = N.lib().dr_ray_setup_rows(cam.data_ptr(), V, W, H, *_rows(rows, W), VX, VY, VZ,
+                                       float(np.radians(fov_deg)), float(near),
+                                       float(sampling_rate), int(jitter_seed) & 0xFFFFFFFF, int(view_base),
+                                       entry.data_ptr(), exit_.data_ptr(), rays.data_ptr(), n.data_ptr(), _stream())
+    N.check(rc, "dr_ray_setup_rows")
     return entry, exit_, rays, n
 
 
 def march_fwd(vol, tf, cam, entry, exit_, rays, n, max_samples, sampling_rate, mode=N.DR_MODE_DIFF,
-              variant=N.DR_VARIANT_AUTO, want_steps=True, fov_deg=30.0, near=0.1, workspace="auto"):
+              variant=N.DR_VARIANT_AUTO, want_steps=True, fov_deg=30.0, near=0.1, workspace="auto", rows=None):
     """raycast + get_final_image (VR.py:261-306,363-372) or the nondiff pair (VR.py:308-361).
     Returns out (views,W,H,4) and steps (views,W,H) int32 (or None).
     workspace: a buffer from alloc_workspace() (keep it for march_bwd), "auto" to allocate a throw-away one,
@@ -120,17 +131,17 @@ def march_fwd(vol, tf, cam, entry, exit_, rays, n, max_samples, sampling_rate, m
     if isinstance(workspace, str):
         workspace = alloc_workspace(V, (W, H), vargs[2:5], targs[1], dev) if variant == N.DR_VARIANT_AUTO else None
     with torch.cuda.device(dev):
-        rc = N.lib().dr_march_fwd(*vargs, targs[0], targs[1], targs[2], cam.data_ptr(), entry.data_ptr(),
-                                  exit_.data_ptr(), rays.data_ptr(), n.data_ptr(), V, W, H, int(max_samples),
-                                  float(sampling_rate), float(np.radians(fov_deg)), float(near), int(mode),
-                                  int(variant), out.data_ptr(), steps.data_ptr() if want_steps else None,
-                                  *_ws_args(workspace), _stream())
-    N.check(rc, "dr_march_fwd")
+        rc = N.lib().dr_march_fwd_rows(*vargs, targs[0], targs[1], targs[2], cam.data_ptr(), entry.data_ptr(),
+                                       exit_.data_ptr(), rays.data_ptr(), n.data_ptr(), V, W, H, int(max_samples),
+                                       float(sampling_rate), float(np.radians(fov_deg)), float(near), int(mode),
+                                       int(variant), out.data_ptr(), steps.data_ptr() if want_steps else None,
+                                       *_ws_args(workspace), *_rows(rows, W), _stream())
+    N.check(rc, "dr_march_fwd_rows")
     return out, steps
 
 
 def march_bwd(vol, tf, cam, entry, exit_, rays, n, max_samples, sampling_rate, grad_out, out, want_vol=True,
-              want_tf=True, variant=N.DR_VARIANT_AUTO, fov_deg=30.0, near=0.1, workspace=None):
+              want_tf=True, variant=N.DR_VARIANT_AUTO, fov_deg=30.0, near=0.1, workspace=None, rows=None):
     """Adjoint of the differentiable march w.r.t. vol and tf (replaces raycast.grad, VR.py:460-461,470-471).
     Shared (un-batched) vol / tf receive one gradient accumulated over all views.
     workspace: the buffer the matching march_fwd filled (fast path); None runs the baseline kernels."""
@@ -156,11 +167,12 @@ def march_bwd(vol, tf, cam, entry, exit_, rays, n, max_samples, sampling_rate, g
     if not (want_vol or want_tf):
         return None, None
     with torch.cuda.device(vol.device):
-        rc = N.lib().dr_march_bwd(*vargs, targs[0], targs[1], targs[2], cam.data_ptr(), entry.data_ptr(),
-                                  exit_.data_ptr(), rays.data_ptr(), n.data_ptr(), V, W, H, int(max_samples),
-                                  float(sampling_rate), float(np.radians(fov_deg)), float(near), int(variant),
-                                  grad_out.data_ptr(), out.data_ptr(), *dv, *dt, *_ws_args(workspace), _stream())
-    N.check(rc, "dr_march_bwd")
+        rc = N.lib().dr_march_bwd_rows(*vargs, targs[0], targs[1], targs[2], cam.data_ptr(), entry.data_ptr(),
+                                       exit_.data_ptr(), rays.data_ptr(), n.data_ptr(), V, W, H, int(max_samples),
+                                       float(sampling_rate), float(np.radians(fov_deg)), float(near), int(variant),
+                                       grad_out.data_ptr(), out.data_ptr(), *dv, *dt, *_ws_args(workspace),
+                                       *_rows(rows, W), _stream())
+    N.check(rc, "dr_march_bwd_rows")
     return d_vol, d_tf
 
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DR_ABI_VERSION 3
+#define DR_ABI_VERSION 4
 
 enum { DR_F32 = 0, DR_F16 = 1 };
 enum { DR_MODE_DIFF = 0, DR_MODE_NONDIFF = 1 };
@@ -109,6 +109,34 @@ int dr_march_bwd(const void *vol, int vol_dtype, int VX, int VY, int VZ,
                  float *d_vol, int64_t dsx, int64_t dsy, int64_t dsz, int64_t dvol_view_stride,
                  float *d_tf, int64_t dtf_view_stride,
                  void *workspace, size_t workspace_bytes, void *stream);
+
+/* Image bands: the same three calls for rows [row0, row0 + W) of an image that is img_W rows wide (SURVEY 8(e):
+ * "single view => split the image into G tile bands", one band per GPU). All [n_views][W][H] buffers hold the band
+ * only; pixel (i, j) of the band is pixel (row0 + i, j) of the image -- same ray, same jitter value, bit for bit, as in
+ * a whole-image call. Gradients of the bands add up to the whole image's (all-reduce them like those of views).
+ * The plain entry points above are these with img_W = W, row0 = 0. */
+int dr_ray_setup_rows(const float *cam, int n_views, int W, int H, int img_W, int row0, int VX, int VY, int VZ,
+                      double fov_rad, double near_plane, float sampling_rate,
+                      uint32_t jitter_seed, uint32_t view_base,
+                      float *entry, float *exit_, float *rays, int32_t *nsamp, void *stream);
+int dr_march_fwd_rows(const void *vol, int vol_dtype, int VX, int VY, int VZ,
+                      int64_t sx, int64_t sy, int64_t sz, int64_t vol_view_stride,
+                      const float *tf, int R, int64_t tf_view_stride,
+                      const float *cam, const float *entry, const float *exit_, const float *rays,
+                      const int32_t *nsamp, int n_views, int W, int H, int max_samples,
+                      float sampling_rate, double fov_rad, double near_plane, int mode, int variant,
+                      float *out_rgba, int32_t *steps, void *workspace, size_t workspace_bytes,
+                      int img_W, int row0, void *stream);
+int dr_march_bwd_rows(const void *vol, int vol_dtype, int VX, int VY, int VZ,
+                      int64_t sx, int64_t sy, int64_t sz, int64_t vol_view_stride,
+                      const float *tf, int R, int64_t tf_view_stride,
+                      const float *cam, const float *entry, const float *exit_, const float *rays,
+                      const int32_t *nsamp, int n_views, int W, int H, int max_samples,
+                      float sampling_rate, double fov_rad, double near_plane, int variant,
+                      const float *grad_out, const float *out_rgba,
+                      float *d_vol, int64_t dsx, int64_t dsy, int64_t dsz, int64_t dvol_view_stride,
+                      float *d_tf, int64_t dtf_view_stride,
+                      void *workspace, size_t workspace_bytes, int img_W, int row0, void *stream);
 
 /* Image loss and its gradient, one pass over the rendered image (the step after the march in an optimisation
  * loop): replaces compute_loss (examples/taichi_volume_raycaster.py:368-373, "EX.py") and the torch mse_loss

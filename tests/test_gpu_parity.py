@@ -513,3 +513,41 @@ def test_many_views_without_prepass(oracle, hiplib):
     assert ok, err
     ok, err = grad_close(dt.cpu().numpy(), dt_ref)
     assert ok, err
+
+
+def test_image_bands_reproduce_the_whole_image(oracle, F):
+    """One view rendered as three bands of rows (one per GPU in a strong-scaling run): ray buffers are bit-identical to
+    the corresponding rows of the whole-image call (jitter included), RGBA agrees, and the bands' gradients add up
+    to the whole image's."""
+    vol_h, tf_h, cam_h = scene(oracle, N=40, R=32, tf="peaks")
+    W, H = 50, 36
+    vol, tf, cam = T(vol_h), T(tf_h), T(np.atleast_2d(cam_h))
+    fn = F._f
+    seed = 777
+    e, x, r, n = fn.ray_setup(cam, (W, H), vol.shape, 1.0, jitter_seed=seed)
+    out, steps = F.march_fwd(vol, tf, cam, e, x, r, n, 4096, 1.0)
+    g = T(np.random.default_rng(9).standard_normal(out.shape).astype(np.float32))
+    dv, dt = F.march_bwd(vol, tf, cam, e, x, r, n, 4096, 1.0, g, out)
+    # against the oracle, whole image (the bands are then compared with these rows)
+    eh, xh, rh, nh = (t[0].cpu().numpy() for t in (e, x, r, n))
+    ref, _ = oracle.march_fwd(vol_h, tf_h, cam_h, eh, xh, rh, nh, 4096, 1.0, 0)
+    assert np.abs(out[0].cpu().numpy() - ref).max() <= FWD_TOL
+    from differender_amd.distributed import shard_rows
+    dv_sum = torch.zeros_like(dv); dt_sum = torch.zeros_like(dt)
+    for rank in range(3):
+        row0, nr = shard_rows(W, rank, 3)
+        rows = (row0, W)
+        eb, xb, rb, nb = fn.ray_setup(cam, (nr, H), vol.shape, 1.0, jitter_seed=seed, rows=rows)
+        sl = slice(row0, row0 + nr)
+        assert torch.equal(eb, e[:, sl]) and torch.equal(xb, x[:, sl]) and torch.equal(rb, r[:, sl]) and torch.equal(nb, n[:, sl])
+        ws = fn.alloc_workspace(1, (nr, H), vol.shape, tf.shape[0], dev()) if F.variant != 1 else None
+        ob, sb = fn.march_fwd(vol, tf, cam, eb, xb, rb, nb, 4096, 1.0, variant=F.variant, workspace=ws, rows=rows)
+        assert torch.equal(sb, steps[:, sl])
+        assert float((ob - out[:, sl]).abs().max()) <= 2e-6
+        dvb, dtb = fn.march_bwd(vol, tf, cam, eb, xb, rb, nb, 4096, 1.0, g[:, sl].contiguous(), ob, variant=F.variant,
+                                workspace=ws, rows=rows)
+        dv_sum += dvb; dt_sum += dtb
+    ok, err = grad_close(dv_sum.cpu().numpy(), dv.cpu().numpy(), 2e-5)
+    assert ok, err
+    ok, err = grad_close(dt_sum.cpu().numpy(), dt.cpu().numpy(), 2e-5)
+    assert ok, err

@@ -76,3 +76,15 @@ def test_reciprocal_division_identity(oracle):
     fn.restype = ctypes.c_long
     fn.argtypes = [ctypes.c_int, ctypes.c_long]
     assert fn(3072, 20_000_000) == 0
+
+
+def test_shard_rows_tiles_the_image():
+    from differender_amd.distributed import shard_rows
+    for rows, world in ((512, 8), (100, 3), (7, 8), (1, 1)):
+        bands = [shard_rows(rows, r, world) for r in range(world)]
+        assert sum(n for _, n in bands) == rows
+        pos = 0
+        for row0, n in bands:
+            assert row0 == pos and n >= 0
+            pos += n
+        assert max(n for _, n in bands) - min(n for _, n in bands) <= 1
