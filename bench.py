@@ -127,6 +127,7 @@ def main():
     S = 1 << 20  # tape-free: no depth limit needed
     sr = 1.0
     total_steps = torch.zeros((), dtype=torch.int64, device=dev)
+    planned_steps = torch.zeros((), dtype=torch.int64, device=dev)  # sum of sample_step_nums (VR.py:259)
     ev = {"fwd": [], "bwd": []}
     # scratch of the brick-centric kernels (coarse tape); allocated once, reused by every step
     ws = F.alloc_workspace(V, (ROWS, IMG), (N, N, N), R, dev) if args.variant == 0 else None
@@ -164,9 +165,9 @@ def main():
                 pending[:] = all_reduce_gradients([g for g in (dv, dt) if g is not None], async_op=True)
                 keep_alive[:] = [dv, dt]
         if timed:
-            total_steps.add_(steps.sum())
+            total_steps.add_(steps.sum()); planned_steps.add_(n.sum())
         else:
-            steps.sum()  # same launches as a timed step
+            steps.sum(); n.sum()  # same launches as a timed step
 
     pending, keep_alive = [], []
 
@@ -191,6 +192,7 @@ def main():
     if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(total_steps, op=dist.ReduceOp.SUM)
+        dist.all_reduce(planned_steps, op=dist.ReduceOp.SUM)
     elapsed = float(el.item())
     vsteps = int(total_steps.item())
     passes = 2 if want_bwd else 1  # a voxel-step counted once per marched sample of the fwd(+bwd) pass
@@ -254,6 +256,7 @@ def main():
                                       (" + RCCL all-reduce(d_vol,d_tf)" if world > 1 else ""),
                        "passes_per_voxel_step": passes, "kernel_variant": args.variant, "tf": args.tf},
             "voxel_steps_per_step": int(vsteps / max(args.steps, 1)),
+            "planned_steps_per_step": int(int(planned_steps.item()) / max(args.steps, 1)),  # executed/planned < 1 = early termination
             "roofline": dominant, "roofline_fwd": roof_fwd, "roofline_bwd": roof_bwd,
             "rays_marched_individually": (int(F.workspace_stats(ws)[0]) if ws is not None else None),
             "cpu_baseline": cpu_baseline,
