@@ -281,6 +281,11 @@ def run_cpu_baseline(vol, tf, args, sr, want_vol, want_tf):
     cam = np.array(in_circles(0.0), np.float32)
     W = args.cpu_img
     N = args.vol
+    # untimed warm-up on a 16x16 image: the first parallel region pays for the OpenMP thread pool and first touches
+    ew, xw, rw, nw = O.ray_setup(cam, 16, 16, (N, N, N), sr)
+    ow, _ = O.march_fwd(vol_h, tf_h, cam, ew, xw, rw, nw, 1 << 20, sr, 0)
+    if want_vol or want_tf:
+        O.march_bwd(vol_h, tf_h, cam, ew, xw, rw, nw, 1 << 20, sr, np.ones_like(ow), want_vol, want_tf)
     e, x, r, n = O.ray_setup(cam, W, W, (N, N, N), sr)
     t0 = time.perf_counter()
     out, steps = O.march_fwd(vol_h, tf_h, cam, e, x, r, n, 1 << 20, sr, 0)
@@ -289,9 +294,28 @@ def run_cpu_baseline(vol, tf, args, sr, want_vol, want_tf):
         O.march_bwd(vol_h, tf_h, cam, e, x, r, n, 1 << 20, sr, g.astype(np.float32), want_vol, want_tf)
     dt = time.perf_counter() - t0
     nst = int(steps.sum())
-    return {"value": round(nst / dt / 1e6, 4), "unit": "Mvoxel-steps/s", "cores": cores, "kind": "port",
-            "sample": f"same {N}^3 volume/TF, camera in_circles(0), {W}x{W} image "
-                      f"({nst} voxel-steps, fwd{'+bwd' if (want_tf or want_vol) else ''}), C oracle with OpenMP, {dt:.1f} s"}
+    res = {"value": round(nst / dt / 1e6, 4), "unit": "Mvoxel-steps/s", "cores": cores, "kind": "port",
+           "sample": f"same {N}^3 volume/TF, camera in_circles(0), {W}x{W} image "
+                     f"({nst} voxel-steps, fwd{'+bwd' if (want_tf or want_vol) else ''}), C oracle with OpenMP, {dt:.1f} s"}
+    # single-thread figure on a 16x smaller sample (SURVEY 8(d) asks for both)
+    try:
+        import ctypes
+        gomp = ctypes.CDLL("libgomp.so.1")
+        gomp.omp_set_num_threads(1)
+        W1 = max(W // 4, 8)
+        e, x, r, n = O.ray_setup(cam, W1, W1, (N, N, N), sr)
+        t0 = time.perf_counter()
+        out, steps = O.march_fwd(vol_h, tf_h, cam, e, x, r, n, 1 << 20, sr, 0)
+        if want_vol or want_tf:
+            g = (2.0 / out.size) * (out - 0.5)
+            O.march_bwd(vol_h, tf_h, cam, e, x, r, n, 1 << 20, sr, g.astype(np.float32), want_vol, want_tf)
+        dt1 = time.perf_counter() - t0
+        gomp.omp_set_num_threads(cores)
+        res["value_1thread"] = round(int(steps.sum()) / dt1 / 1e6, 4)
+        res["sample_1thread"] = f"{W1}x{W1} image, {int(steps.sum())} voxel-steps, {dt1:.1f} s"
+    except OSError:
+        pass
+    return res
 
 
 if __name__ == "__main__":
