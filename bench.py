@@ -73,6 +73,8 @@ def main():
                     help="bench: constant alpha (no early termination, the headline); tf1: the reference's preset "
                          "(UT.py:9-21) -- empty ranges and early termination, reported separately")
     ap.add_argument("--views", type=int, default=1, help="views per rank per step (one native batched launch)")
+    ap.add_argument("--vol-dtype", default="f32", choices=["f32", "f16"], help="volume storage (arithmetic is f32 either way; C5 uses f16)")
+    ap.add_argument("--jitter", action="store_true", help="jittered ray starts (C5)")
     ap.add_argument("--split", default="views", choices=["views", "rows"],
                     help="N > 1: 'views' = one view per rank per step (weak scaling, the default); 'rows' = ONE view per "
                          "step split into N bands of image rows (strong scaling, SURVEY 8(e))")
@@ -112,6 +114,8 @@ def main():
     n_max = 2.0 * math.sqrt(3.0) * math.sqrt(3.0) * (N - 1)
     alpha = 3.0 / n_max
     vol = synth_volume_torch(N, dev)
+    if args.vol_dtype == "f16":
+        vol = vol.half()
     tf = bench_tf_torch(R, alpha, dev)
     if args.tf == "tf1":
         from differender_amd.utils import get_tf
@@ -140,7 +144,8 @@ def main():
 
     def step(k, timed):
         cam = cams_all[k]
-        e, x, r, n = F.ray_setup(cam, (ROWS, IMG), (N, N, N), sr, rows=rows_arg)
+        e, x, r, n = F.ray_setup(cam, (ROWS, IMG), (N, N, N), sr, rows=rows_arg, jitter_seed=(42 if args.jitter else 0),
+                                 view_base=k * V)
         # (warm-up steps run the very same host code, events included: their first use has a one-time host cost)
         a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a0.record()
@@ -249,8 +254,8 @@ def main():
             "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4),
             "higher_is_better": True, "scaling": "strong" if bands else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{workload}; {N}^3 f32 volume, {IMG}^2 image, {R}-entry TF, sr=1.0, "
-                                   f"{V} view(s) per rank per step, orbit cameras in_circles(0.1*v), jitter off",
+            "config": {"workload": f"{workload}; {N}^3 {args.vol_dtype} volume, {IMG}^2 image, {R}-entry TF, sr=1.0, "
+                                   f"{V} view(s) per rank per step, orbit cameras in_circles(0.1*v), jitter {'on' if args.jitter else 'off'}",
                        "volume": N, "image": IMG, "tf_res": R, "views_per_rank_per_step": V,
                        "parallelism": (f"one view in {world} row bands" if bands else f"view-sharded x{world}") +
                                       (" + RCCL all-reduce(d_vol,d_tf)" if world > 1 else ""),
