@@ -58,6 +58,9 @@ __device__ __forceinline__ void brick_ctx_load(const BrickCtxRec *rec, BrickCtx 
     c.i0 = r.i0; c.i1 = r.i1; c.j0 = r.j0; c.j1 = r.j1; c.live = r.live;
 }
 
+#ifndef DR_RECT_SLACK
+#define DR_RECT_SLACK 0.05f
+#endif
 __device__ __forceinline__ f3 cross3b(f3 a, f3 b) {
     return make_f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
@@ -100,8 +103,12 @@ __device__ __forceinline__ void brick_setup(const BrickParams<VT> &P, int b, f3 
     if (behind) { c.i0 = 0; c.i1 = P.W - 1; c.j0 = 0; c.j1 = P.H - 1; return; }
     pxmin = fmaxf(pxmin, -2.0f); pymin = fmaxf(pymin, -2.0f);
     pxmax = fminf(pxmax, (float)P.imgW + 2.0f); pymax = fminf(pymax, (float)P.H + 2.0f);
-    c.i0 = max(0, (int)floorf(pxmin) - 1 - P.row0); c.i1 = min(P.W - 1, (int)ceilf(pxmax) + 1 - P.row0);  // band rows
-    c.j0 = max(0, (int)floorf(pymin) - 1); c.j1 = min(P.H - 1, (int)ceilf(pymax) + 1);
+    // Pixel (i, j) has its ray through (px, py) = (i, j) exactly (the inverse of ray_setup's mapping), and the brick
+    // (a convex box in front of the camera, already widened by BRICK_EPS) projects inside the bounding box of its
+    // corners: the candidates are the integer points of [pxmin, pxmax] x [pymin, pymax]. DR_RECT_SLACK (pixels) covers
+    // the float error of this projection (~1e-4 px); a miss would still be caught by the per-ray sample-count check.
+    c.i0 = max(0, (int)ceilf(pxmin - DR_RECT_SLACK) - P.row0); c.i1 = min(P.W - 1, (int)floorf(pxmax + DR_RECT_SLACK) - P.row0);  // band rows
+    c.j0 = max(0, (int)ceilf(pymin - DR_RECT_SLACK)); c.j1 = min(P.H - 1, (int)floorf(pymax + DR_RECT_SLACK));
 }
 
 // One thread per (brick, view): brick_setup once, for all passes of a forward/backward pair. The forward launches it
