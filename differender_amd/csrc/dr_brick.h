@@ -34,7 +34,7 @@ constexpr int BOX_SX = BOX * BOX_SY + DR_BOX_PADX;
 constexpr int BOX_VOX = BOX * BOX * BOX;   // voxels staged per brick
 constexpr int BOX_LDS = BOX * BOX_SX;      // LDS elements reserved for them
 constexpr int ECHUNK = 512;                // ray segments listed per round
-constexpr float BRICK_EPS = 2e-4f;         // world-space slack of the conservative ray/brick tests
+constexpr float BRICK_EPS = 5e-5f;         // world-space slack of the conservative ray/brick tests (float error: ~2e-7)
 
 struct BrickGrid {
     int NBx, NBy, NBz, NL;  // bricks per axis, number of layers (NBx+NBy+NBz-2)

@@ -149,8 +149,8 @@ __device__ __forceinline__ bool segment_range(const BrickCtx &c, f3 cam, f3 vd, 
     }
     if (!(ta <= tb)) return false;
     const float scale = (float)(n - 1) / (exit_ - t0);
-    // samples with ta <= t_s <= tb: ceil(xa) .. floor(xb). The slab carries BRICK_EPS (~0.2 samples at 512^3, never
-    // below 0.02) of slack, orders of magnitude above the rounding of this inverse map (~1e-4 samples). A miss would
+    // samples with ta <= t_s <= tb: ceil(xa) .. floor(xb). The slab carries BRICK_EPS (0.045 samples at 512^3, never
+    // below 0.005) of slack, an order of magnitude above the rounding of this inverse map (<= 1e-7 * n samples). A miss would
     // still be caught by the per-ray sample-count check (and the ray marched whole).
     float sa = ceilf((ta - t0) * scale), sb = floorf((tb - t0) * scale) + 1.0f;
     sa = fminf(fmaxf(sa, 0.0f), (float)nmarch); sb = fminf(fmaxf(sb, 0.0f), (float)nmarch);
