@@ -571,14 +571,19 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
         Over carry = {0.f, 0.f, 0.f, 0.f};
         int carry_e = -1;  // entry whose composite so far is in `carry` (continues into the next chunk)
         int e_cur = ea;
-        for (int f0 = fa; f0 < fb; f0 += 64 * KS) {
-            const int f = f0 + KS * lane;
+        for (int f0 = fa, ks = 1; f0 < fb; f0 += 64 * ks) {
+            // samples per lane in this pass: KS, but the tail of the wave's samples takes the smallest power of two
+            // that still covers it with 64 lanes (a half-empty last pass would cost all KS sub-samples)
+            const int rem = fb - f0;
+            const int ksh = (KS >= 4 && rem > 128) ? 2 : ((KS >= 2 && rem > 64) ? 1 : 0);  // uniform
+            ks = 1 << ksh;
+            const int f = f0 + ks * lane;
             const bool act = f < fb;
             // entry of this lane: advance from the previous chunk's entry (flat order is entry order)
             if (act) { while (f >= offs[e_cur + 1]) ++e_cur; }
             const int e = act ? e_cur : eb - 1;
             const int eoff = offs[e];
-            const int sl = max(lane - (f - eoff) / KS, 0);  // first lane of this lane's segment within the chunk
+            const int sl = max(lane - ((f - eoff) >> ksh), 0);  // first lane of this lane's segment within the chunk
             const float4 r0 = L.ray0[e], r1 = L.ray1[e];
             const int s = f + L.s_rel[e];
             const f3 vd = make_f3(r1.x, r1.y, r1.z);
@@ -598,6 +603,7 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
                 int cnt_lane = 0;  // in-brick samples of this lane
 #pragma unroll
                 for (int j = 0; j < KS; ++j) {
+                    if (j >= ks) continue;  // uniform
                     Sample sa;
                     int x0 = 0, y0 = 0, z0 = 0;
                     float fx = 0.f, fy = 0.f, fz = 0.f;
@@ -621,14 +627,14 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
                 {
                     const int e_last = __builtin_amdgcn_readlane(e, 63);
                     const float lastT = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Tl), 63));
-                    const bool more = (f0 + 64 * KS < fb) && (offs[e_last + 1] > f0 + 64 * KS);
+                    const bool more = (f0 + 64 * ks < fb) && (offs[e_last + 1] > f0 + 64 * ks);
                     carry.a = lastT; carry_e = more ? e_last : -1;
                 }
-                const bool seg_end = act && (f + KS >= offs[e + 1]);
+                const bool seg_end = act && (f + ks >= offs[e + 1]);
                 // in-brick samples of the piece [sl, lane]: inclusive lane-sum of the per-lane counts
                 float cf[1] = {(float)cnt_lane};
                 seg_scan_sum<1>(cf, lane, sl);
-                const bool piece_end = act && (seg_end || lane == 63 || f + KS >= fb);
+                const bool piece_end = act && (seg_end || lane == 63 || f + ks >= fb);
                 if (piece_end) {
                     const int cntp = (int)cf[0];
                     const int before = cntp ? atomicAdd(&L.valid[e], cntp) : L.valid[e];
@@ -670,6 +676,7 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
                 const int slen = L.slen[e];
 #pragma unroll
                 for (int j = 0; j < KS; ++j) {
+                    if (j >= ks) { vm_fwd[j] = 0ull; continue; }  // uniform
                     const bool actj = act && (f + j - eoff) < slen;
                     bool vj = false;
                     if (actj) {
@@ -706,13 +713,13 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
             {
                 const int e_last = __builtin_amdgcn_readlane(e, 63);
                 const Over last = readlane_over(inc, 63);
-                const bool more = (f0 + 64 * KS < fb) && (offs[e_last + 1] > f0 + 64 * KS);
+                const bool more = (f0 + 64 * ks < fb) && (offs[e_last + 1] > f0 + 64 * ks);
                 carry = last; carry_e = more ? e_last : -1;
             }
-            const bool seg_end = act && (f + KS >= offs[e + 1]);
+            const bool seg_end = act && (f + ks >= offs[e + 1]);
             if (!BWD) {
                 // count the in-brick samples of each segment piece, store finished segments
-                const bool piece_end = act && (seg_end || lane == 63 || f + KS >= fb);
+                const bool piece_end = act && (seg_end || lane == 63 || f + ks >= fb);
                 if (piece_end) {
                     const unsigned long long below = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
                     const unsigned long long from = ~((1ull << sl) - 1ull);
