@@ -18,7 +18,9 @@ struct BrickParams {
     float near_, near_w, near_h;
     BrickGrid g;
     float4 *seg_rgba;    // [view][NL][NP]: F1 partial composite, then (F2) prefix before the segment
-    int32_t *seg_cnt;    // [view][NL][NP]: samples of the ray inside the brick of that layer
+    uint16_t *seg_cnt;   // [view][NL][NP]: samples of the ray inside the brick of that layer (saturating at 65535: a
+                         // longer in-brick run -- sampling rates in the thousands -- fails the count check and the
+                         // ray is marched whole)
     uint8_t *rayflag;    // [view][NP]: 1 = irregular ray (marched whole by F2 / B2)
     int32_t *ws_steps;   // [view][NP]: live samples per ray (F2 -> B1)
     unsigned int *stats; // [0] rays repaired by the count check, [1] bits of max|grad_out| (backward),
@@ -439,7 +441,7 @@ static __global__ __launch_bounds__(256) void absmax_kernel(const float *x, size
 
 // ------------------------------------------------------------------------------------------------ host
 struct Workspace {
-    float4 *seg_rgba; int32_t *seg_cnt; int32_t *ws_steps; uint8_t *rayflag; unsigned int *stats;
+    float4 *seg_rgba; uint16_t *seg_cnt; int32_t *ws_steps; uint8_t *rayflag; unsigned int *stats;
     BrickCtxRec *ctx;
     size_t cnt_bytes;
 };
@@ -452,8 +454,8 @@ static inline size_t ws_layout(void *base, int n_views, int NP, const BrickGrid 
     o += 256;
     if (w) w->seg_rgba = reinterpret_cast<float4 *>(b + o);
     o += nseg * 16;
-    if (w) { w->seg_cnt = reinterpret_cast<int32_t *>(b + o); w->cnt_bytes = nseg * 4; }
-    o += nseg * 4;
+    if (w) { w->seg_cnt = reinterpret_cast<uint16_t *>(b + o); w->cnt_bytes = nseg * 2; }
+    o += align16(nseg * 2);
     if (w) w->ws_steps = reinterpret_cast<int32_t *>(b + o);
     o += align16((size_t)n_views * NP * 4);
     if (w) w->rayflag = reinterpret_cast<uint8_t *>(b + o);

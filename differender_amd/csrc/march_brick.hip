@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void brick_fwd_kernel(BrickParams<VT> P) {
             }
             if (valid > 0) {
                 P.seg_rgba[seg_base + pl] = make_float4(C0, C1, C2, A);
-                P.seg_cnt[seg_base + pl] = valid;
+                P.seg_cnt[seg_base + pl] = (uint16_t)min(valid, 65535);
             }
         }
         __syncthreads();

@@ -821,7 +821,7 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
             bool some = false;
             for (int e = ea + lane; e < eb; e += 64) {
                 const int v = L.valid[e];
-                if (v > 0) { P.seg_cnt[seg_base + __float_as_int(L.ray1[e].w)] = v; some = true; }
+                if (v > 0) { P.seg_cnt[seg_base + __float_as_int(L.ray1[e].w)] = (uint16_t)min(v, 65535); some = true; }
             }
             if (!ALPHA && __any(some) && lane == 0)  // tell the backward that this brick holds live samples of the view
                 const_cast<BrickCtxRec *>(P.ctx)[(size_t)view * gridDim.x + blockIdx.x].live = 1;
