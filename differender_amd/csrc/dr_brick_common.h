@@ -118,9 +118,33 @@ __device__ __forceinline__ void brick_setup(const BrickParams<VT> &P, int b, f3 
 // forward's"); the backward recomputes the geometry (it may follow a forward of another kernel variant) and keeps
 // the live flags, which its kernels only trust when the mark is there.
 constexpr unsigned int DR_CTX_MARK = 0x600DF1A7u;
+// Can any ray of a view terminate early? Upper bound from the largest TF alpha: after n_max samples of opacity
+// op_max the accumulated alpha is 1 - (1 - op_max)^n_max. Evaluated by one wave.
+__device__ __forceinline__ unsigned int may_terminate(const float4 *t, int R, float inv_sr, float n_max) {
+    const int lane = threadIdx.x & 63;
+    float amax = 0.0f;
+    for (int k = lane; k < R; k += 64) {
+        const float a = t[k].w;
+        amax = (a != a) ? 1.0f : fmaxf(amax, a);  // NaN alpha: assume anything can happen
+    }
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+    const float op = 1.0f - powf(fmaxf(1.0f - fminf(amax, 1.0f), 0.0f), inv_sr);
+    const float remain = powf(1.0f - op, n_max);  // transmittance left after the longest possible ray
+    return (remain <= 0.02f) ? 1u : 0u;           // 0.01 is the exact bound; keep a margin
+}
+// forward = 1 additionally initialises the workspace header for this call: repair counter, per-view "may terminate"
+// flags (n_max > 0: the alpha pre-pass is available) and the mark -- no separate memset / flag kernel.
 template <typename VT>
-static __global__ __launch_bounds__(256) void brick_ctx_kernel(BrickParams<VT> P, BrickCtxRec *out, int nbricks, int forward) {
+static __global__ __launch_bounds__(256) void brick_ctx_kernel(BrickParams<VT> P, BrickCtxRec *out, int nbricks, int forward,
+                                                              float n_max) {
     const int b = blockIdx.x * 256 + threadIdx.x, view = blockIdx.y;
+    if (forward && blockIdx.x == 0 && threadIdx.x < 64) {  // first wave of the view's first block
+        const unsigned int flag = n_max > 0.0f ? may_terminate(P.tf + view * P.tf_vs, P.R, P.inv_sr, n_max) : 0u;
+        if (threadIdx.x == 0) {
+            if (view < 48) P.stats[2 + view] = flag;  // (more views: no pre-pass, nobody reads the flags)
+            if (view == 0) { P.stats[0] = 0u; P.stats[51] = DR_CTX_MARK; }
+        }
+    }
     if (b >= nbricks) return;
     const f3 cam = make_f3(P.cam[3 * view], P.cam[3 * view + 1], P.cam[3 * view + 2]);
     BrickCtx c;
@@ -131,7 +155,6 @@ static __global__ __launch_bounds__(256) void brick_ctx_kernel(BrickParams<VT> P
     r.i0 = c.i0; r.i1 = c.i1; r.j0 = c.j0; r.j1 = c.j1; r.pad1 = 0;
     r.live = forward ? 0 : out[(size_t)view * nbricks + b].live;
     out[(size_t)view * nbricks + b] = r;
-    if (forward && b == 0 && view == 0) P.stats[51] = DR_CTX_MARK;
 }
 
 // Conservative sample-index range [s0, s1) of ray p inside the brick (exact membership is decided per
@@ -408,24 +431,6 @@ __device__ __forceinline__ void tri_scatter_lds(unsigned long long *dbox, int ba
     fix_add(dbox + base + BOX_SX + 1, a10 * fz, f);
     fix_add(dbox + base + BOX_SY + 1, a01 * fz, f);
     fix_add(dbox + base + BOX_SX + BOX_SY + 1, a11 * fz, f);
-}
-
-// Can any ray of a view terminate early? Upper bound from the largest TF alpha: after n_max samples of opacity
-// op_max the accumulated alpha is 1 - (1 - op_max)^n_max. One wave per view.
-static __global__ __launch_bounds__(64) void may_terminate_kernel(const float4 *tf, long tf_vs, int R, float inv_sr,
-                                                                  float n_max, unsigned int *flags) {
-    const float4 *t = tf + blockIdx.x * tf_vs;
-    float amax = 0.0f;
-    for (int k = threadIdx.x; k < R; k += 64) {
-        const float a = t[k].w;
-        amax = (a != a) ? 1.0f : fmaxf(amax, a);  // NaN alpha: assume anything can happen
-    }
-    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
-    if (threadIdx.x == 0) {
-        const float op = 1.0f - powf(fmaxf(1.0f - fminf(amax, 1.0f), 0.0f), inv_sr);
-        const float remain = powf(1.0f - op, n_max);  // transmittance left after the longest possible ray
-        flags[blockIdx.x] = (remain <= 0.02f) ? 1u : 0u;  // 0.01 is the exact bound; keep a margin
-    }
 }
 
 // max |x| over a buffer -> bits of the (non-negative) float, combined with atomicMax on the integer view

@@ -265,10 +265,11 @@ __global__ __launch_bounds__(256) void ray_cross_kernel(BrickParams<VT> P) {
     const int view = blockIdx.y;
     if (P.stats[2 + view] == 0u) return;  // uniform
     const int NP = P.W * P.H;
-    const int pl = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (pl >= NP) return;  // wave-uniform
+    const int lane = threadIdx.x & 63;
+    // waves walk over the rays (a bounded grid: gated off, the launch costs a few thousand workgroup exits)
+    for (int pl = blockIdx.x * 4 + (threadIdx.x >> 6); pl < NP; pl += 4 * (int)gridDim.x) {  // wave-uniform
     const size_t p = (size_t)view * NP + pl;
-    if (P.ws_steps[p] != -1) return;  // wave-uniform: no crossing to resolve
+    if (P.ws_steps[p] != -1) continue;  // wave-uniform: no crossing to resolve
     const float4 parked = reinterpret_cast<const float4 *>(P.out)[p];
     RayGeom rg;
     load_ray(P.entry, P.exit_, P.rays, P.nsamp, p, rg);
@@ -318,6 +319,7 @@ __global__ __launch_bounds__(256) void ray_cross_kernel(BrickParams<VT> P) {
         A = 0.0f; s = 0;
     }
     if (lane == 0) P.ws_steps[p] = s;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ B1
@@ -511,7 +513,7 @@ static int ray_alpha_dispatch(const MarchArgs &a, hipStream_t stream, bool cross
     Workspace w;
     ws_layout(a.workspace, a.n_views, NP, g, &w);
     BrickParams<VT> P = make_brick_params<VT>(a, w);
-    const dim3 grid2((NP + 255) / 256, a.n_views), grid3((NP + 3) / 4, a.n_views);
+    const dim3 grid2((NP + 255) / 256, a.n_views), grid3((NP + 3) / 4 < 8192 ? (NP + 3) / 4 : 8192, a.n_views);
     if (a.mode == DR_MODE_DIFF) {
         if (!cross) hipLaunchKernelGGL((ray_alpha_kernel<VT, DR_MODE_DIFF>), grid2, dim3(256), 0, stream, P);
         else hipLaunchKernelGGL((ray_cross_kernel<VT, DR_MODE_DIFF>), grid3, dim3(256), 0, stream, P);

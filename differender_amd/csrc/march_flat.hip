@@ -888,23 +888,29 @@ static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     const size_t need = ws_layout(a.workspace, a.n_views, NP, g, &w);
     if (!a.workspace || a.workspace_bytes < need) return DR_EINVAL;
     BrickParams<VT> P = make_brick_params<VT>(a, w);
-    hipError_t e = hipMemsetAsync(w.stats, 0, 256, stream);
-    if (e != hipSuccess) return (int)e;
+    hipError_t e;
+#if DR_PHASE_TIMING
+    if ((e = hipMemsetAsync(w.stats, 0, 256, stream)) != hipSuccess) return (int)e;  // the timing slots
+#endif
     e = hipMemsetAsync(w.seg_cnt, 0, w.cnt_bytes, stream);
     if (e != hipSuccess) return (int)e;
     const size_t lds = flat_lds_bytes<false>(a.R, false, false);
     const int nbricks = g.NBx * g.NBy * g.NBz;
     const dim3 grid1(nbricks, a.n_views);
-    hipLaunchKernelGGL(brick_ctx_kernel<VT>, dim3((nbricks + 255) / 256, a.n_views), dim3(256), 0, stream, P, w.ctx, nbricks, 1);
     // Alpha pre-pass (early-termination culling): only if the TF can make some ray reach alpha >= 0.99 -- decided on
-    // the device from max(alpha), the kernels of the pre-pass return at once otherwise.
+    // the device from max(alpha) by the first kernel (which also writes the brick records and resets the workspace
+    // header); the kernels of the pre-pass return at once otherwise. The header holds flags for 48 views.
     const bool prepass = a.n_views <= 48;
+    double n_max = 0.0;
     if (prepass) {
         const double diag = sqrt((double)(a.VX - 1) * (a.VX - 1) + (double)(a.VY - 1) * (a.VY - 1) + (double)(a.VZ - 1) * (a.VZ - 1));
-        double n_max = floor((double)a.sr * 2.0 * sqrt(3.0) * diag) + 1.0;  // longest chord of the box (VR.py:251-253)
+        n_max = floor((double)a.sr * 2.0 * sqrt(3.0) * diag) + 1.0;  // longest chord of the box (VR.py:251-253)
         if (a.mode == DR_MODE_DIFF && n_max > a.S) n_max = a.S;
-        hipLaunchKernelGGL(may_terminate_kernel, dim3(a.n_views), dim3(64), 0, stream, reinterpret_cast<const float4 *>(a.tf),
-                           (long)(a.tf_vs / 4), a.R, 1.0f / a.sr, (float)n_max, w.stats + 2);
+        if (n_max < 1.0) n_max = 1.0;
+    }
+    hipLaunchKernelGGL(brick_ctx_kernel<VT>, dim3((nbricks + 255) / 256, a.n_views), dim3(256), 0, stream, P, w.ctx, nbricks, 1,
+                       (float)n_max);
+    if (prepass) {
         // The pre-pass runs front to back in G groups of brick layers; after each group the rays that have reached
         // alpha >= 0.99 are known and the next group does not march them (with the reference's tf1 preset three
         // quarters of all samples lie behind the termination point): ground-truth renders at sampling rate 8 take
@@ -966,7 +972,7 @@ static int flat_bwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     const dim3 grid1(g.NBx * g.NBy * g.NBz, a.n_views);
     hipError_t e = hipMemsetAsync(w.stats + 1, 0, 4, stream);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(brick_ctx_kernel<VT>, dim3((grid1.x + 255) / 256, a.n_views), dim3(256), 0, stream, P, w.ctx, (int)grid1.x, 0);
+    hipLaunchKernelGGL(brick_ctx_kernel<VT>, dim3((grid1.x + 255) / 256, a.n_views), dim3(256), 0, stream, P, w.ctx, (int)grid1.x, 0, 0.0f);
     const size_t ng = (size_t)a.n_views * NP * 4;
     const size_t nb = (ng + 256 * 16 - 1) / (256 * 16);
     hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(nb > 1024 ? 1024 : nb)), dim3(256), 0, stream, a.grad_out, ng,
