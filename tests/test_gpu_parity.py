@@ -551,3 +551,45 @@ def test_image_bands_reproduce_the_whole_image(oracle, F):
     assert ok, err
     ok, err = grad_close(dt_sum.cpu().numpy(), dt.cpu().numpy(), 2e-5)
     assert ok, err
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_configurations(oracle, hiplib, seed):
+    """Fuzz: random volume shapes, image shapes, TF sizes and contents, cameras (any direction and distance, sometimes
+    inside the volume), sampling rates, jitter, modes -- fast path against the oracle on the same ray buffers."""
+    from differender_amd import functional as Fn
+    rng = np.random.default_rng(1000 + seed)
+    vshape = tuple(int(v) for v in rng.integers(9, 45, 3))
+    WH = (int(rng.integers(5, 40)), int(rng.integers(5, 40)))
+    R = int(rng.choice([2, 5, 16, 64, 200]))
+    sr = float(rng.choice([0.6, 1.0, 1.5, 2.0, 3.5]))
+    mode = int(rng.integers(0, 2))
+    vol_h = rng.random(vshape, dtype=np.float32)
+    # smooth it a little so that normals are not pure noise, keep it in [0, 1]
+    for ax in range(3):
+        vol_h = (vol_h + np.roll(vol_h, 1, ax) + np.roll(vol_h, -1, ax)) / 3.0
+    vol_h = np.ascontiguousarray(vol_h.astype(np.float32))
+    tf_h = rng.random((R, 4), dtype=np.float32)
+    tf_h[:, 3] *= float(rng.choice([0.02, 0.2, 0.9]))          # from "never terminates" to "terminates at once"
+    d = rng.standard_normal(3); d /= np.linalg.norm(d)
+    if abs(d[1]) > 0.97:                                       # looking (anti)parallel to the up vector is degenerate in VR.py:143
+        d = np.array([0.6, 0.3, 0.74]); d /= np.linalg.norm(d)
+    cam_h = (d * float(rng.choice([0.5, 1.2, 2.5, 6.0]))).astype(np.float32)
+    jitter = int(rng.integers(0, 2)) * 12345
+    vol, tf, cam = T(vol_h), T(tf_h), T(np.atleast_2d(cam_h))
+    e, x, r, n = Fn.ray_setup(cam, WH, vshape, sr, jitter_seed=jitter)
+    eh, xh, rh, nh = (t[0].cpu().numpy() for t in (e, x, r, n))
+    ws = Fn.alloc_workspace(1, WH, vshape, R, dev())
+    out, steps = Fn.march_fwd(vol, tf, cam, e, x, r, n, 5000, sr, mode, workspace=ws)
+    ref, sref = oracle.march_fwd(vol_h, tf_h, cam_h, eh, xh, rh, nh, 5000, sr, mode)
+    assert np.isfinite(ref).all()
+    assert np.array_equal(steps[0].cpu().numpy(), sref), (vshape, WH, R, sr, mode, cam_h)
+    assert np.abs(out[0].cpu().numpy() - ref).max() <= FWD_TOL, (vshape, WH, R, sr, mode, cam_h)
+    if mode == 0:
+        g = rng.standard_normal(out.shape).astype(np.float32)
+        dv, dt = Fn.march_bwd(vol, tf, cam, e, x, r, n, 5000, sr, T(g), out, workspace=ws)
+        dv_o, dt_o = oracle.march_bwd(vol_h, tf_h, cam_h, eh, xh, rh, nh, 5000, sr, g[0])
+        ok, err = grad_close(dv.cpu().numpy(), dv_o)
+        assert ok, (err, vshape, WH, R, sr, cam_h)
+        ok, err = grad_close(dt.cpu().numpy(), dt_o)
+        assert ok, (err, vshape, WH, R, sr, cam_h)
