@@ -403,10 +403,10 @@ __device__ __forceinline__ void fix_add_wide(unsigned long long *p, float x, con
 // Common case: |x * 2^shift| < 2^31 -- one multiply, one float->int conversion (exact to 2^-shift), a sign
 // extension. Callers test the magnitude once per sample (fix_fits) and pick WIDE under a wave-uniform branch.
 __device__ __forceinline__ bool fix_fits(float absmax, const FixScale &f) { return absmax * f.lo < 2147483520.0f; }
-template <bool WIDE>
+template <bool WIDE, bool PRE = false>  // PRE: x already carries the factor 2^shift
 __device__ __forceinline__ void fix_add_t(unsigned long long *p, float x, const FixScale &f) {
     if (WIDE) { fix_add_wide(p, x, f); return; }
-    const int q = (int)(x * f.lo);  // truncation: <= 1 unit of 2^-shift (~4e-9 max|grad_out|) per add
+    const int q = (int)(PRE ? x : x * f.lo);  // truncation: <= 1 unit of 2^-shift (~4e-9 max|grad_out|) per add
 #ifdef DR_ABL_NOATOMIC
     asm volatile("" :: "v"(p), "v"((unsigned long long)(long long)q));
 #else

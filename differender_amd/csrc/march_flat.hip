@@ -415,24 +415,24 @@ __device__ __forceinline__ Over shfl_up1_over(const Over &v) {
     return r;
 }
 
-template <bool WIDE>
+template <bool WIDE, bool PRE = false>
 __device__ __forceinline__ void scatter8(unsigned long long *dbox, int base, const float (&w)[8], const FixScale &f) {
-    fix_add_t<WIDE>(dbox + base, w[0], f);
-    fix_add_t<WIDE>(dbox + base + BOX_SX, w[1], f);
-    fix_add_t<WIDE>(dbox + base + BOX_SY, w[2], f);
-    fix_add_t<WIDE>(dbox + base + BOX_SX + BOX_SY, w[3], f);
-    fix_add_t<WIDE>(dbox + base + 1, w[4], f);
-    fix_add_t<WIDE>(dbox + base + BOX_SX + 1, w[5], f);
-    fix_add_t<WIDE>(dbox + base + BOX_SY + 1, w[6], f);
-    fix_add_t<WIDE>(dbox + base + BOX_SX + BOX_SY + 1, w[7], f);
+    fix_add_t<WIDE, PRE>(dbox + base, w[0], f);
+    fix_add_t<WIDE, PRE>(dbox + base + BOX_SX, w[1], f);
+    fix_add_t<WIDE, PRE>(dbox + base + BOX_SY, w[2], f);
+    fix_add_t<WIDE, PRE>(dbox + base + BOX_SX + BOX_SY, w[3], f);
+    fix_add_t<WIDE, PRE>(dbox + base + 1, w[4], f);
+    fix_add_t<WIDE, PRE>(dbox + base + BOX_SX + 1, w[5], f);
+    fix_add_t<WIDE, PRE>(dbox + base + BOX_SY + 1, w[6], f);
+    fix_add_t<WIDE, PRE>(dbox + base + BOX_SX + BOX_SY + 1, w[7], f);
 }
 // the four voxels base + {0, SA, SB, SA+SB} receive c * w[0..3]
-template <bool WIDE, int SA, int SB>
+template <bool WIDE, int SA, int SB, bool PRE = false>
 __device__ __forceinline__ void scatter4(unsigned long long *dbox, int base, float c, const float (&w)[4], const FixScale &f) {
-    fix_add_t<WIDE>(dbox + base, c * w[0], f);
-    fix_add_t<WIDE>(dbox + base + SA, c * w[1], f);
-    fix_add_t<WIDE>(dbox + base + SB, c * w[2], f);
-    fix_add_t<WIDE>(dbox + base + SA + SB, c * w[3], f);
+    fix_add_t<WIDE, PRE>(dbox + base, c * w[0], f);
+    fix_add_t<WIDE, PRE>(dbox + base + SA, c * w[1], f);
+    fix_add_t<WIDE, PRE>(dbox + base + SB, c * w[2], f);
+    fix_add_t<WIDE, PRE>(dbox + base + SA + SB, c * w[3], f);
 }
 // Adjoint of the two central-difference taps of one axis, reduced to coefficients along that axis over the box
 // planes l0-1 .. l0+2 (l0 = centre cell). The +delta tap sits in cell l0 or l0+1, the -delta tap in l0-1 or l0
@@ -452,7 +452,7 @@ __device__ __forceinline__ void tap_line(int l0, int lp, int lm, float fp, float
 // lands there is summed into the centre's 8 corners first (8 LDS adds); what remains per axis is one outside
 // plane of 4 voxels (l0+2 or l0-1; both only when delta >= 0.5 voxel, i.e. dim > 1000: rare uniform branch).
 // 8 + 3*4 = 20 LDS adds per sample instead of 8 per tap.
-template <bool WIDE>
+template <bool WIDE, bool PRE = false>
 __device__ __forceinline__ void scatter_sample(unsigned long long *dbox, const TapCoords &t, bool valid, int cbase_i,
                                                float I_bar, const float (&gq)[3], const FixScale &fs) {
     const float X[2] = {1.0f - t.fx, t.fx}, Y[2] = {1.0f - t.fy, t.fy}, Z[2] = {1.0f - t.fz, t.fz};
@@ -472,22 +472,22 @@ __device__ __forceinline__ void scatter_sample(unsigned long long *dbox, const T
     }
     {   // x: outside plane l0+2 (coefficient cx[3]) or l0-1 (cx[0])
         const bool hi = cx[3] != 0.0f, lo = cx[0] != 0.0f;
-        if (valid && (hi || lo)) scatter4<WIDE, BOX_SY, 1>(dbox, cbase_i + (hi ? 2 * BOX_SX : -BOX_SX), hi ? cx[3] : cx[0], YZ, fs);
-        if (__any(valid && hi && lo)) { if (valid && hi && lo) scatter4<WIDE, BOX_SY, 1>(dbox, cbase_i - BOX_SX, cx[0], YZ, fs); }
+        if (valid && (hi || lo)) scatter4<WIDE, BOX_SY, 1, PRE>(dbox, cbase_i + (hi ? 2 * BOX_SX : -BOX_SX), hi ? cx[3] : cx[0], YZ, fs);
+        if (__any(valid && hi && lo)) { if (valid && hi && lo) scatter4<WIDE, BOX_SY, 1, PRE>(dbox, cbase_i - BOX_SX, cx[0], YZ, fs); }
     }
     {   // y
         const bool hi = cy[3] != 0.0f, lo = cy[0] != 0.0f;
-        if (valid && (hi || lo)) scatter4<WIDE, BOX_SX, 1>(dbox, cbase_i + (hi ? 2 * BOX_SY : -BOX_SY), hi ? cy[3] : cy[0], XZ, fs);
-        if (__any(valid && hi && lo)) { if (valid && hi && lo) scatter4<WIDE, BOX_SX, 1>(dbox, cbase_i - BOX_SY, cy[0], XZ, fs); }
+        if (valid && (hi || lo)) scatter4<WIDE, BOX_SX, 1, PRE>(dbox, cbase_i + (hi ? 2 * BOX_SY : -BOX_SY), hi ? cy[3] : cy[0], XZ, fs);
+        if (__any(valid && hi && lo)) { if (valid && hi && lo) scatter4<WIDE, BOX_SX, 1, PRE>(dbox, cbase_i - BOX_SY, cy[0], XZ, fs); }
     }
     {   // z
         const bool hi = cz[3] != 0.0f, lo = cz[0] != 0.0f;
-        if (valid && (hi || lo)) scatter4<WIDE, BOX_SX, BOX_SY>(dbox, cbase_i + (hi ? 2 : -1), hi ? cz[3] : cz[0], XY, fs);
-        if (__any(valid && hi && lo)) { if (valid && hi && lo) scatter4<WIDE, BOX_SX, BOX_SY>(dbox, cbase_i - 1, cz[0], XY, fs); }
+        if (valid && (hi || lo)) scatter4<WIDE, BOX_SX, BOX_SY, PRE>(dbox, cbase_i + (hi ? 2 : -1), hi ? cz[3] : cz[0], XY, fs);
+        if (__any(valid && hi && lo)) { if (valid && hi && lo) scatter4<WIDE, BOX_SX, BOX_SY, PRE>(dbox, cbase_i - 1, cz[0], XY, fs); }
     }
     // (Consecutive lanes are consecutive samples of a ray, ~3.5 per cell: these eight adds collide in the LDS, ~7 cycles
     // per duplicate address. Summing the runs across lanes first was tried twice: +1.0 ms of VALU for 0.4 ms of LDS.)
-    if (valid) scatter8<WIDE>(dbox, cbase_i, acc, fs);
+    if (valid) scatter8<WIDE, PRE>(dbox, cbase_i, acc, fs);
 }
 
 // ALPHA (forward only): the alpha pre-pass -- centre tap + TF only, the partial of a segment is its accumulated alpha.
@@ -812,7 +812,10 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
                     }
                     const float bound = fabsf(I_bar) + (fabsf(gq[0]) + fabsf(gq[1]) + fabsf(gq[2]));
                     if (__any(!fix_fits(bound, fs))) scatter_sample<true>(L.dbox, t, valid, cbase_i, I_bar, gq, fs);
-                    else scatter_sample<false>(L.dbox, t, valid, cbase_i, I_bar, gq, fs);
+                    else {  // common case: scale the four adjoints once instead of the twenty addends
+                        const float gs[3] = {gq[0] * fs.lo, gq[1] * fs.lo, gq[2] * fs.lo};
+                        scatter_sample<false, true>(L.dbox, t, valid, cbase_i, I_bar * fs.lo, gs, fs);
+                    }
                 }
             }
         }
