@@ -807,12 +807,15 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
                     float I_bar = 0.f;
                     float gq[3] = {0.f, 0.f, 0.f};
                     if (valid) {
-                        I_bar = fix_clamp(intensity_adjoint(sm, L.tf[sm.lo], L.tf[sm.hi], ad, P.tf_len), fs);
-                        if (!sm.flat) { gq[0] = fix_clamp(ad.gx, fs); gq[1] = fix_clamp(ad.gy, fs); gq[2] = fix_clamp(ad.gz, fs); }
+                        I_bar = intensity_adjoint(sm, L.tf[sm.lo], L.tf[sm.hi], ad, P.tf_len);
+                        if (!sm.flat) { gq[0] = ad.gx; gq[1] = ad.gy; gq[2] = ad.gz; }
                     }
+                    // (a NaN or an overflow makes the test fail: the exact path below clamps, the common one need not)
                     const float bound = fabsf(I_bar) + (fabsf(gq[0]) + fabsf(gq[1]) + fabsf(gq[2]));
-                    if (__any(!fix_fits(bound, fs))) scatter_sample<true>(L.dbox, t, valid, cbase_i, I_bar, gq, fs);
-                    else {  // common case: scale the four adjoints once instead of the twenty addends
+                    if (__any(!fix_fits(bound, fs))) {
+                        const float gc[3] = {fix_clamp(gq[0], fs), fix_clamp(gq[1], fs), fix_clamp(gq[2], fs)};
+                        scatter_sample<true>(L.dbox, t, valid, cbase_i, fix_clamp(I_bar, fs), gc, fs);
+                    } else {  // common case: scale the four adjoints once instead of the twenty addends
                         const float gs[3] = {gq[0] * fs.lo, gq[1] * fs.lo, gq[2] * fs.lo};
                         scatter_sample<false, true>(L.dbox, t, valid, cbase_i, I_bar * fs.lo, gs, fs);
                     }

@@ -593,3 +593,28 @@ def test_random_configurations(oracle, hiplib, seed):
         assert ok, (err, vshape, WH, R, sr, cam_h)
         ok, err = grad_close(dt.cpu().numpy(), dt_o)
         assert ok, (err, vshape, WH, R, sr, cam_h)
+
+
+def test_backward_with_non_finite_upstream_gradient(oracle, F):
+    """NaN / inf / huge entries in grad_out take the exact (clamping) accumulation path: the gradients stay finite,
+    and the pixels with ordinary upstream gradients still produce the ordinary result."""
+    vol_h, tf_h, cam_h = scene(oracle, N=32, R=32, tf="peaks")
+    WH = (24, 24)
+    vol, tf, cam = T(vol_h), T(tf_h), T(np.atleast_2d(cam_h))
+    e, x, r, n = F.ray_setup(cam, WH, vol.shape, 1.0, 30.0, 0.1, 0, 0)
+    out, _ = F.march_fwd(vol, tf, cam, e, x, r, n, 4096, 1.0)
+    g = np.random.default_rng(4).standard_normal((1, *WH, 4)).astype(np.float32)
+    g_bad = g.copy()
+    g_bad[0, 3, 4, 0] = np.nan; g_bad[0, 10, 11, 3] = np.inf; g_bad[0, 17, 5, 1] = -3e30
+    dv, dt = F.march_bwd(vol, tf, cam, e, x, r, n, 4096, 1.0, T(g_bad), out)
+    if F.variant != 1:  # (the baseline kernels propagate NaN like the reference; RaycastFunction applies nan_to_num)
+        assert torch.isfinite(dv).all() and torch.isfinite(dt).all()
+    # the same with the three pixels zeroed, against the oracle: only voxels on those three rays may differ
+    g_ok = g.copy()
+    for (i, j) in ((3, 4), (10, 11), (17, 5)):
+        g_ok[0, i, j] = 0.0
+    eh, xh, rh, nh = (t[0].cpu().numpy() for t in (e, x, r, n))
+    dv_o, dt_o = oracle.march_bwd(vol_h, tf_h, cam_h, eh, xh, rh, nh, 4096, 1.0, g_ok[0])
+    dv2, dt2 = F.march_bwd(vol, tf, cam, e, x, r, n, 4096, 1.0, T(g_ok), out)
+    ok, err = grad_close(dv2.cpu().numpy(), dv_o)
+    assert ok, err
