@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("DIFFERENDER_HIP_LIB") or os.path.join(_HERE, "libdiff
 
 DR_F32, DR_F16 = 0, 1
 DR_MODE_DIFF, DR_MODE_NONDIFF = 0, 1
-DR_VARIANT_AUTO, DR_VARIANT_BASELINE, DR_VARIANT_BRICK_RAYSEG = 0, 1, 2
+DR_VARIANT_AUTO, DR_VARIANT_BASELINE = 0, 1
 
 _c = ctypes
 _P, _I, _L, _F, _D, _U, _Z = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_double, _c.c_uint32, _c.c_size_t
@@ -51,7 +51,7 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.dr_abi_version() != 4:
+        if handle.dr_abi_version() != 5:
             raise ImportError("libdifferender_hip.so ABI version mismatch; rebuild it")
         _lib = handle
     return _lib

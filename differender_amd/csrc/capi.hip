@@ -78,14 +78,12 @@ int dr_march_fwd_rows(const void *vol, int vol_dtype, int VX, int VY, int VZ, in
     if (row0 < 0 || img_W < W || row0 > img_W - W) return DR_EINVAL;
     a.img_W = img_W; a.row0 = row0;
     if (mode != DR_MODE_DIFF && mode != DR_MODE_NONDIFF) return DR_EINVAL;
-    if (variant < DR_VARIANT_AUTO || variant > DR_VARIANT_BRICK_RAYSEG) return DR_EINVAL;
+    if (variant < DR_VARIANT_AUTO || variant > DR_VARIANT_BASELINE) return DR_EINVAL;
     a.mode = mode; a.out = out_rgba; a.steps = steps;
     a.fov_rad = fov_rad; a.near_plane = near_plane; a.workspace = workspace; a.workspace_bytes = workspace_bytes;
     if (variant != DR_VARIANT_BASELINE && workspace && brick_path_supported(VX, VY, VZ, R)) {
         if (workspace_bytes < brick_workspace_bytes(n_views, W, H, VX, VY, VZ)) return DR_EINVAL;
-        if (variant == DR_VARIANT_AUTO && flat_path_supported(VX, VY, VZ, R) && flat_strides_ok(sx, sy, sz))
-            return launch_march_fwd_flat(a, (hipStream_t)stream);
-        return launch_march_fwd_brick(a, (hipStream_t)stream);
+        if (flat_strides_ok(sx, sy, sz)) return launch_march_fwd_flat(a, (hipStream_t)stream);
     }
     return launch_march_fwd_baseline(a, (hipStream_t)stream);
 }
@@ -114,7 +112,7 @@ int dr_march_bwd_rows(const void *vol, int vol_dtype, int VX, int VY, int VZ, in
     if (!grad_out || !out_rgba) return DR_EINVAL;
     if (row0 < 0 || img_W < W || row0 > img_W - W) return DR_EINVAL;
     a.img_W = img_W; a.row0 = row0;
-    if (variant < DR_VARIANT_AUTO || variant > DR_VARIANT_BRICK_RAYSEG) return DR_EINVAL;
+    if (variant < DR_VARIANT_AUTO || variant > DR_VARIANT_BASELINE) return DR_EINVAL;
     if (dtf_view_stride % 4 != 0) return DR_EINVAL;
     if (!d_vol && !d_tf) return 0;  // nothing requested
     a.mode = DR_MODE_DIFF;
@@ -124,10 +122,8 @@ int dr_march_bwd_rows(const void *vol, int vol_dtype, int VX, int VY, int VZ, in
     a.fov_rad = fov_rad; a.near_plane = near_plane; a.workspace = workspace; a.workspace_bytes = workspace_bytes;
     if (variant != DR_VARIANT_BASELINE && workspace && brick_path_supported(VX, VY, VZ, R)) {
         if (workspace_bytes < brick_workspace_bytes(n_views, W, H, VX, VY, VZ)) return DR_EINVAL;
-        if (variant == DR_VARIANT_AUTO && flat_path_supported(VX, VY, VZ, R) && flat_strides_ok(sx, sy, sz) &&
-            (!d_vol || flat_strides_ok(dsx, dsy, dsz)))
+        if (flat_strides_ok(sx, sy, sz) && (!d_vol || flat_strides_ok(dsx, dsy, dsz)))
             return launch_march_bwd_flat(a, (hipStream_t)stream);
-        return launch_march_bwd_brick(a, (hipStream_t)stream);
     }
     return launch_march_bwd_baseline(a, (hipStream_t)stream);
 }

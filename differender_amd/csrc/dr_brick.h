@@ -1,4 +1,4 @@
-// dr_brick.h -- geometry shared by the brick-centric march kernels (march_brick.hip).
+// dr_brick.h -- geometry shared by the brick-centric march kernels (march_flat.hip, ray_passes.hip).
 //
 // The volume's cells (one cell = the unit cube between 8 voxels, indexed by the low voxel) are grouped
 // into bricks of BRK^3 cells. A sample belongs to the brick that holds the cell of its centre tap; the
@@ -33,7 +33,6 @@ constexpr int BOX_SY = BOX + DR_BOX_PADY;
 constexpr int BOX_SX = BOX * BOX_SY + DR_BOX_PADX;
 constexpr int BOX_VOX = BOX * BOX * BOX;   // voxels staged per brick
 constexpr int BOX_LDS = BOX * BOX_SX;      // LDS elements reserved for them
-constexpr int ECHUNK = 512;                // ray segments listed per round
 constexpr float BRICK_EPS = 5e-5f;         // world-space slack of the conservative ray/brick tests (float error: ~2e-7)
 
 struct BrickGrid {

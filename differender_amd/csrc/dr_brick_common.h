@@ -1,6 +1,6 @@
-// dr_brick_common.h -- pieces shared by the brick-centric kernel files (march_brick.hip: one lane per ray
-// segment; march_flat.hip: one lane per sample): parameters, brick geometry, LDS staging, tap evaluation,
-// 64-bit fixed-point LDS accumulation, workspace layout.
+// dr_brick_common.h -- pieces shared by the brick-centric kernel files (march_flat.hip: the per-brick passes, one
+// lane per sample; ray_passes.hip: the per-ray passes): parameters, brick geometry, tap evaluation, 64-bit
+// fixed-point LDS accumulation, workspace layout.
 #pragma once
 #include "dr_brick.h"
 #include "dr_kernels.h"
@@ -183,102 +183,7 @@ __device__ __forceinline__ bool segment_range(const BrickCtx &c, f3 cam, f3 vd, 
     return s1 > s0;
 }
 
-struct LdsLayout {
-    float4 *tf; float *box; unsigned long long *dbox; unsigned long long *dtf;
-    int *e_pix, *e_s0, *e_cnt; unsigned short *order; int *hist; int *misc;
-};
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
-__host__ __device__ inline size_t brick_lds_bytes(int R, bool bwd_vol, bool bwd_tf) {
-    size_t s = (size_t)R * 16 + align16(BOX_LDS * 4);
-    if (bwd_vol) s += align16(BOX_LDS * 8);
-    if (bwd_tf) s += (size_t)R * 32;
-    s += 3 * ECHUNK * 4 + ECHUNK * 2 + 128 * 4 + 16;
-    return s;
-}
-__device__ __forceinline__ LdsLayout carve(unsigned char *smem, int R, bool bwd_vol, bool bwd_tf) {
-    LdsLayout L;
-    size_t o = 0;
-    L.tf = reinterpret_cast<float4 *>(smem + o); o += (size_t)R * 16;
-    L.box = reinterpret_cast<float *>(smem + o); o += align16(BOX_LDS * 4);
-    L.dbox = nullptr; L.dtf = nullptr;
-    if (bwd_vol) { L.dbox = reinterpret_cast<unsigned long long *>(smem + o); o += align16(BOX_LDS * 8); }
-    if (bwd_tf) { L.dtf = reinterpret_cast<unsigned long long *>(smem + o); o += (size_t)R * 32; }
-    L.e_pix = reinterpret_cast<int *>(smem + o); o += ECHUNK * 4;
-    L.e_s0 = reinterpret_cast<int *>(smem + o); o += ECHUNK * 4;
-    L.e_cnt = reinterpret_cast<int *>(smem + o); o += ECHUNK * 4;
-    L.order = reinterpret_cast<unsigned short *>(smem + o); o += ECHUNK * 2;
-    L.hist = reinterpret_cast<int *>(smem + o); o += 128 * 4;
-    L.misc = reinterpret_cast<int *>(smem + o);
-    return L;
-}
-
-// Stage TF and the brick's voxel box in LDS. Global reads walk the axis with the smallest stride.
-template <typename VT>
-__device__ __forceinline__ void load_tf_and_box(const BrickParams<VT> &P, const VolView<VT> &vol, const BrickCtx &c,
-                                                const float4 *tfg, LdsLayout &L) {
-    for (int k = threadIdx.x; k < P.R; k += 256) L.tf[k] = tfg[k];
-    const int fast = (vol.sx <= vol.sy && vol.sx <= vol.sz) ? 0 : ((vol.sy <= vol.sz) ? 1 : 2);
-    for (int idx = threadIdx.x; idx < BOX_VOX; idx += 256) {
-        const int a = idx % BOX, b = (idx / BOX) % BOX, d = idx / (BOX * BOX);
-        int lx, ly, lz;
-        if (fast == 0) { lx = a; ly = b; lz = d; } else if (fast == 1) { ly = a; lx = b; lz = d; } else { lz = a; ly = b; lx = d; }
-        const int gx = c.ox + lx, gy = c.oy + ly, gz = c.oz + lz;
-        float v = 0.0f;
-        if (gx >= 0 && gx < vol.VX && gy >= 0 && gy < vol.VY && gz >= 0 && gz < vol.VZ)
-            v = ld_voxel(vol.p + gx * vol.sx + gy * vol.sy + gz * vol.sz);
-        L.box[lx * BOX_SX + ly * BOX_SY + lz] = v;
-    }
-}
-
-// One round of segment listing: candidates [cbase, cbase+ECHUNK) of the pixel rectangle -> sorted entry list.
-// SKIPFLAG: backward skips irregular rays (flagged by F2) and clips to the live sample count.
-template <typename VT, bool BWD>
-__device__ __forceinline__ int build_entries(const BrickParams<VT> &P, const BrickCtx &c, f3 cam, int view, int cbase,
-                                             int ncand, int mode, LdsLayout &L) {
-    const int NP = P.W * P.H;
-    if (threadIdx.x < 128) L.hist[threadIdx.x] = 0;
-    if (threadIdx.x == 0) L.misc[0] = 0;
-    __syncthreads();
-    const int nj = c.j1 - c.j0 + 1;
-    const int cend = min(ncand, cbase + ECHUNK);
-    for (int cc = cbase + threadIdx.x; cc < cend; cc += 256) {
-        const int i = c.i0 + cc / nj, j = c.j0 + cc % nj;
-        const int pl = i * P.H + j;
-        const size_t p = (size_t)view * NP + pl;
-        const int n = P.nsamp[p];
-        const float entry = P.entry[p];
-        if (!ray_is_regular(n, entry)) continue;
-        int nmarch = (mode == DR_MODE_DIFF && n > P.S) ? P.S : n;
-        if (BWD) {
-            if (P.rayflag[p]) continue;
-            nmarch = min(nmarch, P.ws_steps[p]);
-        }
-        const float exit_ = P.exit_[p];
-        const f3 vd = make_f3(P.rays[3 * p], P.rays[3 * p + 1], P.rays[3 * p + 2]);
-        const float t0 = entry + 0.5f * (exit_ - entry) / (float)n;
-        int s0, s1;
-        if (!segment_range(c, cam, vd, t0, exit_, n, nmarch, s0, s1)) continue;
-        const int slot = atomicAdd(&L.misc[0], 1);
-        L.e_pix[slot] = pl; L.e_s0[slot] = s0; L.e_cnt[slot] = s1 - s0;
-        atomicAdd(&L.hist[min(s1 - s0, 127)], 1);
-    }
-    __syncthreads();
-    const int nE = L.misc[0];
-    // descending counting sort by segment length
-    int start = 0;
-    if (threadIdx.x < 128) {
-        for (int k = threadIdx.x + 1; k < 128; ++k) start += L.hist[k];
-    }
-    __syncthreads();
-    if (threadIdx.x < 128) L.hist[threadIdx.x] = start;
-    __syncthreads();
-    for (int e = threadIdx.x; e < nE; e += 256) {
-        const int pos = atomicAdd(&L.hist[min(L.e_cnt[e], 127)], 1);
-        L.order[pos] = (unsigned short)e;
-    }
-    __syncthreads();
-    return nE;
-}
 
 struct TapCoords {
     int lx, ly, lz;       // local (box) cell of the centre tap
@@ -287,17 +192,8 @@ struct TapCoords {
     float fxp, fxm, fyp, fym, fzp, fzm;
 };
 
-// All seven taps of one sample from the LDS box: intensity and central differences.
-__device__ __forceinline__ void sample_taps_lds(const float *box, const TapCoords &t, float &I, float &dx, float &dy,
-                                                float &dz) {
-    const int by = t.ly * BOX_SY, bz = t.lz, bx = t.lx * BOX_SX;
-    I = tri_lds(box, bx + by + bz, t.fx, t.fy, t.fz);
-    dx = tri_lds(box, t.lxp * BOX_SX + by + bz, t.fxp, t.fy, t.fz) - tri_lds(box, t.lxm * BOX_SX + by + bz, t.fxm, t.fy, t.fz);
-    dy = tri_lds(box, bx + t.lyp * BOX_SY + bz, t.fx, t.fyp, t.fz) - tri_lds(box, bx + t.lym * BOX_SY + bz, t.fx, t.fym, t.fz);
-    dz = tri_lds(box, bx + by + t.lzp, t.fx, t.fy, t.fzp) - tri_lds(box, bx + by + t.lzm, t.fx, t.fy, t.fzm);
-}
-
-// The same in two halves, so that the six normal taps can be skipped when no lane needs the lighting term.
+// Centre tap and the six normal taps from the LDS box (two halves, so that the normal taps can be skipped when no
+// lane needs the lighting term).
 __device__ __forceinline__ float sample_centre_lds(const float *box, const TapCoords &t) {
     return tri_lds(box, t.lx * BOX_SX + t.ly * BOX_SY + t.lz, t.fx, t.fy, t.fz);
 }
@@ -329,31 +225,6 @@ __device__ __forceinline__ bool sample_coords_at(const VolView<VT> &vol, const B
     axis_coord(sm.pz - delta, vol.scz, k, t.fzm); t.lzm = k - c.oz;
     return true;
 }
-// Position of sample s and its tap coordinates.
-template <typename VT>
-__device__ __forceinline__ bool sample_coords(const VolView<VT> &vol, const BrickCtx &c, const RayGeom &rg, f3 cam,
-                                              int s, Sample &sm, TapCoords &t) {
-    sample_pos(rg, cam.x, cam.y, cam.z, s, sm.px, sm.py, sm.pz);
-    return sample_coords_at(vol, c, sm, t);
-}
-
-// Tap coordinates alone, from a position (same arithmetic as sample_coords).
-template <typename VT>
-__device__ __forceinline__ void tap_coords(const VolView<VT> &vol, const BrickCtx &c, float px, float py, float pz,
-                                           TapCoords &t) {
-    const float delta = 1e-3f;
-    int k;
-    axis_coord(px, vol.scx, k, t.fx); t.lx = k - c.ox;
-    axis_coord(py, vol.scy, k, t.fy); t.ly = k - c.oy;
-    axis_coord(pz, vol.scz, k, t.fz); t.lz = k - c.oz;
-    axis_coord(px + delta, vol.scx, k, t.fxp); t.lxp = k - c.ox;
-    axis_coord(px - delta, vol.scx, k, t.fxm); t.lxm = k - c.ox;
-    axis_coord(py + delta, vol.scy, k, t.fyp); t.lyp = k - c.oy;
-    axis_coord(py - delta, vol.scy, k, t.fym); t.lym = k - c.oy;
-    axis_coord(pz + delta, vol.scz, k, t.fzp); t.lzp = k - c.oz;
-    axis_coord(pz - delta, vol.scz, k, t.fzm); t.lzm = k - c.oz;
-}
-
 __device__ __forceinline__ void load_ray(const float *entry, const float *exit_, const float *rays, const int32_t *nsamp,
                                          size_t p, RayGeom &rg) {
     rg.n = nsamp[p]; rg.entry = entry[p]; rg.exit_ = exit_[p];
@@ -416,21 +287,6 @@ __device__ __forceinline__ void fix_add_t(unsigned long long *p, float x, const 
 __device__ __forceinline__ void fix_add(unsigned long long *p, float x, const FixScale &f) { fix_add_wide(p, x, f); }
 __device__ __forceinline__ float fix_to_float(unsigned long long v, const FixScale &f) {
     return (float)((double)(long long)v * f.inv);
-}
-
-// adjoint of tri_lds into the fixed-point LDS box
-__device__ __forceinline__ void tri_scatter_lds(unsigned long long *dbox, int base, float fx, float fy, float fz,
-                                                float adj, const FixScale &f) {
-    const float gx = 1.0f - fx, gy = 1.0f - fy, gz = 1.0f - fz;
-    const float a00 = gx * gy * adj, a10 = fx * gy * adj, a01 = gx * fy * adj, a11 = fx * fy * adj;
-    fix_add(dbox + base, a00 * gz, f);
-    fix_add(dbox + base + BOX_SX, a10 * gz, f);
-    fix_add(dbox + base + BOX_SY, a01 * gz, f);
-    fix_add(dbox + base + BOX_SX + BOX_SY, a11 * gz, f);
-    fix_add(dbox + base + 1, a00 * fz, f);
-    fix_add(dbox + base + BOX_SX + 1, a10 * fz, f);
-    fix_add(dbox + base + BOX_SY + 1, a01 * fz, f);
-    fix_add(dbox + base + BOX_SX + BOX_SY + 1, a11 * fz, f);
 }
 
 // max |x| over a buffer -> bits of the (non-negative) float, combined with atomicMax on the integer view

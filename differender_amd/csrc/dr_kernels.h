@@ -36,12 +36,9 @@ int launch_march_bwd_baseline(const MarchArgs &a, hipStream_t stream);
 // Brick-centric kernels (DR_VARIANT_AUTO): LDS-staged bricks, per-(ray,layer) partial composites.
 bool brick_path_supported(int VX, int VY, int VZ, int R);
 size_t brick_workspace_bytes(int n_views, int W, int H, int VX, int VY, int VZ);
-int launch_march_fwd_brick(const MarchArgs &a, hipStream_t stream);  // one lane per ray segment
-int launch_march_bwd_brick(const MarchArgs &a, hipStream_t stream);
-int launch_ray_compose(const MarchArgs &a, hipStream_t stream);      // F2, shared by the brick pipelines
+int launch_ray_compose(const MarchArgs &a, hipStream_t stream);      // F2
 int launch_ray_alpha(const MarchArgs &a, hipStream_t stream);        // alpha pre-pass: per-ray composition of one phase
 int launch_ray_cross(const MarchArgs &a, hipStream_t stream);        // alpha pre-pass: exact termination sample of crossing rays
-bool flat_path_supported(int VX, int VY, int VZ, int R);
 bool flat_strides_ok(int64_t sx, int64_t sy, int64_t sz);  // 32-bit in-box offsets
 int launch_march_fwd_flat(const MarchArgs &a, hipStream_t stream);   // one lane per sample
 int launch_march_bwd_flat(const MarchArgs &a, hipStream_t stream);

@@ -1,8 +1,12 @@
 // march_flat.hip -- brick-centric march with ONE LANE PER SAMPLE (DR_VARIANT_AUTO fast path, gfx950).
 //
-// Same pipeline as march_brick.hip (LDS-staged 12^3-cell bricks, per-(ray,layer) partial composites, F2
-// per-ray composition, fixed-point LDS gradient boxes), but the work items of a brick are the SAMPLES of all
-// ray segments that cross it, laid out back to back ("flat" index): a wave takes 64 consecutive lanes' worth.
+// Why bricks: one marched sample needs 56 voxel fetches (7 trilinear taps, VR.py:153-203). Served as global gathers
+// they cost >= 25 cycles per wave-load on a CU (measured, tools/microbench); from LDS they cost 2-6. So the volume is
+// processed brick by brick: a workgroup stages one 12^3-cell brick (+apron: 15^3 voxels) in LDS with coalesced reads
+// and marches every ray segment that crosses it, leaving one partial composite per (ray, layer) for the per-ray
+// composition (F2, ray_passes.hip); the backward accumulates d_volume / d_tf in fixed-point LDS boxes and flushes
+// each once per brick. The work items of a brick are the SAMPLES of all ray segments that cross it, laid out back
+// to back ("flat" index): a wave takes 64 consecutive lanes' worth.
 //   * every lane is busy whatever the lengths of the individual segments (a brick holds only ~170 segments
 //     but ~7800 samples);
 //   * the 64 lanes of a load walk along one or two rays: few distinct cells per instruction on odd LDS
@@ -881,8 +885,9 @@ bool flat_strides_ok(int64_t sx, int64_t sy, int64_t sz) {
     const int64_t lim = ((int64_t)1 << 31) / (3 * BOX);
     return sx >= 0 && sy >= 0 && sz >= 0 && sx < lim && sy < lim && sz < lim;
 }
-bool flat_path_supported(int VX, int VY, int VZ, int R) {
-    if (!brick_path_supported(VX, VY, VZ, R)) return false;
+bool brick_path_supported(int VX, int VY, int VZ, int R) {
+    const int m = VX > VY ? (VX > VZ ? VX : VZ) : (VY > VZ ? VY : VZ);
+    if (m - 1 >= 2000) return false;       // normal taps must stay within one voxel of the centre cell
     return flat_lds_bytes<true>(R, true, true) <= 160 * 1024;
 }
 

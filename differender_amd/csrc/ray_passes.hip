@@ -1,0 +1,311 @@
+// ray_passes.hip -- the per-RAY passes of the brick-centric pipeline (gfx950); the per-BRICK passes (F1, the alpha
+// pre-pass P1, B1) live in march_flat.hip.
+//
+//   F2  ray_compose_kernel  per ray: composite the per-(ray, layer) partials of F1 front to back ("over" is
+//                           associative); without an alpha pre-pass the one segment in which alpha crosses 0.99 is
+//                           re-marched sample by sample so early termination stays exact (VR.py:267); irregular rays
+//                           are marched whole. Leaves the prefix (C, A) before every segment in the workspace for B1.
+//   P2  ray_alpha_kernel    per ray: composes the alpha-only partials of one phase of the pre-pass, finds the segment
+//                           in which the ray terminates.
+//   P2b ray_cross_kernel    one wave per terminating ray: the exact sample at which alpha reaches 0.99.
+//
+// Reference functions replaced: get_final_image[_nondiff] (VR.py:353-372) and the early-termination test of
+// raycast / raycast_nondiff (VR.py:267,318).
+#include "dr_brick_common.h"
+
+namespace dr {
+
+// ------------------------------------------------------------------------------------------------ F2
+// Layer (dr_brick.h) of the brick that holds sample s of a ray. Layers grow monotonically along a ray, so the
+// bricks of samples [0, n) all have layers between those of sample 0 and sample n-1: the per-ray passes only look
+// at that range of the [layer][pixel] workspace (typically 45-60 of 127 layers at 512^3).
+template <typename VT>
+__device__ __forceinline__ int sample_layer(const BrickParams<VT> &P, const RayGeom &rg, f3 cam, int s) {
+    float px, py, pz, fr;
+    int x0, y0, z0;
+    sample_pos(rg, cam.x, cam.y, cam.z, s, px, py, pz);
+    axis_coord(px, P.vol.scx, x0, fr); axis_coord(py, P.vol.scy, y0, fr); axis_coord(pz, P.vol.scz, z0, fr);
+    const int cbx = cam_brick(cam.x, P.vol.scx), cby = cam_brick(cam.y, P.vol.scy), cbz = cam_brick(cam.z, P.vol.scz);
+    const int lmin = axis_layer_min(cbx, P.g.NBx) + axis_layer_min(cby, P.g.NBy) + axis_layer_min(cbz, P.g.NBz);
+    return abs(x0 / BRK - cbx) + abs(y0 / BRK - cby) + abs(z0 / BRK - cbz) - lmin;
+}
+
+template <typename VT, int MODE>
+__global__ __launch_bounds__(256) void ray_compose_kernel(BrickParams<VT> P) {
+    extern __shared__ __attribute__((aligned(16))) float4 lds_tf[];
+    const int view = blockIdx.y;
+    const float4 *tfg = P.tf + view * P.tf_vs;
+    for (int k = threadIdx.x; k < P.R; k += 256) lds_tf[k] = tfg[k];
+    __syncthreads();
+    const int NP = P.W * P.H;
+    const int pl = blockIdx.x * 256 + threadIdx.x;
+    if (pl >= NP) return;
+    const size_t p = (size_t)view * NP + pl;
+    RayGeom rg;
+    load_ray(P.entry, P.exit_, P.rays, P.nsamp, p, rg);
+    float C0 = 0.f, C1 = 0.f, C2 = 0.f, A = 0.f;
+    int steps = 0;
+    uint8_t flag = 0;
+    if (rg.n > 0) {
+        VolView<VT> vol = P.vol;
+        vol.p += view * P.vol_vs;
+        const f3 cam = make_f3(P.cam[3 * view], P.cam[3 * view + 1], P.cam[3 * view + 2]);
+        const f3 light = make_f3(cam.x + 0.0f, cam.y + 1.0f, cam.z + 0.0f);
+        const f3 vd = make_f3(rg.vx, rg.vy, rg.vz);
+        int nmarch = (MODE == DR_MODE_DIFF && rg.n > P.S) ? P.S : rg.n;
+        const int nfull = nmarch;
+        const size_t seg0 = (size_t)view * P.g.NL * NP + pl;
+        bool regular = ray_is_regular(rg.n, rg.entry);
+        // with an alpha pre-pass the bricks marched exactly the live samples of the ray: no crossing to look for
+        const bool use_live = P.use_live && P.stats[2 + view] != 0u;
+        if (regular && use_live) nmarch = min(nmarch, P.ws_steps[p]);
+        int l_lo = 0, l_hi = P.g.NL - 1;
+        if (regular && nmarch > 0) {
+            l_lo = max(sample_layer(P, rg, cam, 0), 0);
+            l_hi = min(sample_layer(P, rg, cam, nmarch - 1), P.g.NL - 1);
+        }
+        if (regular) {
+            // safety net: the segments must account for every sample, else march this ray whole
+            int total = 0;
+            for (int l = l_lo; l <= l_hi; ++l) total += P.seg_cnt[seg0 + (size_t)l * NP];
+            if (total != nmarch) { regular = false; nmarch = nfull; atomicAdd(&P.stats[0], 1u); }
+        }
+        int s_from = 0, s_to = 0;  // samples to march one by one with early termination
+        if (!regular) {
+            flag = 1; s_to = nmarch;
+        } else {
+            int sacc = 0;
+            steps = nmarch;
+            for (int l = l_lo; l <= l_hi; ++l) {
+                const size_t si = seg0 + (size_t)l * NP;
+                const int cnt = P.seg_cnt[si];
+                if (cnt == 0) continue;
+                const float4 sg = P.seg_rgba[si];
+                if (MODE == DR_MODE_DIFF) P.seg_rgba[si] = make_float4(C0, C1, C2, A);  // prefix for the backward
+                const float T = 1.0f - A;
+                const float A_after = fmaf(T, sg.w, A);
+                if (!use_live && !(A_after < 0.99f)) {  // alpha crosses 0.99 inside this segment
+                    s_from = sacc; s_to = sacc + cnt;
+                    break;
+                }
+                C0 = fmaf(T, sg.x, C0); C1 = fmaf(T, sg.y, C1); C2 = fmaf(T, sg.z, C2);
+                A = A_after;
+                sacc += cnt;
+            }
+        }
+        if (s_to > s_from) {
+            steps = s_from;
+            for (int s = s_from; s < s_to; ++s) {
+                if (!(A < 0.99f)) break;
+                Sample sm;
+                sample_pos(rg, cam.x, cam.y, cam.z, s, sm.px, sm.py, sm.pz);
+                classify(vol, lds_tf, P.R, P.tf_len, P.inv_sr, sm);
+                ++steps;
+                if (MODE == DR_MODE_NONDIFF && !(sm.a > 1e-3f)) continue;
+                shade(vol, light, vd, MODE == DR_MODE_DIFF, sm);
+                const float T = 1.0f - A;
+                C0 = fmaf(T, sm.L * sm.r * sm.op, C0);
+                C1 = fmaf(T, sm.L * sm.g * sm.op, C1);
+                C2 = fmaf(T, sm.L * sm.b * sm.op, C2);
+                A = fmaf(T, sm.op, A);
+            }
+            // a regular ray that crossed 0.99 exactly on the last sample of its segment keeps marching
+            // nothing further: later segments are ignored (their first sample would see A >= 0.99).
+            if (!flag && A < 0.99f) {
+                // the partial composite crossed 0.99 but the exact recurrence did not (rounding): fall
+                // back to marching the rest of the ray sample by sample.
+                for (int s = s_to; s < nmarch; ++s) {
+                    if (!(A < 0.99f)) break;
+                    Sample sm;
+                    sample_pos(rg, cam.x, cam.y, cam.z, s, sm.px, sm.py, sm.pz);
+                    classify(vol, lds_tf, P.R, P.tf_len, P.inv_sr, sm);
+                    ++steps;
+                    if (MODE == DR_MODE_NONDIFF && !(sm.a > 1e-3f)) continue;
+                    shade(vol, light, vd, MODE == DR_MODE_DIFF, sm);
+                    const float T = 1.0f - A;
+                    C0 = fmaf(T, sm.L * sm.r * sm.op, C0);
+                    C1 = fmaf(T, sm.L * sm.g * sm.op, C1);
+                    C2 = fmaf(T, sm.L * sm.b * sm.op, C2);
+                    A = fmaf(T, sm.op, A);
+                }
+                flag = 1;  // its stored prefixes beyond s_to are stale: let B2 handle the whole ray
+            }
+        }
+    }
+    if (MODE == DR_MODE_NONDIFF) {
+        C0 = fminf(1.0f, C0); C1 = fminf(1.0f, C1); C2 = fminf(1.0f, C2); A = fminf(1.0f, A);
+    }
+    reinterpret_cast<float4 *>(P.out)[p] = make_float4(C0, C1, C2, A);
+    if (P.steps) P.steps[p] = steps;
+    P.ws_steps[p] = steps;
+    P.rayflag[p] = flag;
+}
+
+// ------------------------------------------------------------------------------------------------ P2
+// Alpha pre-pass, per ray: accumulated alpha does not depend on lighting (A_s = A_{s-1} + (1-A_{s-1}) op_s with
+// op_s a function of the centre tap only), so the sample at which a ray terminates can be found from alpha-only
+// partials at a fraction of the cost. Composes the alpha partials of the bricks front to back; the segment in which
+// alpha crosses 0.99 is re-marched sample by sample (centre tap from global memory) -- the same decisions, in the
+// same arithmetic, as ray_compose_kernel would take. Writes ws_steps[p] = exact number of live samples.
+template <typename VT, int MODE>
+__global__ __launch_bounds__(256) void ray_alpha_kernel(BrickParams<VT> P) {
+    const int view = blockIdx.y;
+    if (P.stats[2 + view] == 0u) return;  // uniform: no ray of this view can terminate, nothing to find
+    const int NP = P.W * P.H;
+    const int pl = blockIdx.x * 256 + threadIdx.x;
+    if (pl >= NP) return;
+    const size_t p = (size_t)view * NP + pl;
+    if (!P.pp_first && P.ws_steps[p] == -1) return;  // crossing found in an earlier phase
+    RayGeom rg;
+    load_ray(P.entry, P.exit_, P.rays, P.nsamp, p, rg);
+    const int nmarch = (MODE == DR_MODE_DIFF && rg.n > P.S) ? P.S : rg.n;
+    if (ray_is_regular(rg.n, rg.entry)) {
+        // state carried from phase to phase in the (not yet written) output buffer: alpha so far, samples so far
+        float4 *park = reinterpret_cast<float4 *>(P.out) + p;
+        float A = 0.f;
+        int sacc = 0;
+        if (!P.pp_first) { const float4 st = *park; A = st.x; sacc = __float_as_int(st.y); }
+        const size_t seg0 = (size_t)view * P.g.NL * NP + pl;
+        const f3 cam = make_f3(P.cam[3 * view], P.cam[3 * view + 1], P.cam[3 * view + 2]);
+        const int l_lo = max(max(sample_layer(P, rg, cam, 0), 0), P.pp_l0);
+        const int l_hi = min(min(sample_layer(P, rg, cam, nmarch - 1), P.g.NL - 1), P.pp_l1 - 1);
+        for (int l = l_lo; l <= l_hi; ++l) {
+            const size_t si = seg0 + (size_t)l * NP;
+            const int cnt = P.seg_cnt[si];
+            if (cnt == 0) continue;
+            const float A_after = fmaf(1.0f - A, P.seg_rgba[si].w, A);
+            if (!(A_after < 0.99f - 1e-5f)) {  // the crossing segment (with a margin for the re-associated partials)
+                                              // starts at sample sacc: resolved by ray_cross_kernel
+                *park = make_float4(A, __int_as_float(sacc), 0.f, 0.f);
+                P.ws_steps[p] = -1;
+                return;
+            }
+            A = A_after;
+            sacc += cnt;
+        }
+        *park = make_float4(A, __int_as_float(sacc), 0.f, 0.f);
+    }
+    if (P.pp_first) P.ws_steps[p] = nmarch;  // alive (so far): every planned sample is live
+}
+
+// P2b: the rays whose accumulated alpha crosses 0.99 (ws_steps == -1, crossing segment and alpha before it parked in
+// the not-yet-written output buffer). One WAVE per ray: 64 consecutive samples per pass -- positions, centre taps (the
+// lanes read neighbouring voxels) and TF lookups in parallel, then the exact sequential recurrence
+// A <- fma(1 - A, op_s, A) of VR.py:318-349 over the 64 opacities (a one-thread-per-ray loop spent ~370 dependent
+// global gathers per ray at sampling rate 8). Passes whose total transmittance keeps alpha clear of the threshold are
+// skipped with the (re-associated) wave product; the pass that can cross is evaluated in F2's sequential arithmetic.
+template <typename VT, int MODE>
+__global__ __launch_bounds__(256) void ray_cross_kernel(BrickParams<VT> P) {
+    const int view = blockIdx.y;
+    if (P.stats[2 + view] == 0u) return;  // uniform
+    const int NP = P.W * P.H;
+    const int lane = threadIdx.x & 63;
+    // waves walk over the rays (a bounded grid: gated off, the launch costs a few thousand workgroup exits)
+    for (int pl = blockIdx.x * 4 + (threadIdx.x >> 6); pl < NP; pl += 4 * (int)gridDim.x) {  // wave-uniform
+    const size_t p = (size_t)view * NP + pl;
+    if (P.ws_steps[p] != -1) continue;  // wave-uniform: no crossing to resolve
+    const float4 parked = reinterpret_cast<const float4 *>(P.out)[p];
+    RayGeom rg;
+    load_ray(P.entry, P.exit_, P.rays, P.nsamp, p, rg);
+    const int nmarch = (MODE == DR_MODE_DIFF && rg.n > P.S) ? P.S : rg.n;
+    VolView<VT> vol = P.vol;
+    vol.p += view * P.vol_vs;
+    const float4 *tfg = P.tf + view * P.tf_vs;
+    const f3 cam = make_f3(P.cam[3 * view], P.cam[3 * view + 1], P.cam[3 * view + 2]);
+    // Round 1 starts at the crossing segment with the alpha the (re-associated) partial composites give, ~1e-7 off
+    // the sequential value. If the decision it reaches is closer to the threshold than that error could matter
+    // (2e-6), round 2 repeats the recurrence from the first sample in exact sequential arithmetic -- the decision
+    // is then the oracle's, bit for bit (deviation D3 of DESIGN.md does not arise on this path).
+    float A = parked.x;
+    int s = __float_as_int(parked.y);
+    for (int round = 0; round < 2; ++round) {
+        float A_prev = A;
+        bool done = false;
+        for (int base = s; base < nmarch && !done; base += 64) {
+            const int sl = base + lane;
+            float op = 0.0f;
+            if (sl < nmarch) {
+                Sample sm;
+                sample_pos(rg, cam.x, cam.y, cam.z, sl, sm.px, sm.py, sm.pz);
+                classify(vol, tfg, P.R, P.tf_len, P.inv_sr, sm);
+                op = (MODE == DR_MODE_NONDIFF && !(sm.a > 1e-3f)) ? 0.0f : sm.op;  // skipped sample: A unchanged (fma(T, 0, A) == A)
+            }
+            const int cnt = min(64, nmarch - base);
+            if (round == 0) {
+                // Transmittance of the whole pass (wave product): if even its end stays clear of the threshold (by far
+                // more than re-association can move it) no sample of the pass terminates the ray: skip the sequential part.
+                float Tw = 1.0f - op;  // inactive lanes: op = 0
+                for (int o = 32; o > 0; o >>= 1) Tw *= __shfl_xor(Tw, o);
+                const float A_end = fmaf(1.0f - A, 1.0f - Tw, A);
+                if (A < 0.99f && A_end < 0.99f - 1e-4f) { A_prev = A = A_end; s += cnt; continue; }  // uniform
+            }
+            for (int i = 0; i < cnt; ++i) {  // uniform
+                if (!(A < 0.99f)) { done = true; break; }
+                const float opi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(op), i));
+                A_prev = A;
+                A = fmaf(1.0f - A, opi, A);
+                ++s;
+            }
+        }
+        // decided at A (>= 0.99, or the ray ran out of samples) with A_prev (< 0.99) before it
+        const bool ambiguous = fabsf(A - 0.99f) < 2e-6f || fabsf(A_prev - 0.99f) < 2e-6f;
+        if (round == 1 || !ambiguous) break;  // uniform
+        A = 0.0f; s = 0;
+    }
+    if (lane == 0) P.ws_steps[p] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host
+size_t brick_workspace_bytes(int n_views, int W, int H, int VX, int VY, int VZ) {
+    const BrickGrid g = make_brick_grid(VX, VY, VZ);
+    return ws_layout(nullptr, n_views, W * H, g, nullptr);
+}
+
+// F2: the workspace must hold the F1 output of the same call.
+template <typename VT>
+static int ray_compose_dispatch(const MarchArgs &a, hipStream_t stream) {
+    const BrickGrid g = make_brick_grid(a.VX, a.VY, a.VZ);
+    const int NP = a.W * a.H;
+    Workspace w;
+    ws_layout(a.workspace, a.n_views, NP, g, &w);
+    BrickParams<VT> P = make_brick_params<VT>(a, w);
+    const dim3 grid2((NP + 255) / 256, a.n_views);
+    const size_t lds2 = (size_t)a.R * 16;
+    if (a.mode == DR_MODE_DIFF)
+        hipLaunchKernelGGL((ray_compose_kernel<VT, DR_MODE_DIFF>), grid2, dim3(256), lds2, stream, P);
+    else
+        hipLaunchKernelGGL((ray_compose_kernel<VT, DR_MODE_NONDIFF>), grid2, dim3(256), lds2, stream, P);
+    return (int)hipGetLastError();
+}
+
+int launch_ray_compose(const MarchArgs &a, hipStream_t stream) {
+    return a.vol_dtype == DR_F16 ? ray_compose_dispatch<__half>(a, stream) : ray_compose_dispatch<float>(a, stream);
+}
+
+template <typename VT>
+static int ray_alpha_dispatch(const MarchArgs &a, hipStream_t stream, bool cross) {
+    const BrickGrid g = make_brick_grid(a.VX, a.VY, a.VZ);
+    const int NP = a.W * a.H;
+    Workspace w;
+    ws_layout(a.workspace, a.n_views, NP, g, &w);
+    BrickParams<VT> P = make_brick_params<VT>(a, w);
+    const dim3 grid2((NP + 255) / 256, a.n_views), grid3((NP + 3) / 4 < 8192 ? (NP + 3) / 4 : 8192, a.n_views);
+    if (a.mode == DR_MODE_DIFF) {
+        if (!cross) hipLaunchKernelGGL((ray_alpha_kernel<VT, DR_MODE_DIFF>), grid2, dim3(256), 0, stream, P);
+        else hipLaunchKernelGGL((ray_cross_kernel<VT, DR_MODE_DIFF>), grid3, dim3(256), 0, stream, P);
+    } else {
+        if (!cross) hipLaunchKernelGGL((ray_alpha_kernel<VT, DR_MODE_NONDIFF>), grid2, dim3(256), 0, stream, P);
+        else hipLaunchKernelGGL((ray_cross_kernel<VT, DR_MODE_NONDIFF>), grid3, dim3(256), 0, stream, P);
+    }
+    return (int)hipGetLastError();
+}
+
+int launch_ray_alpha(const MarchArgs &a, hipStream_t stream) {
+    return a.vol_dtype == DR_F16 ? ray_alpha_dispatch<__half>(a, stream, false) : ray_alpha_dispatch<float>(a, stream, false);
+}
+int launch_ray_cross(const MarchArgs &a, hipStream_t stream) {
+    return a.vol_dtype == DR_F16 ? ray_alpha_dispatch<__half>(a, stream, true) : ray_alpha_dispatch<float>(a, stream, true);
+}
+
+}  // namespace dr

@@ -31,14 +31,14 @@
 extern "C" {
 #endif
 
-#define DR_ABI_VERSION 4
+#define DR_ABI_VERSION 5
 
 enum { DR_F32 = 0, DR_F16 = 1 };
 enum { DR_MODE_DIFF = 0, DR_MODE_NONDIFF = 1 };
-/* kernel variant selector: AUTO picks the fastest validated kernels for the problem (brick-centric, one
- * lane per sample); BASELINE forces the plain one-lane-per-ray kernels; BRICK_RAYSEG the brick-centric
- * kernels with one lane per ray segment. The last two are kept for differential testing. */
-enum { DR_VARIANT_AUTO = 0, DR_VARIANT_BASELINE = 1, DR_VARIANT_BRICK_RAYSEG = 2 };
+/* kernel variant selector: AUTO picks the fastest validated kernels for the problem (brick-centric, one lane
+ * per sample); BASELINE forces the plain one-lane-per-ray kernels (kept for differential testing and as the
+ * fallback for problems the fast kernels do not serve). */
+enum { DR_VARIANT_AUTO = 0, DR_VARIANT_BASELINE = 1 };
 
 enum {
     DR_EINVAL = -1,      /* bad argument (null pointer, non-positive extent, unknown enum) */

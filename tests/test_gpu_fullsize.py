@@ -42,9 +42,6 @@ def test_sample_conservation_and_variant_agreement(scene):
     assert int(F.workspace_stats(ws0)[0]) == 0, "rays fell back to individual marching"
     assert torch.equal(steps0, n)  # alpha this low never terminates a ray: every planned sample is marched
     assert int(steps0.sum()) > 2.0e8
-    out2, steps2, ws2 = _fwd(scene, 2)
-    assert torch.equal(steps2, n)
-    assert float((out0 - out2).abs().max()) <= 1e-5
     outb, stepsb, _ = _fwd(scene, 1)
     assert float((out0 - outb).abs().max()) <= 1e-5 and torch.equal(stepsb, n)
 
@@ -100,12 +97,6 @@ def test_backward_linearity_and_stability(scene):
     assert float((dv1b - dv1).abs().max()) <= 1e-6 * float(dv1.abs().max())
     assert float((dt1b - dt1).abs().max()) <= 1e-6 * float(dt1.abs().max())
     assert torch.isfinite(dv1).all() and torch.isfinite(dt1).all()
-    # a second variant of the backward (one lane per ray segment) agrees
-    out2, _, ws2 = _fwd(scene, 2)
-    dvr, dtr = F.march_bwd(scene["vol"], scene["tf"], scene["cam"], *scene["rays"], 1 << 20, 1.0, g1, out2, variant=2,
-                           workspace=ws2)
-    assert float((dvr - dv1).abs().max()) <= 1e-4 * float(dv1.abs().max())
-    assert float((dtr - dt1).abs().max()) <= 1e-4 * float(dt1.abs().max())
 
 
 def test_early_termination_at_full_size(scene):
@@ -143,7 +134,7 @@ def test_termination_decisions_match_sequential_kernels(scene, mode, sr):
 
 
 def test_config_c2_256_forward_only(hiplib, oracle):
-    """BASELINE config C2: 256^3 f32 volume, 256^2 image, 256-entry TF, forward only (all kernel variants, patches vs oracle)."""
+    """BASELINE config C2: 256^3 f32 volume, 256^2 image, 256-entry TF, forward only (both kernel variants, patches vs oracle)."""
     import bench
     from differender_amd import functional as F
     dev = torch.device("cuda:0")
@@ -153,11 +144,11 @@ def test_config_c2_256_forward_only(hiplib, oracle):
     cam = torch.tensor([bench.in_circles(0.1)], dtype=torch.float32, device=dev)
     e, x, r, ns = F.ray_setup(cam, (img, img), (n, n, n), 1.0)
     outs = {}
-    for variant in (0, 2, 1):
+    for variant in (0, 1):
         ws = F.alloc_workspace(1, (img, img), (n, n, n), 256, dev) if variant != 1 else None
         outs[variant], steps = F.march_fwd(vol, tf, cam, e, x, r, ns, 1 << 20, 1.0, variant=variant, workspace=ws)
         assert torch.equal(steps, ns)
-    assert float((outs[0] - outs[1]).abs().max()) <= 1e-5 and float((outs[2] - outs[1]).abs().max()) <= 1e-5
+    assert float((outs[0] - outs[1]).abs().max()) <= 1e-5
     vol_h = vol.cpu().numpy(); tf_h = tf.cpu().numpy(); cam_h = cam[0].cpu().numpy()
     eh, xh, rh, nh = (t[0].cpu().numpy() for t in (e, x, r, ns))
     for (i0, j0) in [(120, 120), (40, 200)]:

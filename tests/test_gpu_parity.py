@@ -59,7 +59,7 @@ class _Variant:
                                  workspace=self._ws)
 
 
-@pytest.fixture(scope="module", params=[0, 2, 1], ids=["flat", "brick", "baseline"])
+@pytest.fixture(scope="module", params=[0, 1], ids=["flat", "baseline"])
 def F(hiplib, request):
     assert torch.cuda.is_available(), "gpu tests need a ROCm device"
     from differender_amd import functional
@@ -463,10 +463,9 @@ def test_huge_strides_take_the_64bit_path(oracle, hiplib):
     assert ok, err
 
 
-@pytest.mark.parametrize("vf,vb", [(2, 0), (0, 2)], ids=["rayseg-fwd_flat-bwd", "flat-fwd_rayseg-bwd"])
-def test_mixed_variants_share_a_workspace(oracle, hiplib, vf, vb):
-    """The workspace is a contract between any forward and any backward of the brick pipelines: the flat backward
-    must not rely on records only the flat forward writes (brick contexts, live flags)."""
+def test_stale_workspace_and_mixed_variants(oracle, hiplib):
+    """The workspace is scratch: whatever bytes an earlier call left in it must not matter; and the baseline backward
+    (which needs no workspace) may follow a forward of the fast path."""
     from differender_amd import functional as Fn
     vol_h, tf_h, cam_h = scene(oracle, N=40, R=32, tf="peaks")
     WH = (48, 40)
@@ -474,15 +473,16 @@ def test_mixed_variants_share_a_workspace(oracle, hiplib, vf, vb):
     e, x, r, n = Fn.ray_setup(cam, WH, vol.shape, 1.0)
     ws = Fn.alloc_workspace(1, WH, vol.shape, tf.shape[0], dev())
     ws.fill_(0x5A)                                        # stale bytes from "another call"
-    out, _ = Fn.march_fwd(vol, tf, cam, e, x, r, n, 4096, 1.0, variant=vf, workspace=ws)
+    out, _ = Fn.march_fwd(vol, tf, cam, e, x, r, n, 4096, 1.0, workspace=ws)
     g = T(np.random.default_rng(3).standard_normal(out.shape).astype(np.float32))
-    dv, dt = Fn.march_bwd(vol, tf, cam, e, x, r, n, 4096, 1.0, g, out, variant=vb, workspace=ws)
     eh, xh, rh, nh = (t[0].cpu().numpy() for t in (e, x, r, n))
     dv_o, dt_o = oracle.march_bwd(vol_h, tf_h, cam_h, eh, xh, rh, nh, 4096, 1.0, g[0].cpu().numpy())
-    ok, err = grad_close(dv.cpu().numpy(), dv_o)
-    assert ok, err
-    ok, err = grad_close(dt.cpu().numpy(), dt_o)
-    assert ok, err
+    for vb in (0, 1):
+        dv, dt = Fn.march_bwd(vol, tf, cam, e, x, r, n, 4096, 1.0, g, out, variant=vb, workspace=ws)
+        ok, err = grad_close(dv.cpu().numpy(), dv_o)
+        assert ok, (vb, err)
+        ok, err = grad_close(dt.cpu().numpy(), dt_o)
+        assert ok, (vb, err)
 
 
 def test_many_views_without_prepass(oracle, hiplib):
