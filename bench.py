@@ -6,13 +6,25 @@ One "step" = one pass of the hot path over one view per rank: ray setup -> forwa
 A voxel-step = one marched sample (sum of the per-pixel executed-step counters, VR.py:303,381).
 Inputs are synthetic and resident in HBM before the timed region. Prints ONE JSON line on rank 0.
 
-  python bench.py [--gpus N --steps K --warmup W]            (N > 1: launched by torch.distributed.run)
+  python bench.py [--gpus N --steps K --warmup W]
+
+N > 1: either launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the environment, what the
+driver does), or started plainly -- then this process spawns the N ranks itself, before touching the GPU, and
+relays rank 0's line. On a box with fewer than N GPUs the spawned ranks share the card(s) and talk over gloo (a
+rehearsal of the control flow, said so in the line); on a real node they use RCCL ("nccl") over xGMI.
+
+  python bench.py --workload opt     the reference's demo loop (examples/test_opt_tf.py:33-88) through Raycaster
 """
 import argparse
+import csv
+import glob
 import json
 import math
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -58,53 +70,166 @@ def in_circles(i, y=0.7, dist=2.5):
     return [math.cos(i) * dist, y, math.sin(i) * dist]
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--vol", type=int, default=512)
-    ap.add_argument("--img", type=int, default=512)
-    ap.add_argument("--tf-res", type=int, default=256)
+    ap.add_argument("--workload", default="march", choices=["march", "opt"],
+                    help="march: the headline (C4 and its variants below); opt: the reference's demo loop "
+                         "(examples/test_opt_tf.py:33-88: 256^3, 256^2, 8 views, tf1, jittered fwd+bwd + sr-8 ground-truth "
+                         "render + AdamW step per iteration) through the drop-in Raycaster module")
+    ap.add_argument("--vol", type=int, default=None, help="volume edge (default 512; opt: 256)")
+    ap.add_argument("--img", type=int, default=None, help="image edge (default 512; opt: 256)")
+    ap.add_argument("--tf-res", type=int, default=None, help="TF entries (default 256; opt: 128)")
     ap.add_argument("--grads", default="vol+tf", choices=["vol+tf", "tf", "vol", "none"],
                     help="vol+tf = C4 (default); tf = C3; none = forward only (C2-style)")
     ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 baseline kernels")
     ap.add_argument("--tf", default="bench", choices=["bench", "tf1"],
                     help="bench: constant alpha (no early termination, the headline); tf1: the reference's preset "
                          "(UT.py:9-21) -- empty ranges and early termination, reported separately")
-    ap.add_argument("--views", type=int, default=1, help="views per rank per step (one native batched launch)")
+    ap.add_argument("--views", type=int, default=None, help="views per rank per step (one native batched launch; opt: 8)")
     ap.add_argument("--vol-dtype", default="f32", choices=["f32", "f16"], help="volume storage (arithmetic is f32 either way; C5 uses f16)")
     ap.add_argument("--jitter", action="store_true", help="jittered ray starts (C5)")
+    ap.add_argument("--cam", default="orbit", choices=["orbit", "inside"], help="inside: camera inside the volume (every ray starts behind the eye)")
     ap.add_argument("--split", default="views", choices=["views", "rows"],
                     help="N > 1: 'views' = one view per rank per step (weak scaling, the default); 'rows' = ONE view per "
                          "step split into N bands of image rows (strong scaling, SURVEY 8(e))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-img", type=int, default=224, help="image edge of the bounded CPU-baseline sample")
-    args = ap.parse_args()
+    ap.add_argument("--pmc", default="auto", choices=["auto", "live", "off"],
+                    help="roofline.traffic: 'live' collects FETCH_SIZE / WRITE_SIZE with rocprofv3 around short child runs of "
+                         "this very command; 'auto' = live for the default single-GPU headline, else off")
+    ap.add_argument("--pmc-json", default=None, help="use this per-launch counter file (tools/profile_round.sh) instead")
+    return ap.parse_args(argv)
 
+
+# ------------------------------------------------------------------------------------------------ N > 1 self-launch
+def self_launch(args):
+    """--gpus N without a launcher: start the N ranks as fresh child processes (this process has not touched the GPU;
+    torch.cuda.device_count() does not initialise it) and relay rank 0's JSON line."""
+    import socket
+    n = args.gpus
+    ndev = torch.cuda.device_count()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    if ndev < n and "DR_BENCH_BACKEND" not in env:
+        env["DR_BENCH_BACKEND"] = "gloo"  # rehearsal: ranks share the card(s)
+        print(f"[bench] {ndev} GPU(s) for {n} ranks: rehearsing over gloo on shared devices", file=sys.stderr)
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r), OMP_NUM_THREADS=env.get("OMP_NUM_THREADS", "4"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode]
+    for p in procs[1:]:
+        try:
+            rcs.append(p.wait(timeout=600))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rcs.append(-9)
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+# ------------------------------------------------------------------------------------------------ live HBM counters
+def measure_traffic_live(argv_workload):
+    """roofline.traffic, measured in THIS job: rocprofv3 --pmc around short child runs of the same command, FETCH_SIZE
+    and WRITE_SIZE in separate passes (the TCC block has 4 slots: 3 + 2 do not fit, MI355X guide "rocprofv3 PMC slots"),
+    --kernel-trace only. Returns ({kernel: {"FETCH_SIZE": KB, "WRITE_SIZE": KB, "launches": n}}, note)."""
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not found"
+    res = {}
+    work = tempfile.mkdtemp(prefix="dr_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(work, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--",
+                   sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                   "--pmc", "off"] + argv_workload
+            p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=420)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if p.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {p.returncode})"
+            agg, cnt = {}, {}
+            for row in csv.DictReader(open(files[0])):
+                if "dr::" not in row["Kernel_Name"] or row["Counter_Name"] != counter:
+                    continue
+                k = row["Kernel_Name"].split("(")[0].replace("void ", "")
+                agg[k] = agg.get(k, 0.0) + float(row["Counter_Value"])
+                cnt[k] = cnt.get(k, 0) + 1
+            for k in agg:
+                res.setdefault(k, {})[counter] = agg[k] / cnt[k]
+                res[k]["launches"] = cnt[k]
+    except (subprocess.TimeoutExpired, OSError) as ex:
+        return None, f"live PMC pass failed: {ex}"
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    return res, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) around child runs of this command, same job"
+
+
+def traffic_bytes(pm, want_bwd_kernel):
+    """HBM-side bytes per launch of the forward / backward brick kernel from a per-launch counter table.
+    FETCH_SIZE counts 128-B fabric requests at 64 B on gfx950: doubled, as the MI355X guide prescribes (calibrated on
+    this access pattern: tools/microbench/fetch_calib.hip, profiles/r01_fetch_calibration.txt). WRITE_SIZE is exact for
+    16-B stores and float atomics. Both are in KB. Memory-side requests include Infinity-Cache hits: an upper bound."""
+    for k, v in pm.items():
+        if "brick_flat_kernel" not in k or "FETCH_SIZE" not in v:
+            continue
+        targs = [t.strip(" >") for t in k.split("<")[1].split(",")]  # <VT, MODE, BWD, VOL, TF, ALPHA, K>
+        if len(targs) >= 6 and targs[5] == "true":
+            continue  # the (gated) alpha pre-pass
+        if (targs[2] == "true") == want_bwd_kernel:
+            return int((2.0 * v["FETCH_SIZE"] + v.get("WRITE_SIZE", 0.0)) * 1024)
+    return None
+
+
+# ------------------------------------------------------------------------------------------------ main
+def init_dist(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     ndev = max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local_rank % ndev)  # (% ndev only matters for the 1-GPU rehearsal below)
+    torch.cuda.set_device(local_rank % ndev)  # (% ndev only matters for the shared-card rehearsal)
     dev = torch.device("cuda", local_rank % ndev)
-    dist = None
+    dist, backend = None, None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        # DR_BENCH_BACKEND=gloo rehearses the N > 1 control flow on a 1-GPU box (ranks share the card);
-        # the real run uses RCCL ("nccl" on ROCm) over xGMI.
-        backend = os.environ.get("DR_BENCH_BACKEND", "nccl")
+        backend = os.environ.get("DR_BENCH_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    return world, rank, dev, dist, backend
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+    if args.workload == "opt":
+        return main_opt(args)
+    args.vol = args.vol or 512
+    args.img = args.img or 512
+    args.tf_res = args.tf_res or 256
+    args.views = args.views or 1
+    world, rank, dev, dist, backend = init_dist(args)
 
     from differender_amd import functional as F
-    from differender_amd.distributed import all_reduce_gradients
+    from differender_amd.distributed import GradientReducer, all_reduce_gradients, shard_rows
 
     N, IMG, R = args.vol, args.img, args.tf_res
     want_vol = args.grads in ("vol+tf", "vol")
@@ -122,7 +247,6 @@ def main():
         tf = get_tf("tf1", R).t().contiguous().to(dev)
     gen = torch.Generator(device="cpu").manual_seed(4321)
     V = args.views
-    from differender_amd.distributed import shard_rows
     bands = args.split == "rows" and world > 1
     row0, ROWS = shard_rows(IMG, rank, world) if bands else (0, IMG)
     rows_arg = (row0, IMG) if bands else None
@@ -139,8 +263,15 @@ def main():
     # all camera positions are uploaded before the timed region (a host->device copy inside the loop would
     # synchronise the stream every step)
     nstep_total = args.warmup + args.steps
-    cams_all = torch.tensor([[in_circles(0.1 * ((k if bands else k * world + rank) * V + i)) for i in range(V)]
+
+    def cam_of(v):
+        if args.cam == "inside":  # a slow orbit INSIDE the box, looking at the origin
+            return [0.45 * math.cos(0.1 * v), 0.2, 0.45 * math.sin(0.1 * v)]
+        return in_circles(0.1 * v)
+
+    cams_all = torch.tensor([[cam_of((k if bands else k * world + rank) * V + i) for i in range(V)]
                              for k in range(nstep_total)], dtype=torch.float32, device=dev)
+    reducer = GradientReducer()
 
     def step(k, timed):
         cam = cams_all[k]
@@ -153,6 +284,7 @@ def main():
         a1.record()
         if timed:
             ev["fwd"].append((a0, a1))
+        dv = dt = None
         if want_bwd:
             _, grad_out = F.mse_loss_grad(out, target, loss=loss_acc)  # loss + d(loss)/d(out) in one pass
             b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -165,21 +297,15 @@ def main():
             if world > 1:
                 # RCCL sum of the shared gradients on its own stream: it overlaps the next step's forward; the
                 # previous step's reduction is awaited first so at most one is in flight (and all before timing ends)
-                for h in pending:
-                    h.wait()
-                pending[:] = all_reduce_gradients([g for g in (dv, dt) if g is not None], async_op=True)
-                keep_alive[:] = [dv, dt]
+                reducer.submit([dv, dt])
         if timed:
             total_steps.add_(steps.sum()); planned_steps.add_(n.sum())
         else:
             steps.sum(); n.sum()  # same launches as a timed step
-
-    pending, keep_alive = [], []
+        return dv, dt
 
     def barrier():
-        for h in pending:
-            h.wait()
-        pending[:] = []
+        reducer.wait()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -189,12 +315,29 @@ def main():
         step(k, False)
     barrier()
     t0 = time.perf_counter()
+    last = (None, None)
     for k in range(args.steps):
-        step(args.warmup + k, True)
+        last = step(args.warmup + k, True)
     barrier()
-    elapsed = time.perf_counter() - t0
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    elapsed_local = time.perf_counter() - t0
+
+    # the exchange step on its own (not overlapped): K synchronous all-reduces of the gradient buffers
+    allreduce_ms = None
+    if dist is not None and want_bwd:
+        grads = [g for g in last if g is not None]
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(max(args.steps, 1)):
+            all_reduce_gradients(grads)
+        barrier()
+        allreduce_ms = (time.perf_counter() - t1) / max(args.steps, 1) * 1e3
+
+    el = torch.tensor([elapsed_local], dtype=torch.float64, device=dev)
+    rank_ms = [elapsed_local / max(args.steps, 1) * 1e3]
     if dist is not None:
+        gathered = [torch.zeros_like(el) for _ in range(world)]
+        dist.all_gather(gathered, el)
+        rank_ms = [float(g.item()) / max(args.steps, 1) * 1e3 for g in gathered]
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(total_steps, op=dist.ReduceOp.SUM)
         dist.all_reduce(planned_steps, op=dist.ReduceOp.SUM)
@@ -205,68 +348,190 @@ def main():
     fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in ev["fwd"]]))
     bwd_ms = float(np.mean([a.elapsed_time(b) for a, b in ev["bwd"]])) if ev["bwd"] else 0.0
     steps_per_launch = vsteps / world / max(args.steps, 1)
+    stats = F.workspace_stats(ws) if ws is not None else None
+
+    if dist is not None:
+        dist.destroy_process_group()
+    if rank != 0:
+        return
 
     def roof(name, ms, bytes_per_step):
         ach = steps_per_launch * bytes_per_step / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         return {"kernel": name, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "avg_launch_ms": round(ms, 4),
-                "bytes_per_voxel_step": bytes_per_step, "voxel_steps_per_launch": int(steps_per_launch)}
+                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "hbm_gbs_measured": None, "hbm_frac_measured": None,
+                "avg_launch_ms": round(ms, 4), "bytes_per_voxel_step": bytes_per_step,
+                "voxel_steps_per_launch": int(steps_per_launch),
+                "note": "achieved/frac price the ALGORITHMIC bytes (model); hbm_gbs_measured = traffic / avg_launch is what "
+                        "the memory-side counters saw"}
 
-    # HBM bytes per launch from the latest committed PMC profile (collected with tools/profile_round.sh in
-    # separate --pmc passes: FETCH_SIZE, WRITE_SIZE). FETCH_SIZE counts 128-B fabric requests at 64 B on gfx950: it is
-    # doubled, as the MI355X guide prescribes. Calibrated on this access pattern (tools/microbench/fetch_calib.hip,
-    # profiles/r01_fetch_calibration.txt): a 512 MiB stream of 16-B loads reads exactly 1/2, and the brick staging
-    # pattern (15-float rows, 4 B per lane) tallies its 128-B line requests the same way. Memory-side requests
-    # include infinity-cache hits, so this is an upper bound on HBM bytes.
-    traffic = {}
-    try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_per_launch.json")))
-        for k, v in pm.items():
-            if "brick_flat_kernel" in k and "FETCH_SIZE" in v:
-                targs = [t.strip(" >") for t in k.split("<")[1].split(",")]  # <VT, MODE, BWD, VOL, TF, ALPHA>
-                if len(targs) >= 6 and targs[5] == "true":
-                    continue  # the (gated) alpha pre-pass
-                traffic["bwd" if targs[2] == "true" else "fwd"] = int((2.0 * v["FETCH_SIZE"] + v.get("WRITE_SIZE", 0)) * 1024)
-    except Exception:
-        pass
     roof_fwd = roof("march_fwd", fwd_ms, B_FWD)
     roof_bwd = roof("march_bwd", bwd_ms, B_BWD_VOL if want_vol else B_BWD_TF) if want_bwd else None
-    if N == 512 and IMG == 512 and args.variant == 0:
-        roof_fwd["traffic"] = traffic.get("fwd")
-        if roof_bwd and want_vol and want_tf:
-            roof_bwd["traffic"] = traffic.get("bwd")
+
+    # roofline.traffic: HBM-side bytes per launch of the dominant kernels
+    pm, traffic_source = None, None
+    default_cmd = world == 1 and args.variant == 0
+    if args.pmc_json:
+        pm = json.load(open(args.pmc_json)); traffic_source = f"counter file {args.pmc_json}"
+    elif args.pmc == "live" or (args.pmc == "auto" and default_cmd and N == 512 and IMG == 512 and args.tf == "bench"
+                                and args.grads == "vol+tf" and V == 1):
+        wl = ["--vol", str(N), "--img", str(IMG), "--tf-res", str(R), "--grads", args.grads, "--tf", args.tf,
+              "--views", str(V), "--vol-dtype", args.vol_dtype, "--cam", args.cam] + (["--jitter"] if args.jitter else [])
+        pm, traffic_source = measure_traffic_live(wl)
+    if pm:
+        for rf, is_bwd in ((roof_fwd, False), (roof_bwd, True)):
+            if rf is None:
+                continue
+            tb = traffic_bytes(pm, is_bwd)
+            if tb:
+                rf["traffic"] = tb
+                rf["hbm_gbs_measured"] = round(tb / (rf["avg_launch_ms"] * 1e-3) / 1e9, 1)
+                rf["hbm_frac_measured"] = round(rf["hbm_gbs_measured"] / HBM_PEAK_GBS, 4)
     dominant = roof_bwd if (roof_bwd and bwd_ms >= fwd_ms) else roof_fwd
 
     cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline:
         cpu_baseline = run_cpu_baseline(vol, tf, args, sr, want_vol, want_tf)
 
+    workload = {"vol+tf": "C4: fwd+bwd w.r.t. volume and TF", "tf": "C3: fwd+bwd w.r.t. TF",
+                "vol": "fwd+bwd w.r.t. volume", "none": "forward only"}[args.grads]
+    cams = "orbit cameras in_circles(0.1*v)" if args.cam == "orbit" else "cameras INSIDE the volume (radius 0.45)"
+    line = {
+        "metric": "Mvoxel-steps/s fwd+bwd, 512^3 vol @ 512^2 img",
+        "value": round(vsteps / elapsed / 1e6, 3),
+        "unit": "Mvoxel-steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4),
+        "higher_is_better": True, "scaling": "strong" if bands else "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{workload}; {N}^3 {args.vol_dtype} volume, {IMG}^2 image, {R}-entry TF, sr=1.0, "
+                               f"{V} view(s) per rank per step, {cams}, jitter {'on' if args.jitter else 'off'}",
+                   "volume": N, "image": IMG, "tf_res": R, "views_per_rank_per_step": V,
+                   "parallelism": (f"one view in {world} row bands" if bands else f"view-sharded x{world}") +
+                                  (" + all-reduce(d_vol,d_tf)" if world > 1 else ""),
+                   "backend": ({"nccl": "RCCL (nccl) over xGMI", "gloo": "gloo REHEARSAL: ranks share the card(s)"}.get(backend, backend)
+                               if world > 1 else None),
+                   "passes_per_voxel_step": passes, "kernel_variant": args.variant, "tf": args.tf},
+        "voxel_steps_per_step": int(vsteps / max(args.steps, 1)),
+        "planned_steps_per_step": int(int(planned_steps.item()) / max(args.steps, 1)),  # executed/planned < 1 = early termination
+        "ms_per_step_ranks": [round(v, 4) for v in rank_ms],
+        "allreduce_ms": None if allreduce_ms is None else round(allreduce_ms, 4),
+        "roofline": dominant, "roofline_fwd": roof_fwd, "roofline_bwd": roof_bwd,
+        "traffic_source": traffic_source,
+        "rays_marched_individually": (int(stats[2]) if stats is not None else None),
+        "rays_repaired": (int(stats[0]) if stats is not None else None),
+        "cpu_baseline": cpu_baseline,
+    }
+    print(json.dumps(line))
+
+
+# ------------------------------------------------------------------------------------------------ the demo loop
+def main_opt(args):
+    """examples/test_opt_tf.py:33-88 on synthetic data, through the drop-in module: per iteration 8 camera positions, a
+    non-differentiable ground-truth render at sampling rate 8, the jittered differentiable render, MSE loss (the
+    reference adds DSSIM from pytorch_msssim, not installed here), backward to volume and TF, AdamW + OneCycle step,
+    clamp. This is what dropping the library into the reference's script costs end to end, host glue included."""
+    N = args.vol or 256
+    IMG = args.img or 256
+    R = args.tf_res or 128
+    BS = args.views or 8
+    world, rank, dev, dist, backend = init_dist(args)
+    from differender.utils import get_tf, in_circles as ic, get_rand_pos
+    from differender.volume_raycaster import Raycaster
+
+    torch.manual_seed(1234 + rank)
+    vol_gt = synth_volume_torch(N, dev).permute(1, 2, 0).contiguous()[None]   # (1, D, H, W)
+    vol = vol_gt.clone()
+    mask = torch.rand_like(vol) < 0.05                                         # OPT.py:44-45
+    vol[mask] = torch.rand_like(vol[mask])
+    tf = get_tf("tf1", R)
+    tf_gt = get_tf("tf1", R).to(dev).expand(BS, -1, -1).float()
+    raycast = Raycaster(vol.shape[-3:], (IMG, IMG), R, jitter=True, max_samples=1024)   # OPT.py:49
+    vol = vol.float().requires_grad_(True)
+    tf = tf.to(dev).float().requires_grad_(True)
+    total = args.warmup + args.steps
+    opt = torch.optim.AdamW([vol], weight_decay=0)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-3, total_steps=max(total, 2))
+    nsteps = torch.zeros((), dtype=torch.int64, device=dev)
+    ev = {k: [] for k in ("gt", "fwd", "bwd", "opt")}
+    losses = []
+
+    def mark():
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def iteration(i, timed):
+        lf = torch.cat([ic(0.1 * (i * world + rank))[None], get_rand_pos(BS - 1)], dim=0).float().to(dev)  # OPT.py:65
+        t0 = mark()
+        with torch.no_grad():
+            gt = raycast.raycast_nondiff(vol_gt.detach(), tf_gt.detach(), lf.detach(), sampling_rate=8.0)
+        gt_steps = raycast.vr._steps.sum()
+        t1 = mark()
+        opt.zero_grad()
+        res = raycast(vol, tf, lf)
+        fw_steps = raycast.vr._steps.sum()
+        t2 = mark()
+        loss = torch.nn.functional.mse_loss(res, gt)
+        loss.backward()
+        if dist is not None:
+            from differender_amd.distributed import all_reduce_gradients
+            all_reduce_gradients([vol.grad, tf.grad])
+        t3 = mark()
+        opt.step()
+        sched.step()
+        with torch.no_grad():
+            tf.clamp_(0.0, 1.0)
+            vol.clamp_(0.0, 1.0)
+        t4 = mark()
+        if timed:
+            nsteps.add_(gt_steps + 2 * fw_steps)
+            for k, a, b in (("gt", t0, t1), ("fwd", t1, t2), ("bwd", t2, t3), ("opt", t3, t4)):
+                ev[k].append((a, b))
+            losses.append(loss.detach())
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        iteration(i, False)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        iteration(args.warmup + i, True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if dist is not None:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(nsteps, op=dist.ReduceOp.SUM)
         dist.destroy_process_group()
-    if rank == 0:
-        workload = {"vol+tf": "C4: fwd+bwd w.r.t. volume and TF", "tf": "C3: fwd+bwd w.r.t. TF",
-                    "vol": "fwd+bwd w.r.t. volume", "none": "forward only"}[args.grads]
-        line = {
-            "metric": "Mvoxel-steps/s fwd+bwd, 512^3 vol @ 512^2 img",
-            "value": round(vsteps / elapsed / 1e6, 3),
-            "unit": "Mvoxel-steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4),
-            "higher_is_better": True, "scaling": "strong" if bands else "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{workload}; {N}^3 {args.vol_dtype} volume, {IMG}^2 image, {R}-entry TF, sr=1.0, "
-                                   f"{V} view(s) per rank per step, orbit cameras in_circles(0.1*v), jitter {'on' if args.jitter else 'off'}",
-                       "volume": N, "image": IMG, "tf_res": R, "views_per_rank_per_step": V,
-                       "parallelism": (f"one view in {world} row bands" if bands else f"view-sharded x{world}") +
-                                      (" + RCCL all-reduce(d_vol,d_tf)" if world > 1 else ""),
-                       "passes_per_voxel_step": passes, "kernel_variant": args.variant, "tf": args.tf},
-            "voxel_steps_per_step": int(vsteps / max(args.steps, 1)),
-            "planned_steps_per_step": int(int(planned_steps.item()) / max(args.steps, 1)),  # executed/planned < 1 = early termination
-            "roofline": dominant, "roofline_fwd": roof_fwd, "roofline_bwd": roof_bwd,
-            "rays_marched_individually": (int(F.workspace_stats(ws)[0]) if ws is not None else None),
-            "cpu_baseline": cpu_baseline,
-        }
-        print(json.dumps(line))
+    if rank != 0:
+        return
+    elapsed = float(el.item())
+    ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items()}
+    gpu_ms = sum(ms.values())
+    it_ms = elapsed / max(args.steps, 1) * 1e3
+    line = {
+        "metric": "iterations/s of the reference's optimisation demo (examples/test_opt_tf.py:63-88) through Raycaster",
+        "value": round(args.steps * world / elapsed, 4), "unit": "iterations/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(it_ms, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"OPT demo: {N}^3 f32 volume (5 % voxels randomised), {IMG}^2 image, {BS} views per iteration "
+                               f"(1 orbit + {BS - 1} random, r=2.7), tf1 with {R} entries, max_samples=1024, jitter on; per "
+                               "iteration: nondiff GT render at sr 8, differentiable render at sr 1, MSE, backward to volume "
+                               "and TF, AdamW + OneCycleLR step, clamp",
+                   "volume": N, "image": IMG, "tf_res": R, "views": BS},
+        "mvoxel_steps_per_s": round(int(nsteps.item()) / elapsed / 1e6, 1),
+        "voxel_steps_per_iteration": int(int(nsteps.item()) / max(args.steps, 1) / world),
+        "ms_gt_render": round(ms["gt"], 4), "ms_forward": round(ms["fwd"], 4), "ms_loss_backward": round(ms["bwd"], 4),
+        "ms_optimiser": round(ms["opt"], 4),
+        "ms_host_overhead": round(it_ms - gpu_ms, 4),   # wall time per iteration not covered by the GPU phases above
+        "loss_first_last": [round(float(losses[0]), 6), round(float(losses[-1]), 6)] if losses else None,
+    }
+    print(json.dumps(line))
 
 
 def run_cpu_baseline(vol, tf, args, sr, want_vol, want_tf):
@@ -281,7 +546,7 @@ def run_cpu_baseline(vol, tf, args, sr, want_vol, want_tf):
         pass
     cores = min(cores, 16)  # a 1-GPU box's CPU share (the host exposes all its cores to every box)
     os.environ["OMP_NUM_THREADS"] = str(cores)
-    vol_h = vol.cpu().numpy()
+    vol_h = vol.float().cpu().numpy()
     tf_h = tf.cpu().numpy()
     cam = np.array(in_circles(0.0), np.float32)
     W = args.cpu_img

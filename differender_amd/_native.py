@@ -31,6 +31,7 @@ SIGNATURES = {
                                _I, _I, _I, _I, _F, _D, _D, _I, _I, _P, _P, _P, _Z, _I, _I, _P]),
     "dr_march_bwd_rows": (_I, [_P, _I, _I, _I, _I, _L, _L, _L, _L, _P, _I, _L, _P, _P, _P, _P, _P,
                                _I, _I, _I, _I, _F, _D, _D, _I, _P, _P, _P, _L, _L, _L, _L, _P, _L, _P, _Z, _I, _I, _P]),
+    "dr_march_bwd_variant": (_I, [_I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _I, _I, _I]),
     "dr_mse_loss_grad": (_I, [_P, _P, _L, _F, _P, _P, _P]),
     "dr_tf_momentum_step": (_I, [_P, _P, _P, _I, _F, _F, _F, _P]),
 }

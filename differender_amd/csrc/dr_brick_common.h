@@ -23,8 +23,8 @@ struct BrickParams {
                          // ray is marched whole)
     uint8_t *rayflag;    // [view][NP]: 1 = irregular ray (marched whole by F2 / B2)
     int32_t *ws_steps;   // [view][NP]: live samples per ray (F2 -> B1)
-    unsigned int *stats; // [0] rays repaired by the count check, [1] bits of max|grad_out| (backward),
-                         // [2 + view] 1 if some ray of the view may reach alpha >= 0.99 (alpha pre-pass ran)
+    unsigned int *stats; // workspace header, words ST_* below
+    unsigned int *vflags; // [view] 1 if some ray of the view may reach alpha >= 0.99 (the alpha pre-pass runs for it)
     int use_live;        // forward: ws_steps holds each ray's exact live sample count (from the alpha pre-pass)
     int pp_l0, pp_l1, pp_first;  // alpha pre-pass phase: brick layers [pp_l0, pp_l1); later phases skip terminated rays
     const struct BrickCtxRec *ctx;  // [view][brick]: brick geometry + pixel rectangle, filled once per forward call
@@ -32,6 +32,17 @@ struct BrickParams {
     const float *grad_out, *out_fwd;
     GradView dvol; int64_t dvol_vs;
     float *d_tf; int64_t dtf_vs;
+};
+
+// Workspace header (32-bit words). Written by the device only; read back by functional.workspace_stats().
+enum {
+    ST_REPAIR = 0,         // rays whose segments failed the sample-count check and were marched whole (expected 0)
+    ST_GCAP = 1,           // backward: bits of the robust cap on |grad_out| (gradstat_kernel + brick_ctx_kernel)
+    ST_BASELINE_RAYS = 2,  // rays the per-ray fallback marched in the last forward (irregular rays + repaired ones)
+    ST_MARK = 3,           // DR_CTX_MARK once the flat forward has written brick records and live flags
+    ST_TIMING = 16,        // DR_PHASE_TIMING: u64 x3 forward phases, u64 x3 backward phases, u64 backward lifetime
+    ST_HIST = 64,          // backward: 256-bin histogram of the exponents of grad_out's finite non-zero components
+    ST_WORDS = 512         // header size in words (2 KiB)
 };
 
 struct BrickCtx {
@@ -114,7 +125,7 @@ __device__ __forceinline__ void brick_setup(const BrickParams<VT> &P, int b, f3 
 }
 
 // One thread per (brick, view): brick_setup once, for all passes of a forward/backward pair. The forward launches it
-// with forward = 1 (live flags cleared, DR_CTX_MARK left in stats[51]: "records and live flags are the flat
+// with forward = 1 (live flags cleared, DR_CTX_MARK left in stats[ST_MARK]: "records and live flags are the flat
 // forward's"); the backward recomputes the geometry (it may follow a forward of another kernel variant) and keeps
 // the live flags, which its kernels only trust when the mark is there.
 constexpr unsigned int DR_CTX_MARK = 0x600DF1A7u;
@@ -132,17 +143,42 @@ __device__ __forceinline__ unsigned int may_terminate(const float4 *t, int R, fl
     const float remain = powf(1.0f - op, n_max);  // transmittance left after the longest possible ray
     return (remain <= 0.02f) ? 1u : 0u;           // 0.01 is the exact bound; keep a margin
 }
+// Robust cap on |grad_out| from the exponent histogram (one wave): 2^12 times the upper edge of the bin that holds the
+// 99th percentile of the finite non-zero components. Pixels above it (a stray 1e30, an overflowed loss) do not set
+// any brick's fixed-point scale; their own contributions take the exact clamped path.
+__device__ __forceinline__ unsigned int grad_cap_bits(const unsigned int *hist) {
+    const int lane = threadIdx.x & 63;
+    unsigned int h[4], tot = 0;
+    for (int k = 0; k < 4; ++k) { h[k] = hist[4 * lane + k]; tot += h[k]; }
+    unsigned int incl = tot;
+    for (int o = 1; o < 64; o <<= 1) { const unsigned int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    const unsigned int total = __shfl(incl, 63);
+    if (total == 0u) return __float_as_uint(1.0f);
+    const unsigned int want = total - total / 100u;   // first bin at which the cumulative count reaches 99 %
+    unsigned int cum = incl - tot;
+    int bin = 1000;
+    for (int k = 0; k < 4; ++k) { cum += h[k]; if (bin == 1000 && cum >= want) bin = 4 * lane + k; }
+    for (int o = 32; o > 0; o >>= 1) bin = min(bin, __shfl_xor(bin, o));
+    const int e = min(bin + 1 + 12, 254);             // upper edge of the bin (2^(bin-126)) times 2^12
+    return (unsigned int)e << 23;
+}
 // forward = 1 additionally initialises the workspace header for this call: repair counter, per-view "may terminate"
 // flags (n_max > 0: the alpha pre-pass is available) and the mark -- no separate memset / flag kernel.
+// forward = 0 (backward) turns the exponent histogram of grad_out into the cap (ST_GCAP).
 template <typename VT>
 static __global__ __launch_bounds__(256) void brick_ctx_kernel(BrickParams<VT> P, BrickCtxRec *out, int nbricks, int forward,
                                                               float n_max) {
     const int b = blockIdx.x * 256 + threadIdx.x, view = blockIdx.y;
-    if (forward && blockIdx.x == 0 && threadIdx.x < 64) {  // first wave of the view's first block
-        const unsigned int flag = n_max > 0.0f ? may_terminate(P.tf + view * P.tf_vs, P.R, P.inv_sr, n_max) : 0u;
-        if (threadIdx.x == 0) {
-            if (view < 48) P.stats[2 + view] = flag;  // (more views: no pre-pass, nobody reads the flags)
-            if (view == 0) { P.stats[0] = 0u; P.stats[51] = DR_CTX_MARK; }
+    if (blockIdx.x == 0 && threadIdx.x < 64) {  // first wave of the view's first block
+        if (forward) {
+            const unsigned int flag = n_max > 0.0f ? may_terminate(P.tf + view * P.tf_vs, P.R, P.inv_sr, n_max) : 0u;
+            if (threadIdx.x == 0) {
+                P.vflags[view] = flag;
+                if (view == 0) { P.stats[ST_REPAIR] = 0u; P.stats[ST_BASELINE_RAYS] = 0u; P.stats[ST_MARK] = DR_CTX_MARK; }
+            }
+        } else if (view == 0) {
+            const unsigned int cap = grad_cap_bits(P.stats + ST_HIST);
+            if (threadIdx.x == 0) P.stats[ST_GCAP] = cap;
         }
     }
     if (b >= nbricks) return;
@@ -240,12 +276,13 @@ __device__ __forceinline__ void load_ray(const float *entry, const float *exit_,
 struct FixScale {
     float hi;    // 2^(shift-32): x*hi has the high word in its integer part, the low word in its fraction
     float lo;    // 2^shift
-    float lim;   // adjoints are clamped to +-lim = 2^20 * max|grad_out| (keeps every sum inside 63 bits)
+    float lim;   // adjoints are clamped to +-lim = 2^20 * gmax (keeps every sum inside 63 bits)
     double inv;  // 2^-shift
 };
-__device__ __forceinline__ FixScale make_fix_scale(unsigned int gmax_bits) {
-    float gmax = __uint_as_float(gmax_bits);
-    if (!(gmax > 0.0f) || !(gmax < 3.0e38f)) gmax = 1.0f;  // all-zero or non-finite upstream gradient
+// gmax = the largest |grad_out| component among the brick's candidate pixels (outliers above the robust cap excluded):
+// every brick has its own scale, so the resolution follows the local magnitude of the upstream gradient.
+__device__ __forceinline__ FixScale make_fix_scale(float gmax) {
+    if (!(gmax > 0.0f) || !(gmax < 3.0e38f)) gmax = 1.0f;  // all-zero upstream gradient
     int e;
     frexpf(gmax, &e);            // gmax < 2^e
     const int shift = DR_FIX_BITS - e;    // gmax * 2^shift < 2^DR_FIX_BITS
@@ -256,8 +293,16 @@ __device__ __forceinline__ FixScale make_fix_scale(unsigned int gmax_bits) {
     f.inv = ldexp(1.0, -shift);
     return f;
 }
+// A NaN adjoint (NaN pixel in grad_out, NaN voxel) contributes nothing: the reference lets it poison every voxel and
+// texel the ray touches and then zeroes those with nan_to_num (VR.py:463-475); here only the bad ray is dropped.
 __device__ __forceinline__ float fix_clamp(float x, const FixScale &f) {
-    return fminf(fmaxf(x, -f.lim), f.lim);  // NaN -> -lim (finite), as nan_to_num would make it finite later
+    return (x == x) ? fminf(fmaxf(x, -f.lim), f.lim) : 0.0f;
+}
+// round to nearest (ties up): one instruction, like the truncating conversion, but without its bias toward zero
+__device__ __forceinline__ int cvt_rn_i32(float x) {
+    int q;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(q) : "v"(x));
+    return q;
 }
 // Exact conversion (any magnitude inside the clamp): split x*2^(shift-32) into integer and fraction.
 __device__ __forceinline__ void fix_add_wide(unsigned long long *p, float x, const FixScale &f) {
@@ -271,13 +316,13 @@ __device__ __forceinline__ void fix_add_wide(unsigned long long *p, float x, con
     atomicAdd(p, v);  // ds_add_u64
 #endif
 }
-// Common case: |x * 2^shift| < 2^31 -- one multiply, one float->int conversion (exact to 2^-shift), a sign
+// Common case: |x * 2^shift| < 2^31 -- one multiply, one float->int conversion (rounded to the nearest 2^-shift), a sign
 // extension. Callers test the magnitude once per sample (fix_fits) and pick WIDE under a wave-uniform branch.
 __device__ __forceinline__ bool fix_fits(float absmax, const FixScale &f) { return absmax * f.lo < 2147483520.0f; }
 template <bool WIDE, bool PRE = false>  // PRE: x already carries the factor 2^shift
 __device__ __forceinline__ void fix_add_t(unsigned long long *p, float x, const FixScale &f) {
     if (WIDE) { fix_add_wide(p, x, f); return; }
-    const int q = (int)(PRE ? x : x * f.lo);  // truncation: <= 1 unit of 2^-shift (~4e-9 max|grad_out|) per add
+    const int q = cvt_rn_i32(PRE ? x : x * f.lo);  // <= half a unit of 2^-shift (~2e-9 of the brick's max|grad_out|) per add, unbiased
 #ifdef DR_ABL_NOATOMIC
     asm volatile("" :: "v"(p), "v"((unsigned long long)(long long)q));
 #else
@@ -289,20 +334,23 @@ __device__ __forceinline__ float fix_to_float(unsigned long long v, const FixSca
     return (float)((double)(long long)v * f.inv);
 }
 
-// max |x| over a buffer -> bits of the (non-negative) float, combined with atomicMax on the integer view
-static __global__ __launch_bounds__(256) void absmax_kernel(const float *x, size_t n, unsigned int *out_bits) {
-    float m = 0.0f;
+// Exponent histogram of grad_out (finite, non-zero components): 256 bins in the workspace header, zeroed by the
+// caller. One pass over the upstream gradient; brick_ctx_kernel turns it into the robust cap.
+static __global__ __launch_bounds__(256) void gradstat_kernel(const float *x, size_t n, unsigned int *hist) {
+    __shared__ unsigned int lh[256];
+    lh[threadIdx.x] = 0u;
+    __syncthreads();
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const float v = fabsf(x[i]);
-        m = (v > m) ? v : m;  // NaN never wins
+        const unsigned int e = (__float_as_uint(x[i]) >> 23) & 0xffu;
+        if (e != 0u && e != 255u) atomicAdd(&lh[e], 1u);
     }
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(out_bits, __float_as_uint(fminf(m, 3.0e38f)));
+    __syncthreads();
+    if (lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------------ host
 struct Workspace {
-    float4 *seg_rgba; uint16_t *seg_cnt; int32_t *ws_steps; uint8_t *rayflag; unsigned int *stats;
+    float4 *seg_rgba; uint16_t *seg_cnt; int32_t *ws_steps; uint8_t *rayflag; unsigned int *stats, *vflags;
     BrickCtxRec *ctx;
     size_t cnt_bytes;
 };
@@ -312,7 +360,9 @@ static inline size_t ws_layout(void *base, int n_views, int NP, const BrickGrid 
     const size_t nseg = (size_t)n_views * NL * NP;
     unsigned char *b = static_cast<unsigned char *>(base);
     if (w) w->stats = reinterpret_cast<unsigned int *>(b + o);
-    o += 256;
+    o += ST_WORDS * 4;
+    if (w) w->vflags = reinterpret_cast<unsigned int *>(b + o);
+    o += align16((size_t)n_views * 4);
     if (w) w->seg_rgba = reinterpret_cast<float4 *>(b + o);
     o += nseg * 16;
     if (w) { w->seg_cnt = reinterpret_cast<uint16_t *>(b + o); w->cnt_bytes = nseg * 2; }
@@ -345,7 +395,7 @@ static inline BrickParams<VT> make_brick_params(const MarchArgs &a, const Worksp
     const double near_h = 2.0 * tan(a.fov_rad) * a.near_plane;
     P.near_ = (float)a.near_plane; P.near_h = (float)near_h; P.near_w = (float)(near_h * ((double)P.imgW / (double)a.H));
     P.g = make_brick_grid(a.VX, a.VY, a.VZ);
-    P.seg_rgba = w.seg_rgba; P.seg_cnt = w.seg_cnt; P.rayflag = w.rayflag; P.stats = w.stats; P.ws_steps = w.ws_steps;
+    P.seg_rgba = w.seg_rgba; P.seg_cnt = w.seg_cnt; P.rayflag = w.rayflag; P.stats = w.stats; P.vflags = w.vflags; P.ws_steps = w.ws_steps;
     P.use_live = a.use_live; P.ctx = w.ctx;
     P.pp_l0 = a.pp_l0; P.pp_l1 = a.pp_l1; P.pp_first = a.pp_first;
     P.out = a.out; P.steps = a.steps;

@@ -82,6 +82,8 @@ __global__ __launch_bounds__(256) void march_fwd_baseline_kernel(MarchParams<VT>
     if (P.steps) P.steps[p] = cnt;
 }
 
+__device__ __forceinline__ float finite_or_zero(float x) { return (x == x) ? fminf(fmaxf(x, -1.0e30f), 1.0e30f) : 0.0f; }
+
 template <typename VT>
 __global__ __launch_bounds__(256) void march_bwd_baseline_kernel(MarchParams<VT> P) {
     extern __shared__ __attribute__((aligned(16))) float4 lds_tf[];  // [R] TF, then [R] dTF accumulators
@@ -136,6 +138,15 @@ __global__ __launch_bounds__(256) void march_bwd_baseline_kernel(MarchParams<VT>
             const float suffix = (go.x * (of.x - C0) + go.y * (of.y - C1) + go.z * (of.z - C2)) + go.w * (of.w - A);
             SampleAdj ad;
             sample_adjoint(sm, vd, T, suffix, last, go, P.inv_sr, ad);
+            float I_bar = want_vol ? intensity_adjoint(sm, lds_tf[sm.lo], lds_tf[sm.hi], ad, P.tf_len) : 0.0f;
+            if (P.only_flagged) {
+                // second pass of the brick-centric backward (irregular rays): that path promises finite gradients, so a NaN
+                // adjoint is dropped and infinities are clamped here too (dr_march_bwd_variant). On its own, the baseline
+                // propagates NaN like the reference.
+                ad.r_bar = finite_or_zero(ad.r_bar); ad.g_bar = finite_or_zero(ad.g_bar); ad.b_bar = finite_or_zero(ad.b_bar);
+                ad.a_bar = finite_or_zero(ad.a_bar); ad.gx = finite_or_zero(ad.gx); ad.gy = finite_or_zero(ad.gy);
+                ad.gz = finite_or_zero(ad.gz); I_bar = finite_or_zero(I_bar);
+            }
 
             if (want_tf) {
                 const float w0 = 1.0f - sm.fr, w1 = sm.fr;
@@ -146,7 +157,6 @@ __global__ __launch_bounds__(256) void march_bwd_baseline_kernel(MarchParams<VT>
                 atomicAdd(d1 + 2, w1 * ad.b_bar); atomicAdd(d1 + 3, w1 * ad.a_bar);
             }
             if (want_vol) {
-                const float I_bar = intensity_adjoint(sm, lds_tf[sm.lo], lds_tf[sm.hi], ad, P.tf_len);
                 tri_scatter_global(vol, dv, sm.px, sm.py, sm.pz, I_bar);
                 if (!sm.flat) {
                     tri_scatter_global(vol, dv, sm.px + delta, sm.py, sm.pz, ad.gx);

@@ -72,6 +72,7 @@ struct FlatLds {
     int *valid;     // in-brick samples of each segment (forward)
     int *slen;      // forward: true length of the segment (its flat extent is padded to a multiple of FWD_K)
     int *live;      // backward: live sample count of the ray
+    float *gmax;    // backward: per wave, the largest |grad_out| among the brick's candidate pixels
 };
 // LDS layout: everything of compile-time size first (so every address below is an immediate), then the two
 // tables whose size depends on the run-time TF resolution R.
@@ -82,6 +83,7 @@ __host__ __device__ constexpr size_t flat_fixed_bytes(bool want_vol) {
     if (BWD && want_vol) s += ((size_t)BOX_LDS * 8 + 15) / 16 * 16;
     s += (size_t)EC * 32;
     s += (size_t)EC * 4 + (((size_t)EC + 8) * 4 + 15) / 16 * 16 + (size_t)EC * 4 + (size_t)EC * 4;  // (live | slen)
+    if (BWD) s += 64;  // gmax
     return s;
 }
 template <bool BWD>
@@ -102,7 +104,8 @@ __device__ __forceinline__ FlatLds flat_carve(unsigned char *smem, int R) {
     L.offs = reinterpret_cast<int *>(smem + o); o += align16((EC + 8) * 4);  // per wave: its entries' offsets + end marker
     L.valid = reinterpret_cast<int *>(smem + o); o += (size_t)EC * 4;
     L.slen = nullptr;
-    if (BWD) { L.live = reinterpret_cast<int *>(smem + o); o += (size_t)EC * 4; }
+    L.gmax = nullptr;
+    if (BWD) { L.live = reinterpret_cast<int *>(smem + o); o += (size_t)EC * 4; L.gmax = reinterpret_cast<float *>(smem + o); o += 64; }
     else { L.slen = reinterpret_cast<int *>(smem + o); o += (size_t)EC * 4; }
     L.tf = reinterpret_cast<float4 *>(smem + o); o += (size_t)R * 16;
     if (BWD && WANT_TF) L.dtf = reinterpret_cast<unsigned long long *>(smem + o);
@@ -265,7 +268,7 @@ __device__ __forceinline__ void flat_build_entries(const BrickParams<VT> &P, con
         const int n = d.n;
         bool ok = ray_is_regular(n, d.entry);
         int nmarch = (MODE == DR_MODE_DIFF && n > P.S) ? P.S : n;
-        if (!BWD && !ALPHA && ok && P.use_live && P.stats[2 + view] != 0u)
+        if (!BWD && !ALPHA && ok && P.use_live && P.vflags[view] != 0u)
             nmarch = min(nmarch, live);  // exact live count from the alpha pre-pass: dead samples are not marched
         if (ALPHA && !P.pp_first && live == -1) ok = false;  // terminated in an earlier phase of the pre-pass
         if (BWD && ok) {
@@ -494,11 +497,35 @@ __device__ __forceinline__ void scatter_sample(unsigned long long *dbox, const T
     if (valid) scatter8<WIDE, PRE>(dbox, cbase_i, acc, fs);
 }
 
+// Backward: the largest |grad_out| component over the brick's candidate pixels, per thread (the caller reduces it over
+// the workgroup). Pixels with a non-finite component or above the robust cap do not count (their contributions take the
+// exact clamped path). All loads of a thread are independent and issued together with the box staging.
+template <typename VT, int FNT>
+__device__ __forceinline__ float cand_grad_max(const BrickParams<VT> &P, const BrickCtx &c, int view, int ncand) {
+    const float cap = __uint_as_float(P.stats[ST_GCAP]);
+    const float4 *go4 = reinterpret_cast<const float4 *>(P.grad_out) + (size_t)view * P.W * P.H;
+    const int nj = c.j1 - c.j0 + 1;
+    const float rnj = __builtin_amdgcn_rcpf((float)nj);
+    float gm = 0.0f;
+    for (int cc = threadIdx.x; cc < ncand; cc += FNT) {
+        const int qi = (ncand < (1 << 21)) ? (int)(((float)cc + 0.5f) * rnj) : cc / nj;  // see cand_load
+        const float4 g = go4[(c.i0 + qi) * P.H + c.j0 + (cc - qi * nj)];
+        const float a = fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w)));
+        const bool bad = !(fabsf(g.x) <= cap) || !(fabsf(g.y) <= cap) || !(fabsf(g.z) <= cap) || !(fabsf(g.w) <= cap);
+        gm = fmaxf(gm, bad ? 0.0f : a);
+    }
+    return gm;
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
 // ALPHA (forward only): the alpha pre-pass -- centre tap + TF only, the partial of a segment is its accumulated alpha.
 template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, bool ALPHA = false, int KF = 1>
 __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FWD_WAVES) void brick_flat_kernel(BrickParams<VT> P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (ALPHA && P.stats[2 + blockIdx.y] == 0u) return;  // uniform: no ray of this view can terminate early
+    if (ALPHA && P.vflags[blockIdx.y] == 0u) return;  // uniform: no ray of this view can terminate early
     constexpr int EC = BWD ? FEC_BWD : FEC_FWD;
     constexpr int FNT = BWD ? FNT_BWD : FNT_FWD;
     constexpr int FNW = FNT / 64;
@@ -510,7 +537,7 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
     if (c.i0 > c.i1 || c.j0 > c.j1) return;  // uniform: the brick projects outside the image
     if (ALPHA && (c.layer < P.pp_l0 || c.layer >= P.pp_l1)) return;  // uniform: not in this phase of the pre-pass
     // backward after a flat forward: bricks in which the forward marched nothing (rays terminated before them) have no work
-    if (BWD && !DR_PHASE_TIMING && c.live == 0 && P.stats[51] == DR_CTX_MARK) return;  // uniform
+    if (BWD && !DR_PHASE_TIMING && c.live == 0 && P.stats[ST_MARK] == DR_CTX_MARK) return;  // uniform
 
 #if DR_SETPRIO
     __builtin_amdgcn_s_setprio(3);  // the staging / listing prologue is short and latency-bound: let it overtake sample loops
@@ -533,22 +560,32 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
     // Forward after an alpha pre-pass that found terminating rays: many bricks lie entirely behind the termination
     // points (likewise in the later groups of the pre-pass itself). List the segments first and leave without staging
     // anything when there are none.
-    const bool lazy = (!BWD && !ALPHA && P.use_live && P.stats[2 + view] != 0u) || (ALPHA && !P.pp_first);  // uniform
+    const bool lazy = (!BWD && !ALPHA && P.use_live && P.vflags[view] != 0u) || (ALPHA && !P.pp_first);  // uniform
     if (lazy) {
         flat_build_entries<VT, MODE, BWD, FNT, ALPHA, KS>(P, c, cam, view, cd, seg_base, L, nE0, M0);
         if (!__syncthreads_or(nE0 > 0) && ncand <= EC) return;  // uniform: no wave found a segment
         box_issue<VT, FNT>(P, vol, c, P.tf + view * P.tf_vs, stage);
     } else {
+        float gm = 0.0f;
+        if (BWD) gm = cand_grad_max<VT, FNT>(P, c, view, ncand);            // upstream gradients of the candidates,
         box_issue<VT, FNT>(P, vol, c, P.tf + view * P.tf_vs, stage);      // voxel box + TF: in flight ...
         if (BWD) {
             if (WANT_VOL) for (int k = threadIdx.x; k < BOX_LDS; k += FNT) L.dbox[k] = 0ull;
             if (WANT_TF) for (int k = threadIdx.x; k < 4 * P.R; k += FNT) L.dtf[k] = 0ull;
-            fs = make_fix_scale(P.stats[1]);
+            gm = wave_max_f(gm);
+            if ((threadIdx.x & 63) == 0) L.gmax[threadIdx.x >> 6] = gm;
         }
         flat_build_entries<VT, MODE, BWD, FNT, ALPHA, KS>(P, c, cam, view, cd, seg_base, L, nE0, M0);  // ... while the segments are listed
     }
     box_commit<VT, FNT>(P, vol, c, P.tf + view * P.tf_vs, stage, L);
     __syncthreads();
+    if (BWD) {  // this brick's fixed-point scale (every thread derives the same one)
+        float gm = 0.0f;
+#pragma unroll
+        for (int k = 0; k < FNW; ++k) gm = fmaxf(gm, L.gmax[k]);
+        if (!(gm > 0.0f)) gm = __uint_as_float(P.stats[ST_GCAP]);  // only outliers (or zeros) in this brick
+        fs = make_fix_scale(gm);
+    }
 #if DR_PHASE_TIMING
     const long long tk1 = clock64();
 #endif
@@ -840,7 +877,7 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
 #if DR_PHASE_TIMING
     if (!ALPHA && threadIdx.x == 0) {  // per-phase clocks of this workgroup, summed over the grid (tools/phase_times.py)
         const long long tk3 = clock64();
-        unsigned long long *tt = reinterpret_cast<unsigned long long *>(P.stats + (BWD ? 58 : 52));
+        unsigned long long *tt = reinterpret_cast<unsigned long long *>(P.stats + ST_TIMING) + (BWD ? 3 : 0);
         atomicAdd(tt + 0, (unsigned long long)(tk1 - tk0));   // staging: candidate + box loads, first segment listing
         atomicAdd(tt + 1, (unsigned long long)(tk2 - tk1));   // wave split
         atomicAdd(tt + 2, (unsigned long long)(tk3 - tk2));   // sample loop (+ further rounds)
@@ -875,7 +912,7 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
 #if DR_PHASE_TIMING
     __syncthreads();
     if (threadIdx.x == 0)  // whole lifetime of a backward workgroup, gradient flush included
-        atomicAdd(reinterpret_cast<unsigned long long *>(P.stats + 50), (unsigned long long)(clock64() - tk0));
+        atomicAdd(reinterpret_cast<unsigned long long *>(P.stats + ST_TIMING) + 6, (unsigned long long)(clock64() - tk0));
 #endif
 }
 
@@ -901,7 +938,7 @@ static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     BrickParams<VT> P = make_brick_params<VT>(a, w);
     hipError_t e;
 #if DR_PHASE_TIMING
-    if ((e = hipMemsetAsync(w.stats, 0, 256, stream)) != hipSuccess) return (int)e;  // the timing slots
+    if ((e = hipMemsetAsync(w.stats + ST_TIMING, 0, 64, stream)) != hipSuccess) return (int)e;  // the timing slots
 #endif
     e = hipMemsetAsync(w.seg_cnt, 0, w.cnt_bytes, stream);
     if (e != hipSuccess) return (int)e;
@@ -910,8 +947,8 @@ static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     const dim3 grid1(nbricks, a.n_views);
     // Alpha pre-pass (early-termination culling): only if the TF can make some ray reach alpha >= 0.99 -- decided on
     // the device from max(alpha) by the first kernel (which also writes the brick records and resets the workspace
-    // header); the kernels of the pre-pass return at once otherwise. The header holds flags for 48 views.
-    const bool prepass = a.n_views <= 48;
+    // header); the kernels of the pre-pass return at once otherwise.
+    const bool prepass = true;
     double n_max = 0.0;
     if (prepass) {
         const double diag = sqrt((double)(a.VX - 1) * (a.VX - 1) + (double)(a.VY - 1) * (a.VY - 1) + (double)(a.VZ - 1) * (a.VZ - 1));
@@ -981,13 +1018,14 @@ static int flat_bwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     const bool wv = a.d_vol != nullptr, wt = a.d_tf != nullptr;
     const size_t lds = flat_lds_bytes<true>(a.R, wv, wt);
     const dim3 grid1(g.NBx * g.NBy * g.NBz, a.n_views);
-    hipError_t e = hipMemsetAsync(w.stats + 1, 0, 4, stream);
+    // robust cap on |grad_out| (exponent histogram -> 99th percentile x 2^12), then the brick records
+    hipError_t e = hipMemsetAsync(w.stats + ST_HIST, 0, 256 * 4, stream);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(brick_ctx_kernel<VT>, dim3((grid1.x + 255) / 256, a.n_views), dim3(256), 0, stream, P, w.ctx, (int)grid1.x, 0, 0.0f);
     const size_t ng = (size_t)a.n_views * NP * 4;
-    const size_t nb = (ng + 256 * 16 - 1) / (256 * 16);
-    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(nb > 1024 ? 1024 : nb)), dim3(256), 0, stream, a.grad_out, ng,
-                       w.stats + 1);
+    const size_t nb = (ng + 256 * 4 - 1) / (256 * 4);
+    hipLaunchKernelGGL(gradstat_kernel, dim3((unsigned)(nb > 1024 ? 1024 : nb)), dim3(256), 0, stream, a.grad_out, ng,
+                       w.stats + ST_HIST);
+    hipLaunchKernelGGL(brick_ctx_kernel<VT>, dim3((grid1.x + 255) / 256, a.n_views), dim3(256), 0, stream, P, w.ctx, (int)grid1.x, 0, 0.0f);
     if (wv && wt) {
         if ((e = allow_lds(brick_flat_kernel<VT, DR_MODE_DIFF, true, true, true>, lds)) != hipSuccess) return (int)e;
         hipLaunchKernelGGL((brick_flat_kernel<VT, DR_MODE_DIFF, true, true, true>), grid1, dim3(FNT_BWD), lds, stream, P);

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void ray_compose_kernel(BrickParams<VT> P) {
         const size_t seg0 = (size_t)view * P.g.NL * NP + pl;
         bool regular = ray_is_regular(rg.n, rg.entry);
         // with an alpha pre-pass the bricks marched exactly the live samples of the ray: no crossing to look for
-        const bool use_live = P.use_live && P.stats[2 + view] != 0u;
+        const bool use_live = P.use_live && P.vflags[view] != 0u;
         if (regular && use_live) nmarch = min(nmarch, P.ws_steps[p]);
         int l_lo = 0, l_hi = P.g.NL - 1;
         if (regular && nmarch > 0) {
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void ray_compose_kernel(BrickParams<VT> P) {
             // safety net: the segments must account for every sample, else march this ray whole
             int total = 0;
             for (int l = l_lo; l <= l_hi; ++l) total += P.seg_cnt[seg0 + (size_t)l * NP];
-            if (total != nmarch) { regular = false; nmarch = nfull; atomicAdd(&P.stats[0], 1u); }
+            if (total != nmarch) { regular = false; nmarch = nfull; atomicAdd(&P.stats[ST_REPAIR], 1u); }
         }
         int s_from = 0, s_to = 0;  // samples to march one by one with early termination
         if (!regular) {
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void ray_compose_kernel(BrickParams<VT> P) {
 template <typename VT, int MODE>
 __global__ __launch_bounds__(256) void ray_alpha_kernel(BrickParams<VT> P) {
     const int view = blockIdx.y;
-    if (P.stats[2 + view] == 0u) return;  // uniform: no ray of this view can terminate, nothing to find
+    if (P.vflags[view] == 0u) return;  // uniform: no ray of this view can terminate, nothing to find
     const int NP = P.W * P.H;
     const int pl = blockIdx.x * 256 + threadIdx.x;
     if (pl >= NP) return;
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void ray_alpha_kernel(BrickParams<VT> P) {
 template <typename VT, int MODE>
 __global__ __launch_bounds__(256) void ray_cross_kernel(BrickParams<VT> P) {
     const int view = blockIdx.y;
-    if (P.stats[2 + view] == 0u) return;  // uniform
+    if (P.vflags[view] == 0u) return;  // uniform
     const int NP = P.W * P.H;
     const int lane = threadIdx.x & 63;
     // waves walk over the rays (a bounded grid: gated off, the launch costs a few thousand workgroup exits)

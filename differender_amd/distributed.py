@@ -7,7 +7,7 @@ d_volume / d_tf over them. The only exchange step is one sum all-reduce of those
 """
 import torch
 
-__all__ = ["shard_views", "shard_rows", "all_reduce_gradients"]
+__all__ = ["shard_views", "shard_rows", "all_reduce_gradients", "GradientReducer"]
 
 
 def shard_views(n_views, rank=None, world_size=None):
@@ -75,3 +75,28 @@ def _dense(t):
 def _flat_view(t):
     """1-D view over the storage block of a dense tensor (order is irrelevant for an elementwise sum)."""
     return torch.as_strided(t, (t.numel(),), (1,))
+
+
+class GradientReducer:
+    """At most ONE gradient all-reduce in flight, overlapped with the next step's rendering.
+
+    `submit(grads)` first waits for the reduction submitted before (so its buffers may be recycled), then starts the sum
+    all-reduce of `grads` asynchronously -- on RCCL's own stream, i.e. concurrent with the kernels the caller enqueues
+    next -- and keeps the tensors alive until it has completed. `wait()` blocks the current stream on the reduction in
+    flight and returns the reduced tensors of that step (read them only after it). One instance per training loop."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self._handles, self._grads = [], []
+
+    def submit(self, grads):
+        done = self.wait()
+        self._grads = [g for g in grads if g is not None]
+        self._handles = all_reduce_gradients(self._grads, group=self.group, async_op=True)
+        return done
+
+    def wait(self):
+        for h in self._handles:
+            h.wait()
+        done, self._handles, self._grads = self._grads, [], []
+        return done

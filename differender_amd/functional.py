@@ -11,7 +11,7 @@ import torch
 from . import _native as N
 
 __all__ = ["ray_setup", "march_fwd", "march_bwd", "new_jitter_seed", "alloc_workspace", "workspace_stats",
-           "mse_loss_grad", "tf_momentum_step"]
+           "mse_loss_grad", "tf_momentum_step", "as_volume", "bwd_is_sanitised"]
 
 
 def _stream():
@@ -22,6 +22,24 @@ def _require_gpu(t, name):
     if not t.is_cuda:
         raise RuntimeError(f"differender_amd: `{name}` must live on a ROCm GPU (got {t.device}); "
                            "there is no CPU path")
+
+
+def as_volume(vol):
+    """The reference's setters call `.float()` on whatever they are given (VR.py:118-125): float64, bfloat16 or
+    integer volumes are converted; float32 and float16 (storage extension) pass through untouched."""
+    return vol if vol.dtype in (torch.float32, torch.float16) else vol.float()
+
+
+def bwd_is_sanitised(vol, tf, d_vol, workspace):
+    """True if march_bwd(vol, tf, ..., workspace=workspace) is served by the fast kernels, whose gradients are
+    finite by construction (dr_march_bwd_variant); False for the plain kernels, which propagate NaN like the
+    reference and want the reference's nan_to_num."""
+    if workspace is None:
+        return False
+    sv = vol.stride()[-3:]
+    sd = d_vol.stride()[-3:] if d_vol is not None else (0, 0, 0)
+    return N.lib().dr_march_bwd_variant(*(int(v) for v in vol.shape[-3:]), int(tf.shape[-2]), *sv, *sd,
+                                        int(d_vol is not None), N.DR_VARIANT_AUTO, 1) == N.DR_VARIANT_AUTO
 
 
 def _vol_args(vol, n_views):
@@ -72,7 +90,8 @@ def alloc_workspace(n_views, out_shape, vol_shape, R, device):
 
 def workspace_stats(workspace):
     """Diagnostics the last forward left in the workspace header: [0] = rays whose segments failed the
-    sample-count check and were marched individually (expected 0)."""
+    sample-count check and were marched individually (expected 0), [2] = all rays the per-ray fallback marched
+    (those plus the irregular ones: single-sample rays)."""
     return workspace[:32].view(torch.int32).cpu()
 
 

@@ -13,6 +13,8 @@ Differences from the reference that a caller can observe (all documented in DESI
   * there is no render tape: `max_samples` only bounds the number of marched samples (H2);
   * flat-normal samples contribute no normal-path gradient instead of NaN (H3).
 """
+import math
+
 import torch
 
 from . import _native as N
@@ -82,13 +84,14 @@ class VolumeRaycaster:
         self.resolution = tuple(render_resolution)
         self.aspect = render_resolution[0] / render_resolution[1]
         self.fov_deg = fov
+        self.fov_rad = math.radians(fov)  # VR.py:77
         self.near, self.far = nearfar
         self.max_samples = max_samples
         self.volume_resolution = tuple(volume_resolution)
         self.tf_resolution = tf_resolution
         self.ambient, self.diffuse, self.specular, self.shininess = 0.4, 0.8, 0.3, 32.0  # VR.py:91-94 (fixed in-kernel)
         for name in ("volume", "tf_tex", "cam_pos", "entry", "exit", "rays", "sample_step_nums",
-                     "valid_sample_step_count", "output_rgba", "volume_grad", "tf_tex_grad", "output_rgba_grad",
+                     "steps", "output_rgba", "volume_grad", "tf_tex_grad", "output_rgba_grad",
                      "tape_last", "workspace"):
             setattr(self, "_" + name, None)
         self.volume = _Field(self, "volume", needs_grad=True)
@@ -110,9 +113,19 @@ class VolumeRaycaster:
             return (self.tf_resolution,)
         return self.resolution
 
-    # -- setters (VR.py:118-125): keep a float32 view, no relayout copy
+    @property
+    def _valid_sample_step_count(self):
+        """The reference's field starts at 1 and counts one per live sample (VR.py:303,381); the kernels report
+        the live samples themselves (`steps`)."""
+        return None if self._steps is None else self._steps + 1
+
+    @_valid_sample_step_count.setter
+    def _valid_sample_step_count(self, t):
+        self._steps = None if t is None else t - 1
+
+    # -- setters (VR.py:118-125): keep a float32 (or float16) view, no relayout copy
     def set_volume(self, volume):
-        self._volume = volume if volume.dtype == torch.float16 else volume.float()
+        self._volume = F.as_volume(volume)
 
     def set_tf_tex(self, tf_tex):
         self._tf_tex = tf_tex.float().contiguous()
@@ -122,14 +135,14 @@ class VolumeRaycaster:
 
     @property
     def max_valid_sample_step_count(self):
-        """VR.py:89,370-372 diagnostic (computed on demand; forces a device sync)."""
-        c = self._valid_sample_step_count
-        return 0 if c is None else int(c.max().item())
+        """VR.py:89,370-372 diagnostic: max over pixels of valid_sample_step_count - 1 (computed on demand; forces a
+        device sync)."""
+        return 0 if self._steps is None else int(self._steps.max().item())
 
     def clear_framebuffer(self):  # VR.py:374-382
         dev = self._volume.device
         self._output_rgba = torch.zeros((*self.resolution, 4), dtype=torch.float32, device=dev)
-        self._valid_sample_step_count = torch.zeros(self.resolution, dtype=torch.int32, device=dev)
+        self._steps = torch.zeros(self.resolution, dtype=torch.int32, device=dev)  # valid_sample_step_count = 1
         self._tape_last = None
 
     def clear_grad(self):  # VR.py:384-389
@@ -150,7 +163,7 @@ class VolumeRaycaster:
                                  self._rays[None], self._sample_step_nums[None], self.max_samples, sampling_rate, mode,
                                  fov_deg=self.fov_deg, near=self.near, workspace=self._workspace)
         self._tape_last = out[0]
-        self._valid_sample_step_count = steps[0]
+        self._steps = steps[0]
         self._sr = sampling_rate
 
     def _raycast(self, sampling_rate):  # VR.py:261-306
@@ -193,7 +206,8 @@ class RaycastFunction(torch.autograd.Function):
         cam = look_from.reshape(-1, 3)
         if is_batched and cam.shape[0] != bs:
             cam = cam.expand(bs, 3)
-        tf = tf.contiguous()
+        volume = F.as_volume(volume)          # set_volume's .float() (VR.py:119); float16 storage is kept
+        tf = tf.float().contiguous()          # set_tf_tex's .float() (VR.py:122)
         seed = F.new_jitter_seed() if jitter else 0
         e, x, r, n = F.ray_setup(cam, vr.resolution, volume.shape[-3:], sampling_rate, vr.fov_deg, vr.near, seed)
         ws = F.alloc_workspace(cam.shape[0], vr.resolution, volume.shape[-3:], tf.shape[-2], volume.device)
@@ -202,7 +216,7 @@ class RaycastFunction(torch.autograd.Function):
         ctx.save_for_backward(volume, tf, cam, e, x, r, n, out)
         ctx.workspace = ws  # coarse tape of the forward (per-segment prefixes), consumed by backward
         ctx.vr, ctx.sampling_rate, ctx.batched, ctx.jitter_seed = vr, sampling_rate, is_batched, seed
-        vr._valid_sample_step_count = steps if is_batched else steps[0]
+        vr._steps = steps if is_batched else steps[0]
         return out if is_batched else out[0]
 
     @staticmethod
@@ -214,11 +228,14 @@ class RaycastFunction(torch.autograd.Function):
         dv, dt = F.march_bwd(volume, tf, cam, e, x, r, n, ctx.vr.max_samples, ctx.sampling_rate, g, out,
                              want_vol=want_vol, want_tf=want_tf, fov_deg=ctx.vr.fov_deg, near=ctx.vr.near,
                              workspace=ctx.workspace)
-        # VR.py:463-464,474-475
-        if dv is not None:
-            dv = torch.nan_to_num(dv)
-        if dt is not None:
-            dt = torch.nan_to_num(dt)
+        # VR.py:463-464,474-475: nan_to_num. The fast kernels drop NaN adjoints and clamp infinite ones themselves
+        # ("non-finite upstream gradients"), so the two full passes over d_volume are only run when the
+        # plain kernels served the call.
+        if not F.bwd_is_sanitised(volume, tf, dv, ctx.workspace):
+            if dv is not None:
+                dv = torch.nan_to_num(dv)
+            if dt is not None:
+                dt = torch.nan_to_num(dt)
         return None, dv, dt, None, None, None, None
 
 
@@ -256,12 +273,12 @@ class Raycaster(torch.nn.Module):
         with torch.no_grad(), torch.autocast("cuda", enabled=False):
             batched, bs, vol_in, tf_in, lf_in = self._determine_batch(volume, tf, look_from)
             sr = sampling_rate if sampling_rate is not None else 4.0 * self.sampling_rate
-            vol_in = vol_in if vol_in.dtype == torch.float16 else vol_in.float()
+            vol_in = F.as_volume(vol_in)
             cam = lf_in.reshape(-1, 3).float()
             e, x, r, n = F.ray_setup(cam, self.vr.resolution, vol_in.shape[-3:], sr, self.vr.fov_deg, self.vr.near, 0)
             out, steps = F.march_fwd(vol_in, tf_in.float().contiguous(), cam, e, x, r, n, self.vr.max_samples, sr,
                                      N.DR_MODE_NONDIFF, fov_deg=self.vr.fov_deg, near=self.vr.near)
-            self.vr._valid_sample_step_count = steps if batched else steps[0]
+            self.vr._steps = steps if batched else steps[0]
             if batched:  # (BS,W,H,4) -> flip H -> (BS,4,H,W), VR.py:513
                 return torch.flip(out, (2,)).permute(0, 3, 2, 1).contiguous()
             return torch.flip(out[0], (1,)).permute(2, 1, 0).contiguous()  # VR.py:523

@@ -110,6 +110,15 @@ int dr_march_bwd(const void *vol, int vol_dtype, int VX, int VY, int VZ,
                  float *d_tf, int64_t dtf_view_stride,
                  void *workspace, size_t workspace_bytes, void *stream);
 
+/* Which kernels dr_march_bwd[_rows] would run for these arguments, without running anything (no GPU needed):
+ * DR_VARIANT_AUTO = the brick-centric kernels, DR_VARIANT_BASELINE = the plain ones (requested, no workspace, a
+ * TF too large for LDS, a volume edge > 2000, or strides beyond 32-bit in-box offsets).
+ * The brick-centric backward returns FINITE gradients by construction: a NaN adjoint (NaN pixel of grad_out, NaN
+ * voxel) contributes nothing and +-inf is clamped, so its caller may skip the torch.nan_to_num of VR.py:463-475; the
+ * plain kernels propagate NaN exactly like the reference and rely on it. (dsx,dsy,dsz) are ignored if !has_dvol. */
+int dr_march_bwd_variant(int VX, int VY, int VZ, int R, int64_t sx, int64_t sy, int64_t sz,
+                         int64_t dsx, int64_t dsy, int64_t dsz, int has_dvol, int variant, int has_workspace);
+
 /* Image bands: the same three calls for rows [row0, row0 + W) of an image that is img_W rows wide (SURVEY 8(e):
  * "single view => split the image into G tile bands", one band per GPU). All [n_views][W][H] buffers hold the band
  * only; pixel (i, j) of the band is pixel (row0 + i, j) of the image -- same ray, same jitter value, bit for bit, as in

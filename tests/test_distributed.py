@@ -82,3 +82,52 @@ def test_two_rank_gradient_allreduce_matches_single_process(oracle):
         dv_ref += a; dt_ref += b
     assert np.abs(dv - dv_ref).max() <= 1e-5 * np.abs(dv_ref).max()
     assert np.abs(dt - dt_ref).max() <= 1e-5 * np.abs(dt_ref).max()
+
+
+def _reducer_worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from differender_amd.distributed import GradientReducer
+        red = GradientReducer()
+        results = []
+        for step in range(4):
+            # what bench.py's step does after the backward: fresh gradient tensors every step, handed to the reducer;
+            # the previous step's reduction is collected when the next one is submitted (at most one in flight)
+            big = torch.full((64, 64, 64), float((rank + 1) * (step + 1))).permute(2, 0, 1)   # >= 1 MiB, dense, not contiguous
+            small = torch.full((16, 4), float(rank + 10 * step))
+            done = red.submit([big, small, None])
+            if done:
+                results.append([t.clone() for t in done])
+        results.append([t.clone() for t in red.wait()])
+        assert red.wait() == []
+        if rank == 0:
+            q.put([(float(b.flatten()[0]), float(b.min()), float(b.max()), float(s_.flatten()[0])) for b, s_ in results])
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put(("error", rank, traceback.format_exc()))
+        raise
+
+
+def test_overlapped_gradient_reducer_two_ranks():
+    """The N > 1 control flow of bench.py: asynchronous all-reduce of each step's gradients, at most one in flight,
+    buffers kept alive until it completes, every step's result correct."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_reducer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    assert not (isinstance(got, tuple) and got[0] == "error"), got
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len(got) == 4
+    for step, (b0, bmin, bmax, s0) in enumerate(got):
+        assert b0 == bmin == bmax == 3.0 * (step + 1)          # (1 + 2) * (step + 1)
+        assert s0 == 1.0 + 20.0 * step                        # (0 + 10 step) + (1 + 10 step)

@@ -99,6 +99,43 @@ def test_backward_linearity_and_stability(scene):
     assert torch.isfinite(dv1).all() and torch.isfinite(dt1).all()
 
 
+def test_config_c3_backward_wrt_tf_only(scene, oracle):
+    """BASELINE config C3 at full size: forward + backward w.r.t. the TF alone (the d_tf-only instantiation of the
+    backward kernel: no gradient box in LDS). Patch parity against the oracle, agreement with the d_tf of the
+    volume+TF backward, linearity."""
+    F = scene["F"]
+    dev = scene["dev"]
+    e, x, r, n = (t[0].cpu().numpy() for t in scene["rays"])
+    vol_h = scene["vol"].cpu().numpy(); tf_h = scene["tf"].cpu().numpy(); cam_h = scene["cam"][0].cpu().numpy()
+    out, steps, ws = _fwd(scene, 0)
+    rng = np.random.RandomState(17)
+    g = np.zeros((IMG, IMG, 4), np.float32)
+    dt_ref = np.zeros_like(tf_h)
+    for (i0, j0) in [(256, 200), (140, 330)]:
+        sl = (slice(i0, i0 + 12), slice(j0, j0 + 12))
+        g[sl] = rng.randn(12, 12, 4).astype(np.float32)
+        _, b = oracle.march_bwd(vol_h, tf_h, cam_h, e[sl], x[sl], r[sl], n[sl], 1 << 20, 1.0, g[sl], want_vol=False)
+        dt_ref += b
+
+    def bwd(gt, want_vol):
+        return F.march_bwd(scene["vol"], scene["tf"], scene["cam"], *scene["rays"], 1 << 20, 1.0, gt, out,
+                           want_vol=want_vol, want_tf=True, workspace=ws)
+
+    dv, dt = bwd(torch.from_numpy(g[None]).to(dev), False)
+    assert dv is None
+    assert np.abs(dt.cpu().numpy() - dt_ref).max() <= 1e-4 * np.abs(dt_ref).max()
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    g1 = torch.randn((1, IMG, IMG, 4), generator=gen).to(dev)
+    g2 = torch.randn((1, IMG, IMG, 4), generator=gen).to(dev)
+    _, dt1 = bwd(g1, False)
+    _, dt2 = bwd(g2, False)
+    _, dt3 = bwd(1.5 * g1 + 0.25 * g2, False)
+    st = float(dt3.abs().max())
+    assert float((dt3 - (1.5 * dt1 + 0.25 * dt2)).abs().max()) <= 2e-5 * st
+    _, dt_both = bwd(g1, True)                                # the volume+TF instantiation computes the same d_tf
+    assert float((dt_both - dt1).abs().max()) <= 2e-6 * float(dt1.abs().max())
+
+
 def test_early_termination_at_full_size(scene):
     """An opaque-ish TF: rays stop early; the exact re-march of the crossing segment must agree with the baseline."""
     tf = scene["tf"].clone()
@@ -194,3 +231,26 @@ def test_config_c5_fp16_1024_jittered_view(hiplib, oracle):
         assert np.abs(dv_h[nz] - a[nz]).max() <= 1e-4 * np.abs(a).max()
     assert np.abs(dt.cpu().numpy() - dt_ref).max() <= 1e-4 * np.abs(dt_ref).max()
     assert dv.dtype == torch.float32 and torch.isfinite(dv).all()
+    # the same view through Raycaster.forward + autograd with an fp16 LEAF volume (user layout (1,D,H,W), jitter drawn by
+    # the module from torch's generator): bit-identical image, gradients = the functional ones rounded to half
+    from differender_amd.volume_raycaster import Raycaster
+    del ws
+    leaf = vol16.permute(1, 2, 0).contiguous()[None].requires_grad_(True)      # field (W,D,H) -> user (1,D,H,W)
+    tf_u = tf.t().contiguous().requires_grad_(True)
+    rc = Raycaster((n, n, n), (img, img), R, jitter=True, max_samples=1 << 20)
+    torch.manual_seed(99)
+    im = rc(leaf, tf_u, cam[0])
+    torch.manual_seed(99)
+    seed = F.new_jitter_seed()
+    e2, x2, r2, n2 = F.ray_setup(cam, (img, img), (n, n, n), 1.0, jitter_seed=seed)
+    ws2 = F.alloc_workspace(1, (img, img), (n, n, n), R, dev)
+    out2, _ = F.march_fwd(vol16, tf, cam, e2, x2, r2, n2, 1 << 20, 1.0, workspace=ws2)
+    assert im.shape == (4, img, img)
+    assert torch.equal(im, torch.flip(out2[0], (1,)).permute(2, 1, 0))
+    gt = torch.from_numpy(g[None]).to(dev)
+    (im * torch.flip(gt[0], (1,)).permute(2, 1, 0)).sum().backward()
+    dv2, dt2 = F.march_bwd(vol16, tf, cam, e2, x2, r2, n2, 1 << 20, 1.0, gt, out2, workspace=ws2)
+    assert leaf.grad.dtype == torch.float16 and leaf.grad.shape == leaf.shape
+    gl = leaf.grad[0].permute(2, 0, 1).float()
+    assert float((gl - dv2).abs().max()) <= 1e-3 * float(dv2.abs().max())      # half rounding of the gradient
+    assert float((tf_u.grad.t() - dt2).abs().max()) <= 1e-5 * float(dt2.abs().max())

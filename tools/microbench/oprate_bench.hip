@@ -45,6 +45,15 @@ KERNEL(k_mul_u24, "v_mul_u32_u24 %0, %0, %1", int, V)
 KERNEL(k_mad_u24, "v_mad_u32_u24 %0, %0, %1, %2", int, V)
 KERNEL(k_min_i32, "v_min_i32 %0, %0, %1", int, V)
 KERNEL(k_bfe, "v_bfe_u32 %0, %0, 3, 5", int, V)
+KERNEL(k_cvt_rpi, "v_cvt_rpi_i32_f32 %0, %0", float, V)
+KERNEL(k_cvt_flr, "v_cvt_flr_i32_f32 %0, %0", float, V)
+KERNEL(k_fract, "v_fract_f32 %0, %0", float, V)
+KERNEL(k_max_dpp, "v_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1", float, V)
+KERNEL(k_frexp_exp, "v_frexp_exp_i32_f32 %0, %0", float, V)
+KERNEL(k_ldexp, "v_ldexp_f32 %0, %0, %1", float, V)
+KERNEL(k_ashr, "v_ashrrev_i32 %0, 31, %0", int, V)
+KERNEL(k_lshl, "v_lshlrev_b32 %0, 3, %0", int, V)
+KERNEL(k_perm, "v_perm_b32 %0, %0, %1, %2", int, V)
 KERNELC(k_readlane, "v_readlane_b32 s20, %0, 63", int, V, "s20")
 
 __global__ __launch_bounds__(256) void k_mad64(int *out, int iters, int b, int c) {
@@ -57,6 +66,45 @@ __global__ __launch_bounds__(256) void k_mad64(int *out, int iters, int b, int c
             for (int i = 0; i < 8; ++i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(a[i]) : "v"(b), "v"(c) : "vcc");
     }
     unsigned long long s = 0; for (int i = 0; i < 8; ++i) s += a[i];
+    out[blockIdx.x * 256 + threadIdx.x] = (int)s;
+}
+
+// 64-bit results: sign-extending multiply (q * 2^k as one instruction) and float -> double conversion
+__global__ __launch_bounds__(256) void k_mad_i64_i32(int *out, int iters, int b, int c) {
+    long long a[8]; int q[8];
+    for (int i = 0; i < 8; ++i) { a[i] = 0; q[i] = threadIdx.x + i + 1; }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, 0" : "=v"(a[i]) : "v"(q[i]), "v"(b) : "vcc");
+    }
+    long long s = 0; for (int i = 0; i < 8; ++i) s += a[i];
+    out[blockIdx.x * 256 + threadIdx.x] = (int)s;
+}
+__global__ __launch_bounds__(256) void k_mad_i64_i32_sgpr(int *out, int iters, int b, int c) {
+    long long a[8]; int q[8];
+    for (int i = 0; i < 8; ++i) { a[i] = 0; q[i] = threadIdx.x + i + 1; }
+    const int bs = __builtin_amdgcn_readfirstlane(b);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, 0" : "=v"(a[i]) : "v"(q[i]), "s"(bs) : "vcc");
+    }
+    long long s = 0; for (int i = 0; i < 8; ++i) s += a[i];
+    out[blockIdx.x * 256 + threadIdx.x] = (int)s;
+}
+__global__ __launch_bounds__(256) void k_cvt_f64_f32(int *out, int iters, int b, int c) {
+    double a[8]; float q[8];
+    for (int i = 0; i < 8; ++i) { a[i] = 0; q[i] = (float)(threadIdx.x + i + 1); }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(a[i]) : "v"(q[i]));
+    }
+    double s = 0; for (int i = 0; i < 8; ++i) s += a[i];
     out[blockIdx.x * 256 + threadIdx.x] = (int)s;
 }
 
@@ -82,6 +130,7 @@ int main() {
     RF(k_fma) RF(k_add) RF(k_mul) RF(k_max) RF(k_floor) RF(k_cvt_i32_f32) RF(k_cvt_f32_i32) RF(k_rcp) RF(k_rsq) RF(k_mov)
     RF(k_mov_dpp) RF(k_add_dpp) RF(k_cndmask) RF(k_cndmask_e32) RF(k_cndmask_sgpr) RF(k_cmp_cndmask) RF(k_cmp_sgpr) RF(k_cmp)
     RI(k_add_u32) RI(k_lshl_add) RI(k_add3) RI(k_mul_lo) RI(k_mul_hi) RI(k_mul_u24) RI(k_mad_u24) RI(k_min_i32) RI(k_bfe) RI(k_readlane)
-    RI(k_mad64)
+    RI(k_mad64) RI(k_mad_i64_i32) RI(k_mad_i64_i32_sgpr) RI(k_cvt_f64_f32)
+    RF(k_cvt_rpi) RF(k_cvt_flr) RF(k_fract) RF(k_max_dpp) RF(k_frexp_exp) RF(k_ldexp) RI(k_ashr) RI(k_lshl) RI(k_perm)
     return 0;
 }
