@@ -176,10 +176,13 @@ static __global__ __launch_bounds__(256) void brick_ctx_kernel(BrickParams<VT> P
                 P.vflags[view] = flag;
                 if (view == 0) { P.stats[ST_REPAIR] = 0u; P.stats[ST_BASELINE_RAYS] = 0u; P.stats[ST_MARK] = DR_CTX_MARK; }
             }
-        } else if (view == 0) {
+        }
+#if !DR_ACC_F64
+        else if (view == 0) {
             const unsigned int cap = grad_cap_bits(P.stats + ST_HIST);
             if (threadIdx.x == 0) P.stats[ST_GCAP] = cap;
         }
+#endif
     }
     if (b >= nbricks) return;
     const f3 cam = make_f3(P.cam[3 * view], P.cam[3 * view + 1], P.cam[3 * view + 2]);
@@ -268,7 +271,42 @@ __device__ __forceinline__ void load_ray(const float *entry, const float *exit_,
     rg.t0 = rg.entry + 0.5f * (rg.exit_ - rg.entry) / (float)rg.n;
 }
 
-// ---- 64-bit fixed point for the LDS accumulators -------------------------------------------------------
+// ---- LDS gradient accumulators --------------------------------------------------------------------------
+// ds_add_f32 is serialised on gfx950 (193 cycles per wave-instruction whatever the addresses), ds_add_u64 takes 9-12 and
+// ds_add_f64 16-20 (tools/microbench/lds_atomic_bench, profiles/r02_microbench_lds_atomics.txt). Two accumulator
+// formats are kept behind DR_ACC_F64:
+//   1 (default)  DOUBLE accumulators: each f32 contribution is widened (v_cvt_f64_f32, same cost as the float->int
+//                conversion) and added with ds_add_f64. No scale, no clamp, no dynamic-range limit: a voxel that only
+//                rays with a 1e-9 times smaller upstream gradient touch is as accurate as any other.
+//   0            64-bit FIXED POINT with one scale per brick (2^28 / max|grad_out| over the brick's candidate pixels),
+//                32-bit addends under a wave-uniform magnitude test: cheaper LDS adds, but contributions below
+//                2^-29 of the brick's largest upstream gradient are lost.
+#ifndef DR_ACC_F64
+#define DR_ACC_F64 1
+#endif
+#if DR_ACC_F64
+struct FixScale { float lo; float lim; };
+__device__ __forceinline__ FixScale make_fix_scale(float) { FixScale f; f.lo = 1.0f; f.lim = 1.0e30f; return f; }
+// A NaN adjoint (NaN pixel in grad_out, NaN voxel) contributes nothing: the reference lets it poison every voxel and
+// texel the ray touches and then zeroes those with nan_to_num (VR.py:463-475); here only the bad ray is dropped.
+// Magnitudes beyond 1e30 (an overflowed loss) are clamped so that no sum can reach infinity.
+__device__ __forceinline__ float fix_clamp(float x, const FixScale &f) {
+    return (x == x) ? fminf(fmaxf(x, -f.lim), f.lim) : 0.0f;
+}
+__device__ __forceinline__ bool fix_fits(float absmax, const FixScale &f) { return absmax <= f.lim; }  // false for NaN
+template <bool WIDE, bool PRE = false>
+__device__ __forceinline__ void fix_add_t(unsigned long long *p, float x, const FixScale &) {
+#ifdef DR_ABL_NOATOMIC
+    asm volatile("" :: "v"(p), "v"((double)x));
+#else
+    atomicAdd(reinterpret_cast<double *>(p), (double)x);  // ds_add_f64
+#endif
+}
+__device__ __forceinline__ void fix_add(unsigned long long *p, float x, const FixScale &f) { fix_add_t<true>(p, x, f); }
+__device__ __forceinline__ float fix_to_float(unsigned long long v, const FixScale &) {
+    return fminf(fmaxf((float)__longlong_as_double((long long)v), -3.0e38f), 3.0e38f);
+}
+#else
 // value = x * 2^shift, stored as a two's-complement int64. fx_hi = 2^(shift-32) is passed around as a float.
 #ifndef DR_FIX_BITS
 #define DR_FIX_BITS 28
@@ -333,6 +371,8 @@ __device__ __forceinline__ void fix_add(unsigned long long *p, float x, const Fi
 __device__ __forceinline__ float fix_to_float(unsigned long long v, const FixScale &f) {
     return (float)((double)(long long)v * f.inv);
 }
+
+#endif  // DR_ACC_F64
 
 // Exponent histogram of grad_out (finite, non-zero components): 256 bins in the workspace header, zeroed by the
 // caller. One pass over the upstream gradient; brick_ctx_kernel turns it into the robust cap.

@@ -566,24 +566,31 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
         if (!__syncthreads_or(nE0 > 0) && ncand <= EC) return;  // uniform: no wave found a segment
         box_issue<VT, FNT>(P, vol, c, P.tf + view * P.tf_vs, stage);
     } else {
+#if !DR_ACC_F64
         float gm = 0.0f;
         if (BWD) gm = cand_grad_max<VT, FNT>(P, c, view, ncand);            // upstream gradients of the candidates,
+#endif
         box_issue<VT, FNT>(P, vol, c, P.tf + view * P.tf_vs, stage);      // voxel box + TF: in flight ...
         if (BWD) {
             if (WANT_VOL) for (int k = threadIdx.x; k < BOX_LDS; k += FNT) L.dbox[k] = 0ull;
             if (WANT_TF) for (int k = threadIdx.x; k < 4 * P.R; k += FNT) L.dtf[k] = 0ull;
+#if !DR_ACC_F64
             gm = wave_max_f(gm);
             if ((threadIdx.x & 63) == 0) L.gmax[threadIdx.x >> 6] = gm;
+#endif
         }
         flat_build_entries<VT, MODE, BWD, FNT, ALPHA, KS>(P, c, cam, view, cd, seg_base, L, nE0, M0);  // ... while the segments are listed
     }
     box_commit<VT, FNT>(P, vol, c, P.tf + view * P.tf_vs, stage, L);
     __syncthreads();
-    if (BWD) {  // this brick's fixed-point scale (every thread derives the same one)
+    if (BWD) {
         float gm = 0.0f;
+#if !DR_ACC_F64
+        // this brick's fixed-point scale (every thread derives the same one)
 #pragma unroll
         for (int k = 0; k < FNW; ++k) gm = fmaxf(gm, L.gmax[k]);
         if (!(gm > 0.0f)) gm = __uint_as_float(P.stats[ST_GCAP]);  // only outliers (or zeros) in this brick
+#endif
         fs = make_fix_scale(gm);
     }
 #if DR_PHASE_TIMING
@@ -1018,13 +1025,16 @@ static int flat_bwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     const bool wv = a.d_vol != nullptr, wt = a.d_tf != nullptr;
     const size_t lds = flat_lds_bytes<true>(a.R, wv, wt);
     const dim3 grid1(g.NBx * g.NBy * g.NBz, a.n_views);
+    hipError_t e = hipSuccess;
+#if !DR_ACC_F64
     // robust cap on |grad_out| (exponent histogram -> 99th percentile x 2^12), then the brick records
-    hipError_t e = hipMemsetAsync(w.stats + ST_HIST, 0, 256 * 4, stream);
+    e = hipMemsetAsync(w.stats + ST_HIST, 0, 256 * 4, stream);
     if (e != hipSuccess) return (int)e;
     const size_t ng = (size_t)a.n_views * NP * 4;
     const size_t nb = (ng + 256 * 4 - 1) / (256 * 4);
     hipLaunchKernelGGL(gradstat_kernel, dim3((unsigned)(nb > 1024 ? 1024 : nb)), dim3(256), 0, stream, a.grad_out, ng,
                        w.stats + ST_HIST);
+#endif
     hipLaunchKernelGGL(brick_ctx_kernel<VT>, dim3((grid1.x + 255) / 256, a.n_views), dim3(256), 0, stream, P, w.ctx, (int)grid1.x, 0, 0.0f);
     if (wv && wt) {
         if ((e = allow_lds(brick_flat_kernel<VT, DR_MODE_DIFF, true, true, true>, lds)) != hipSuccess) return (int)e;

@@ -610,8 +610,8 @@ def _support(O, vol_h, tf_h, cam_h, rays, WH, mask):
 
 def test_backward_dynamic_range_of_upstream_gradient(oracle, F):
     """Half the image carries an upstream gradient 1e-5 times the other half's. The voxels that only the small-gradient
-    rays touch must still come out right ELEMENTWISE: the fixed-point scale of the LDS accumulators is taken per brick
-    from the brick's own candidate pixels (a global scale flushes these voxels to zero)."""
+    rays touch must still come out right ELEMENTWISE (the LDS accumulators are doubles; round 1's fixed point with one
+    global scale flushed these voxels to zero)."""
     vol_h, tf_h, cam_h = scene(oracle, N=48, R=32, alpha=0.03, cam_i=0.3)
     tf_h[:, 3] = np.linspace(0.01, 0.08, 32)
     WH = (64, 64)
@@ -634,20 +634,13 @@ def test_backward_dynamic_range_of_upstream_gradient(oracle, F):
     dvs, _ = oracle.march_bwd(vol_h, tf_h, cam_h, *rays, 4096, 1.0, g_s)
     err = np.abs(dv - dvs)[only_small]
     ref = np.abs(dvs)[only_small]
-    # relative to the voxel's own value, plus an absolute floor far below anything a global scale could resolve
-    # (1e-7 of the SMALL half's own maximum = 1e-12 of the tensor's)
-    bound = 1e-4 * ref + 1e-7 * np.abs(dvs).max()
-    if F.variant == 0:
-        # bricks whose pixel footprint straddles the boundary hold both kinds of rays: their quantum follows the big
-        # ones (2^-28 of the brick's max|grad_out|: DESIGN.md "fixed-point accumulators"); everywhere else the bound
-        # holds elementwise
-        ok = err <= bound
-        frac_bad = 1.0 - ok.mean()
-        assert frac_bad < 0.25, frac_bad
-        assert (err[~ok] <= 2.0 ** -24 * np.abs(dv0).max()).all()
-        assert ok.sum() > 1500
-    else:
-        assert (err <= bound).all()
+    # relative to the voxel's own value, plus a floor for sums that cancel -- relative to the SMALL half's own maximum,
+    # i.e. 2e-11 of the tensor's: five orders of magnitude below anything one global fixed-point scale could resolve
+    bound = 1e-4 * ref + 2e-6 * np.abs(dvs).max()
+    bad = err > bound
+    assert not bad.any(), (int(bad.sum()), int(bad.size), float((err / bound).max()))
+    # d_tf: every texel sees both halves; the small half's share is 1e-5 of it and must at least not disturb the sum
+    assert np.abs(dt - dt0).max() <= 1e-4 * np.abs(dt0).max()
 
 
 def test_backward_with_non_finite_upstream_gradient(oracle, F):
