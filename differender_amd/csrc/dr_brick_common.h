@@ -40,6 +40,7 @@ enum {
     ST_GCAP = 1,           // backward: bits of the robust cap on |grad_out| (gradstat_kernel + brick_ctx_kernel)
     ST_BASELINE_RAYS = 2,  // rays the per-ray fallback marched in the last forward (irregular rays + repaired ones)
     ST_MARK = 3,           // DR_CTX_MARK once the flat forward has written brick records and live flags
+    ST_F64_BRICKS = 4,     // backward: (view, brick) pairs whose d_volume box accumulated in double (wide local range of |grad_out|)
     ST_TIMING = 16,        // DR_PHASE_TIMING: u64 x3 forward phases, u64 x3 backward phases, u64 backward lifetime
     ST_HIST = 64,          // backward: 256-bin histogram of the exponents of grad_out's finite non-zero components
     ST_WORDS = 512         // header size in words (2 KiB)
@@ -176,13 +177,10 @@ static __global__ __launch_bounds__(256) void brick_ctx_kernel(BrickParams<VT> P
                 P.vflags[view] = flag;
                 if (view == 0) { P.stats[ST_REPAIR] = 0u; P.stats[ST_BASELINE_RAYS] = 0u; P.stats[ST_MARK] = DR_CTX_MARK; }
             }
-        }
-#if !DR_ACC_F64
-        else if (view == 0) {
+        } else if (view == 0) {
             const unsigned int cap = grad_cap_bits(P.stats + ST_HIST);
-            if (threadIdx.x == 0) P.stats[ST_GCAP] = cap;
+            if (threadIdx.x == 0) { P.stats[ST_GCAP] = cap; P.stats[ST_F64_BRICKS] = 0u; }
         }
-#endif
     }
     if (b >= nbricks) return;
     const f3 cam = make_f3(P.cam[3 * view], P.cam[3 * view + 1], P.cam[3 * view + 2]);
@@ -273,40 +271,35 @@ __device__ __forceinline__ void load_ray(const float *entry, const float *exit_,
 
 // ---- LDS gradient accumulators --------------------------------------------------------------------------
 // ds_add_f32 is serialised on gfx950 (193 cycles per wave-instruction whatever the addresses), ds_add_u64 takes 9-12 and
-// ds_add_f64 16-20 (tools/microbench/lds_atomic_bench, profiles/r02_microbench_lds_atomics.txt). Two accumulator
-// formats are kept behind DR_ACC_F64:
-//   1 (default)  DOUBLE accumulators: each f32 contribution is widened (v_cvt_f64_f32, same cost as the float->int
-//                conversion) and added with ds_add_f64. No scale, no clamp, no dynamic-range limit: a voxel that only
-//                rays with a 1e-9 times smaller upstream gradient touch is as accurate as any other.
-//   0            64-bit FIXED POINT with one scale per brick (2^28 / max|grad_out| over the brick's candidate pixels),
-//                32-bit addends under a wave-uniform magnitude test: cheaper LDS adds, but contributions below
-//                2^-29 of the brick's largest upstream gradient are lost.
-#ifndef DR_ACC_F64
-#define DR_ACC_F64 1
+// ds_add_f64 16-20, twice that per conflicting address (tools/microbench/lds_atomic_bench,
+// profiles/r02_microbench_lds_atomics.txt). Every accumulator is one 64-bit word, used in one of two formats:
+//   FIXED   64-bit fixed point with one scale PER BRICK (2^28 / the largest |grad_out| among the brick's candidate
+//           pixels), 32-bit addends rounded to nearest under a wave-uniform magnitude test, exact 64-bit addends
+//           otherwise. The fast format (d_volume at 512^3: 6.6 ms against 7.5 ms with doubles), but a contribution below
+//           2^-29 of the brick's largest upstream gradient is lost.
+//   DOUBLE  the f32 contribution is widened (v_cvt_f64_f32: the cost of the float -> int conversion) and added with
+//           ds_add_f64: no scale, no dynamic-range limit.
+// d_tf always accumulates in DOUBLE (few conflicts after the run sums: it is the faster format there). d_volume uses
+// FIXED unless the brick's candidate pixels span more than 2^DR_MIXED_BITS in |grad_out| (smallest non-zero against
+// largest): then a voxel touched only by the small-gradient rays would lose precision, and the brick switches to
+// DOUBLE (brick-uniform branch; stats[ST_F64_BRICKS] counts them).
+#ifndef DR_MIXED_BITS
+#define DR_MIXED_BITS 6
 #endif
-#if DR_ACC_F64
-struct FixScale { float lo; float lim; };
-__device__ __forceinline__ FixScale make_fix_scale(float) { FixScale f; f.lo = 1.0f; f.lim = 1.0e30f; return f; }
-// A NaN adjoint (NaN pixel in grad_out, NaN voxel) contributes nothing: the reference lets it poison every voxel and
-// texel the ray touches and then zeroes those with nan_to_num (VR.py:463-475); here only the bad ray is dropped.
-// Magnitudes beyond 1e30 (an overflowed loss) are clamped so that no sum can reach infinity.
-__device__ __forceinline__ float fix_clamp(float x, const FixScale &f) {
-    return (x == x) ? fminf(fmaxf(x, -f.lim), f.lim) : 0.0f;
-}
-__device__ __forceinline__ bool fix_fits(float absmax, const FixScale &f) { return absmax <= f.lim; }  // false for NaN
-template <bool WIDE, bool PRE = false>
-__device__ __forceinline__ void fix_add_t(unsigned long long *p, float x, const FixScale &) {
+constexpr float ACC_LIM = 1.0e30f;  // DOUBLE: adjoints beyond this (an overflowed loss) are clamped, NaN adjoints dropped
+__device__ __forceinline__ float acc_sanitise(float x) { return (x == x) ? fminf(fmaxf(x, -ACC_LIM), ACC_LIM) : 0.0f; }
+__device__ __forceinline__ void acc_add_f64(unsigned long long *p, float x) {
 #ifdef DR_ABL_NOATOMIC
     asm volatile("" :: "v"(p), "v"((double)x));
 #else
     atomicAdd(reinterpret_cast<double *>(p), (double)x);  // ds_add_f64
 #endif
 }
-__device__ __forceinline__ void fix_add(unsigned long long *p, float x, const FixScale &f) { fix_add_t<true>(p, x, f); }
-__device__ __forceinline__ float fix_to_float(unsigned long long v, const FixScale &) {
+__device__ __forceinline__ float acc_f64_to_float(unsigned long long v) {
     return fminf(fmaxf((float)__longlong_as_double((long long)v), -3.0e38f), 3.0e38f);
 }
-#else
+
+// FIXED format --------------------------------------------------------------------------------------------
 // value = x * 2^shift, stored as a two's-complement int64. fx_hi = 2^(shift-32) is passed around as a float.
 #ifndef DR_FIX_BITS
 #define DR_FIX_BITS 28
@@ -371,8 +364,6 @@ __device__ __forceinline__ void fix_add(unsigned long long *p, float x, const Fi
 __device__ __forceinline__ float fix_to_float(unsigned long long v, const FixScale &f) {
     return (float)((double)(long long)v * f.inv);
 }
-
-#endif  // DR_ACC_F64
 
 // Exponent histogram of grad_out (finite, non-zero components): 256 bins in the workspace header, zeroed by the
 // caller. One pass over the upstream gradient; brick_ctx_kernel turns it into the robust cap.

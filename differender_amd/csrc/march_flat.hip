@@ -83,7 +83,7 @@ __host__ __device__ constexpr size_t flat_fixed_bytes(bool want_vol) {
     if (BWD && want_vol) s += ((size_t)BOX_LDS * 8 + 15) / 16 * 16;
     s += (size_t)EC * 32;
     s += (size_t)EC * 4 + (((size_t)EC + 8) * 4 + 15) / 16 * 16 + (size_t)EC * 4 + (size_t)EC * 4;  // (live | slen)
-    if (BWD) s += 64;  // gmax
+    if (BWD) s += 64;  // gmax, gmin per wave
     return s;
 }
 template <bool BWD>
@@ -422,24 +422,33 @@ __device__ __forceinline__ Over shfl_up1_over(const Over &v) {
     return r;
 }
 
-template <bool WIDE, bool PRE = false>
+// How a d_volume contribution reaches its LDS accumulator (dr_brick_common.h, "LDS gradient accumulators")
+enum { ACC_FIX = 0,       // FIXED, 32-bit addend, value already carries the factor 2^shift
+       ACC_FIX_WIDE = 1,  // FIXED, exact 64-bit addend (some adjoint of the wave is large, non-finite values were clamped)
+       ACC_F64 = 2 };     // DOUBLE
+template <int ACC>
+__device__ __forceinline__ void acc_add(unsigned long long *p, float x, const FixScale &f) {
+    if (ACC == ACC_F64) acc_add_f64(p, x);
+    else fix_add_t<ACC == ACC_FIX_WIDE, ACC == ACC_FIX>(p, x, f);
+}
+template <int ACC>
 __device__ __forceinline__ void scatter8(unsigned long long *dbox, int base, const float (&w)[8], const FixScale &f) {
-    fix_add_t<WIDE, PRE>(dbox + base, w[0], f);
-    fix_add_t<WIDE, PRE>(dbox + base + BOX_SX, w[1], f);
-    fix_add_t<WIDE, PRE>(dbox + base + BOX_SY, w[2], f);
-    fix_add_t<WIDE, PRE>(dbox + base + BOX_SX + BOX_SY, w[3], f);
-    fix_add_t<WIDE, PRE>(dbox + base + 1, w[4], f);
-    fix_add_t<WIDE, PRE>(dbox + base + BOX_SX + 1, w[5], f);
-    fix_add_t<WIDE, PRE>(dbox + base + BOX_SY + 1, w[6], f);
-    fix_add_t<WIDE, PRE>(dbox + base + BOX_SX + BOX_SY + 1, w[7], f);
+    acc_add<ACC>(dbox + base, w[0], f);
+    acc_add<ACC>(dbox + base + BOX_SX, w[1], f);
+    acc_add<ACC>(dbox + base + BOX_SY, w[2], f);
+    acc_add<ACC>(dbox + base + BOX_SX + BOX_SY, w[3], f);
+    acc_add<ACC>(dbox + base + 1, w[4], f);
+    acc_add<ACC>(dbox + base + BOX_SX + 1, w[5], f);
+    acc_add<ACC>(dbox + base + BOX_SY + 1, w[6], f);
+    acc_add<ACC>(dbox + base + BOX_SX + BOX_SY + 1, w[7], f);
 }
 // the four voxels base + {0, SA, SB, SA+SB} receive c * w[0..3]
-template <bool WIDE, int SA, int SB, bool PRE = false>
+template <int ACC, int SA, int SB>
 __device__ __forceinline__ void scatter4(unsigned long long *dbox, int base, float c, const float (&w)[4], const FixScale &f) {
-    fix_add_t<WIDE, PRE>(dbox + base, c * w[0], f);
-    fix_add_t<WIDE, PRE>(dbox + base + SA, c * w[1], f);
-    fix_add_t<WIDE, PRE>(dbox + base + SB, c * w[2], f);
-    fix_add_t<WIDE, PRE>(dbox + base + SA + SB, c * w[3], f);
+    acc_add<ACC>(dbox + base, c * w[0], f);
+    acc_add<ACC>(dbox + base + SA, c * w[1], f);
+    acc_add<ACC>(dbox + base + SB, c * w[2], f);
+    acc_add<ACC>(dbox + base + SA + SB, c * w[3], f);
 }
 // Adjoint of the two central-difference taps of one axis, reduced to coefficients along that axis over the box
 // planes l0-1 .. l0+2 (l0 = centre cell). The +delta tap sits in cell l0 or l0+1, the -delta tap in l0-1 or l0
@@ -459,7 +468,7 @@ __device__ __forceinline__ void tap_line(int l0, int lp, int lm, float fp, float
 // lands there is summed into the centre's 8 corners first (8 LDS adds); what remains per axis is one outside
 // plane of 4 voxels (l0+2 or l0-1; both only when delta >= 0.5 voxel, i.e. dim > 1000: rare uniform branch).
 // 8 + 3*4 = 20 LDS adds per sample instead of 8 per tap.
-template <bool WIDE, bool PRE = false>
+template <int ACC>
 __device__ __forceinline__ void scatter_sample(unsigned long long *dbox, const TapCoords &t, bool valid, int cbase_i,
                                                float I_bar, const float (&gq)[3], const FixScale &fs) {
     const float X[2] = {1.0f - t.fx, t.fx}, Y[2] = {1.0f - t.fy, t.fy}, Z[2] = {1.0f - t.fz, t.fz};
@@ -479,45 +488,53 @@ __device__ __forceinline__ void scatter_sample(unsigned long long *dbox, const T
     }
     {   // x: outside plane l0+2 (coefficient cx[3]) or l0-1 (cx[0])
         const bool hi = cx[3] != 0.0f, lo = cx[0] != 0.0f;
-        if (valid && (hi || lo)) scatter4<WIDE, BOX_SY, 1, PRE>(dbox, cbase_i + (hi ? 2 * BOX_SX : -BOX_SX), hi ? cx[3] : cx[0], YZ, fs);
-        if (__any(valid && hi && lo)) { if (valid && hi && lo) scatter4<WIDE, BOX_SY, 1, PRE>(dbox, cbase_i - BOX_SX, cx[0], YZ, fs); }
+        if (valid && (hi || lo)) scatter4<ACC, BOX_SY, 1>(dbox, cbase_i + (hi ? 2 * BOX_SX : -BOX_SX), hi ? cx[3] : cx[0], YZ, fs);
+        if (__any(valid && hi && lo)) { if (valid && hi && lo) scatter4<ACC, BOX_SY, 1>(dbox, cbase_i - BOX_SX, cx[0], YZ, fs); }
     }
     {   // y
         const bool hi = cy[3] != 0.0f, lo = cy[0] != 0.0f;
-        if (valid && (hi || lo)) scatter4<WIDE, BOX_SX, 1, PRE>(dbox, cbase_i + (hi ? 2 * BOX_SY : -BOX_SY), hi ? cy[3] : cy[0], XZ, fs);
-        if (__any(valid && hi && lo)) { if (valid && hi && lo) scatter4<WIDE, BOX_SX, 1, PRE>(dbox, cbase_i - BOX_SY, cy[0], XZ, fs); }
+        if (valid && (hi || lo)) scatter4<ACC, BOX_SX, 1>(dbox, cbase_i + (hi ? 2 * BOX_SY : -BOX_SY), hi ? cy[3] : cy[0], XZ, fs);
+        if (__any(valid && hi && lo)) { if (valid && hi && lo) scatter4<ACC, BOX_SX, 1>(dbox, cbase_i - BOX_SY, cy[0], XZ, fs); }
     }
     {   // z
         const bool hi = cz[3] != 0.0f, lo = cz[0] != 0.0f;
-        if (valid && (hi || lo)) scatter4<WIDE, BOX_SX, BOX_SY, PRE>(dbox, cbase_i + (hi ? 2 : -1), hi ? cz[3] : cz[0], XY, fs);
-        if (__any(valid && hi && lo)) { if (valid && hi && lo) scatter4<WIDE, BOX_SX, BOX_SY, PRE>(dbox, cbase_i - 1, cz[0], XY, fs); }
+        if (valid && (hi || lo)) scatter4<ACC, BOX_SX, BOX_SY>(dbox, cbase_i + (hi ? 2 : -1), hi ? cz[3] : cz[0], XY, fs);
+        if (__any(valid && hi && lo)) { if (valid && hi && lo) scatter4<ACC, BOX_SX, BOX_SY>(dbox, cbase_i - 1, cz[0], XY, fs); }
     }
     // (Consecutive lanes are consecutive samples of a ray, ~3.5 per cell: these eight adds collide in the LDS, ~7 cycles
     // per duplicate address. Summing the runs across lanes first was tried twice: +1.0 ms of VALU for 0.4 ms of LDS.)
-    if (valid) scatter8<WIDE, PRE>(dbox, cbase_i, acc, fs);
+    if (valid) scatter8<ACC>(dbox, cbase_i, acc, fs);
 }
 
-// Backward: the largest |grad_out| component over the brick's candidate pixels, per thread (the caller reduces it over
-// the workgroup). Pixels with a non-finite component or above the robust cap do not count (their contributions take the
-// exact clamped path). All loads of a thread are independent and issued together with the box staging.
+// Backward: the largest and the smallest non-zero |grad_out| (per pixel: its largest component) over the brick's
+// candidate pixels whose rays hit the volume, per thread (the caller reduces them over the workgroup). Pixels with a
+// non-finite component or above the robust cap do not count (their contributions take the exact clamped path). All loads
+// of a thread are independent and issued together with the box staging.
 template <typename VT, int FNT>
-__device__ __forceinline__ float cand_grad_max(const BrickParams<VT> &P, const BrickCtx &c, int view, int ncand) {
+__device__ __forceinline__ void cand_grad_range(const BrickParams<VT> &P, const BrickCtx &c, int view, int ncand, float &gmax,
+                                                float &gmin) {
     const float cap = __uint_as_float(P.stats[ST_GCAP]);
-    const float4 *go4 = reinterpret_cast<const float4 *>(P.grad_out) + (size_t)view * P.W * P.H;
+    const size_t vb = (size_t)view * P.W * P.H;
+    const float4 *go4 = reinterpret_cast<const float4 *>(P.grad_out) + vb;
     const int nj = c.j1 - c.j0 + 1;
     const float rnj = __builtin_amdgcn_rcpf((float)nj);
-    float gm = 0.0f;
+    gmax = 0.0f; gmin = 3.0e38f;
     for (int cc = threadIdx.x; cc < ncand; cc += FNT) {
         const int qi = (ncand < (1 << 21)) ? (int)(((float)cc + 0.5f) * rnj) : cc / nj;  // see cand_load
-        const float4 g = go4[(c.i0 + qi) * P.H + c.j0 + (cc - qi * nj)];
+        const int pl = (c.i0 + qi) * P.H + c.j0 + (cc - qi * nj);
+        const float4 g = go4[pl];
+        const int n = P.nsamp[vb + pl];
         const float a = fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w)));
         const bool bad = !(fabsf(g.x) <= cap) || !(fabsf(g.y) <= cap) || !(fabsf(g.z) <= cap) || !(fabsf(g.w) <= cap);
-        gm = fmaxf(gm, bad ? 0.0f : a);
+        if (!bad && n > 0 && a > 0.0f) { gmax = fmaxf(gmax, a); gmin = fminf(gmin, a); }
     }
-    return gm;
 }
 __device__ __forceinline__ float wave_max_f(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_min_f(float v) {
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
     return v;
 }
 
@@ -566,32 +583,32 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
         if (!__syncthreads_or(nE0 > 0) && ncand <= EC) return;  // uniform: no wave found a segment
         box_issue<VT, FNT>(P, vol, c, P.tf + view * P.tf_vs, stage);
     } else {
-#if !DR_ACC_F64
-        float gm = 0.0f;
-        if (BWD) gm = cand_grad_max<VT, FNT>(P, c, view, ncand);            // upstream gradients of the candidates,
-#endif
+        float gm = 0.0f, gn = 3.0e38f;
+        if (BWD && WANT_VOL) cand_grad_range<VT, FNT>(P, c, view, ncand, gm, gn);  // upstream gradients of the candidates,
         box_issue<VT, FNT>(P, vol, c, P.tf + view * P.tf_vs, stage);      // voxel box + TF: in flight ...
         if (BWD) {
             if (WANT_VOL) for (int k = threadIdx.x; k < BOX_LDS; k += FNT) L.dbox[k] = 0ull;
             if (WANT_TF) for (int k = threadIdx.x; k < 4 * P.R; k += FNT) L.dtf[k] = 0ull;
-#if !DR_ACC_F64
-            gm = wave_max_f(gm);
-            if ((threadIdx.x & 63) == 0) L.gmax[threadIdx.x >> 6] = gm;
-#endif
+            if (WANT_VOL) {
+                gm = wave_max_f(gm); gn = wave_min_f(gn);
+                if ((threadIdx.x & 63) == 0) { L.gmax[threadIdx.x >> 6] = gm; L.gmax[8 + (threadIdx.x >> 6)] = gn; }
+            }
         }
         flat_build_entries<VT, MODE, BWD, FNT, ALPHA, KS>(P, c, cam, view, cd, seg_base, L, nE0, M0);  // ... while the segments are listed
     }
     box_commit<VT, FNT>(P, vol, c, P.tf + view * P.tf_vs, stage, L);
     __syncthreads();
-    if (BWD) {
-        float gm = 0.0f;
-#if !DR_ACC_F64
-        // this brick's fixed-point scale (every thread derives the same one)
+    bool acc64 = false;  // brick-uniform: d_volume accumulates in double
+    if (BWD && WANT_VOL) {
+        // this brick's fixed-point scale, or doubles if its candidates' |grad_out| span more than 2^DR_MIXED_BITS
+        // (every thread derives the same answer)
+        float gm = 0.0f, gn = 3.0e38f;
 #pragma unroll
-        for (int k = 0; k < FNW; ++k) gm = fmaxf(gm, L.gmax[k]);
+        for (int k = 0; k < FNW; ++k) { gm = fmaxf(gm, L.gmax[k]); gn = fminf(gn, L.gmax[8 + k]); }
+        acc64 = __builtin_amdgcn_readfirstlane((int)(gn * (float)(1 << DR_MIXED_BITS) < gm)) != 0;
         if (!(gm > 0.0f)) gm = __uint_as_float(P.stats[ST_GCAP]);  // only outliers (or zeros) in this brick
-#endif
         fs = make_fix_scale(gm);
+        if (acc64 && threadIdx.x == 0) atomicAdd(&P.stats[ST_F64_BRICKS], 1u);
     }
 #if DR_PHASE_TIMING
     const long long tk1 = clock64();
@@ -823,22 +840,22 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
                     // sum of magnitudes (>= the largest one; full-rate adds, and a NaN propagates into the test)
                     const float vmax = ((fabsf(v8[0]) + fabsf(v8[1])) + (fabsf(v8[2]) + fabsf(v8[3]))) +
                                        ((fabsf(v8[4]) + fabsf(v8[5])) + (fabsf(v8[6]) + fabsf(v8[7])));
-                    // run totals normally fit the 32-bit addend; NaN or a huge total takes the exact clamped path
-                    if (__any(emit && !fix_fits(vmax, fs))) {
+                    // d_tf accumulates in double; a NaN or an absurd run total takes the sanitising path
+                    if (__any(emit && !(vmax <= ACC_LIM))) {
                         if (emit) {
                             unsigned long long *d0 = L.dtf + 4 * sm.lo, *d1 = L.dtf + 4 * sm.hi;
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
-                                fix_add(d0 + q, fix_clamp(v8[q], fs), fs);
-                                fix_add(d1 + q, fix_clamp(v8[4 + q], fs), fs);
+                                acc_add_f64(d0 + q, acc_sanitise(v8[q]));
+                                acc_add_f64(d1 + q, acc_sanitise(v8[4 + q]));
                             }
                         }
                     } else if (emit) {
                         unsigned long long *d0 = L.dtf + 4 * sm.lo, *d1 = L.dtf + 4 * sm.hi;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            fix_add_t<false>(d0 + q, v8[q], fs);
-                            fix_add_t<false>(d1 + q, v8[4 + q], fs);
+                            acc_add_f64(d0 + q, v8[q]);
+                            acc_add_f64(d1 + q, v8[4 + q]);
                         }
                     }
                 }
@@ -858,14 +875,20 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
                         I_bar = intensity_adjoint(sm, L.tf[sm.lo], L.tf[sm.hi], ad, P.tf_len);
                         if (!sm.flat) { gq[0] = ad.gx; gq[1] = ad.gy; gq[2] = ad.gz; }
                     }
-                    // (a NaN or an overflow makes the test fail: the exact path below clamps, the common one need not)
+                    // (a NaN or an overflow makes the magnitude test fail: the exact path clamps, the common one need not)
                     const float bound = fabsf(I_bar) + (fabsf(gq[0]) + fabsf(gq[1]) + fabsf(gq[2]));
-                    if (__any(!fix_fits(bound, fs))) {
+                    if (acc64) {  // brick-uniform
+                        if (__any(!(bound <= ACC_LIM))) {
+                            I_bar = acc_sanitise(I_bar);
+                            gq[0] = acc_sanitise(gq[0]); gq[1] = acc_sanitise(gq[1]); gq[2] = acc_sanitise(gq[2]);
+                        }
+                        scatter_sample<ACC_F64>(L.dbox, t, valid, cbase_i, I_bar, gq, fs);
+                    } else if (__any(!fix_fits(bound, fs))) {
                         const float gc[3] = {fix_clamp(gq[0], fs), fix_clamp(gq[1], fs), fix_clamp(gq[2], fs)};
-                        scatter_sample<true>(L.dbox, t, valid, cbase_i, fix_clamp(I_bar, fs), gc, fs);
+                        scatter_sample<ACC_FIX_WIDE>(L.dbox, t, valid, cbase_i, fix_clamp(I_bar, fs), gc, fs);
                     } else {  // common case: scale the four adjoints once instead of the twenty addends
                         const float gs[3] = {gq[0] * fs.lo, gq[1] * fs.lo, gq[2] * fs.lo};
-                        scatter_sample<false, true>(L.dbox, t, valid, cbase_i, I_bar * fs.lo, gs, fs);
+                        scatter_sample<ACC_FIX>(L.dbox, t, valid, cbase_i, I_bar * fs.lo, gs, fs);
                     }
                 }
             }
@@ -905,7 +928,7 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
                 box_row(r, b, d);
                 const unsigned long long raw = L.dbox[a * w.la + b * w.lb + d * w.ld];
                 if (raw != 0ull)  // in range whenever raw != 0
-                    unsafeAtomicAdd(base + (a * w.ga + b * w.gb + d * w.gd), fix_to_float(raw, fs));
+                    unsafeAtomicAdd(base + (a * w.ga + b * w.gb + d * w.gd), acc64 ? acc_f64_to_float(raw) : fix_to_float(raw, fs));
             }
         }
     }
@@ -913,7 +936,7 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
         float *dtf = P.d_tf + view * P.dtf_vs * 4;
         for (int k = threadIdx.x; k < 4 * P.R; k += FNT) {
             const unsigned long long raw = L.dtf[k];
-            if (raw != 0ull) unsafeAtomicAdd(dtf + k, fix_to_float(raw, fs));
+            if (raw != 0ull) unsafeAtomicAdd(dtf + k, acc_f64_to_float(raw));
         }
     }
 #if DR_PHASE_TIMING
@@ -1026,7 +1049,6 @@ static int flat_bwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     const size_t lds = flat_lds_bytes<true>(a.R, wv, wt);
     const dim3 grid1(g.NBx * g.NBy * g.NBz, a.n_views);
     hipError_t e = hipSuccess;
-#if !DR_ACC_F64
     // robust cap on |grad_out| (exponent histogram -> 99th percentile x 2^12), then the brick records
     e = hipMemsetAsync(w.stats + ST_HIST, 0, 256 * 4, stream);
     if (e != hipSuccess) return (int)e;
@@ -1034,7 +1056,6 @@ static int flat_bwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     const size_t nb = (ng + 256 * 4 - 1) / (256 * 4);
     hipLaunchKernelGGL(gradstat_kernel, dim3((unsigned)(nb > 1024 ? 1024 : nb)), dim3(256), 0, stream, a.grad_out, ng,
                        w.stats + ST_HIST);
-#endif
     hipLaunchKernelGGL(brick_ctx_kernel<VT>, dim3((grid1.x + 255) / 256, a.n_views), dim3(256), 0, stream, P, w.ctx, (int)grid1.x, 0, 0.0f);
     if (wv && wt) {
         if ((e = allow_lds(brick_flat_kernel<VT, DR_MODE_DIFF, true, true, true>, lds)) != hipSuccess) return (int)e;

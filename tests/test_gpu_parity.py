@@ -610,8 +610,8 @@ def _support(O, vol_h, tf_h, cam_h, rays, WH, mask):
 
 def test_backward_dynamic_range_of_upstream_gradient(oracle, F):
     """Half the image carries an upstream gradient 1e-5 times the other half's. The voxels that only the small-gradient
-    rays touch must still come out right ELEMENTWISE (the LDS accumulators are doubles; round 1's fixed point with one
-    global scale flushed these voxels to zero)."""
+    rays touch must still come out right ELEMENTWISE. Round 1's fixed point with ONE global scale flushed them to zero;
+    now every brick has its own scale, and bricks whose pixel footprint holds both kinds of rays accumulate in double."""
     vol_h, tf_h, cam_h = scene(oracle, N=48, R=32, alpha=0.03, cam_i=0.3)
     tf_h[:, 3] = np.linspace(0.01, 0.08, 32)
     WH = (64, 64)
@@ -639,6 +639,9 @@ def test_backward_dynamic_range_of_upstream_gradient(oracle, F):
     bound = 1e-4 * ref + 2e-6 * np.abs(dvs).max()
     bad = err > bound
     assert not bad.any(), (int(bad.sum()), int(bad.size), float((err / bound).max()))
+    if F.variant == 0:
+        from differender_amd.functional import workspace_stats
+        assert int(workspace_stats(F._ws)[4]) > 0, "the bricks along the boundary must have switched to double accumulators"
     # d_tf: every texel sees both halves; the small half's share is 1e-5 of it and must at least not disturb the sum
     assert np.abs(dt - dt0).max() <= 1e-4 * np.abs(dt0).max()
 
