@@ -335,9 +335,11 @@ __device__ __forceinline__ int cvt_rn_i32(float x) {
     asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(q) : "v"(x));
     return q;
 }
-// Exact conversion (any magnitude inside the clamp): split x*2^(shift-32) into integer and fraction.
+// Wide conversion (any magnitude inside the clamp): split x*2^(shift-32) into integer and fraction.
 __device__ __forceinline__ void fix_add_wide(unsigned long long *p, float x, const FixScale &f) {
-    const float t = x * f.hi;
+    // + 2^-33 = half a unit of 2^-shift: the truncation below then rounds to nearest instead of toward -infinity (where
+    // |t| >= 2^-8 the sum is t itself: such values have no bits below 2^-shift to begin with)
+    const float t = fmaf(x, f.hi, 1.16415321826934814453125e-10f);
     const float hf = floorf(t);
     const unsigned int lo = (unsigned int)((t - hf) * 4294967296.0f);  // fraction in [0,1): exact product
     const unsigned long long v = ((unsigned long long)(unsigned int)(int)hf << 32) | lo;
