@@ -672,8 +672,10 @@ def test_backward_with_non_finite_upstream_gradient(oracle, F):
         # components of the NaN pixel that are finite still contribute; compare where that ray has no say
         sv, st = _support(oracle, vol_h, tf_h, cam_h, rays, WH, bad)
         assert np.abs(dv.cpu().numpy() - dv_o)[~sv].max() <= 1e-4 * np.abs(dv_o).max()
-        elem = np.abs(dv.cpu().numpy() - dv_o)[~sv] <= 1e-4 * np.abs(dv_o)[~sv] + 1e-6 * np.abs(dv_o).max()
-        assert elem.all()
+        # elementwise: relative to the voxel's own value plus 5e-6 of the tensor's maximum (the f32 oracle itself is ~5e-4
+        # of the maximum away from its f64 twin on this opaque scene: tools/elem_probe.py)
+        d = np.abs(dv.cpu().numpy() - dv_o)[~sv]
+        assert (d <= 1e-4 * np.abs(dv_o)[~sv] + 5e-6 * np.abs(dv_o).max()).all(), float(d.max() / np.abs(dv_o).max())
     # 2) NaN, inf and -3e30 together
     g_bad = g.copy()
     g_bad[0, 3, 4, 0] = np.nan; g_bad[0, 10, 11, 3] = np.inf; g_bad[0, 17, 5, 1] = -3e30
@@ -683,7 +685,7 @@ def test_backward_with_non_finite_upstream_gradient(oracle, F):
         sv, st = _support(oracle, vol_h, tf_h, cam_h, rays, WH, bad)
         assert (~sv & (dv_o != 0)).sum() > 1000
         d = np.abs(dv.cpu().numpy() - dv_o)[~sv]
-        assert (d <= 1e-4 * np.abs(dv_o)[~sv] + 1e-6 * np.abs(dv_o).max()).all(), float(d.max() / np.abs(dv_o).max())
+        assert (d <= 1e-4 * np.abs(dv_o)[~sv] + 5e-6 * np.abs(dv_o).max()).all(), float(d.max() / np.abs(dv_o).max())
     # 3) the same call with the three pixels zeroed matches the oracle in the usual sense
     dv2, dt2 = F.march_bwd(vol, tf, cam, e, x, r, n, 4096, 1.0, T(g_ok), out)
     ok, err = grad_close(dv2.cpu().numpy(), dv_o)
