@@ -1,0 +1,82 @@
+"""The hand-derived adjoint against an independently derived one: tests/golden/autograd_*.npz hold gradients that
+torch.autograd computed through a float64 transliteration of the reference's raycast (tests/golden/make_autograd_golden.py)
+-- no hand derivation involved. The f64 oracle must match them on EVERY element to 1e-9, the HIP path within the parity
+tolerance."""
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = sorted(glob.glob(os.path.join(HERE, "golden", "autograd_*.npz")))
+IDS = [os.path.basename(p)[len("autograd_"):-4] for p in GOLDEN]
+
+
+def test_fixtures_are_there():
+    assert len(GOLDEN) == 4
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=IDS)
+def test_oracle_f64_matches_autograd_on_every_element(oracle, path):
+    d = np.load(path)
+    ok = d["n"] != 1                                           # single-sample rays are 0/0 in the reference (H6): left out
+    assert np.abs(d["grad_out"][~ok]).max(initial=0.0) == 0.0
+    S, sr = int(d["max_samples"]), float(d["sr"])
+    rgba, steps = oracle.march_fwd(d["vol"], d["tf"], d["cam"], d["entry"], d["exit"], d["rays"], d["n"], S, sr, 0)
+    assert np.array_equal(steps[ok], d["steps"][ok])
+    assert np.abs(rgba - d["rgba"])[ok].max() <= 1e-12
+    dv, dt = oracle.march_bwd(d["vol"], d["tf"], d["cam"], d["entry"], d["exit"], d["rays"], d["n"], S, sr, d["grad_out"])
+    for got, ref, name in ((dv, d["dvol"], "d_vol"), (dt, d["dtf"], "d_tf")):
+        scale = np.abs(ref).max()
+        err = np.abs(got - ref)
+        assert (err <= 1e-9 * np.abs(ref) + 1e-9 * scale).all(), (name, float(err.max() / scale))
+        assert (got != 0).sum() == (ref != 0).sum(), name      # same support: no voxel gained or lost a contribution
+    # the cases must exercise what they claim
+    if "ert" in path:
+        assert (d["steps"] < d["n"]).sum() > 20
+    if "clip" in path:
+        assert int(d["steps"].max()) == S and int(d["n"].max()) > S
+
+
+def test_transliteration_reproduces_its_fixture():
+    """Guards the generating script against rot: re-running it for one case gives the stored vectors."""
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_autograd_golden as G
+    d = np.load(os.path.join(HERE, "golden", "autograd_a_sr1.npz"))
+    inp = G.make_inputs("a_sr1")
+    for k in ("vol", "tf", "entry", "exit", "rays", "grad_out"):
+        assert np.array_equal(inp[k], d[k]), k
+    res = G.run_case(inp)
+    assert np.abs(res["dvol"] - d["dvol"]).max() <= 1e-12 * np.abs(d["dvol"]).max()
+    assert np.abs(res["dtf"] - d["dtf"]).max() <= 1e-12 * np.abs(d["dtf"]).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [0, 1], ids=["flat", "baseline"])
+@pytest.mark.parametrize("path", GOLDEN, ids=IDS)
+def test_hip_matches_autograd(hiplib, path, variant):
+    import torch
+    from differender_amd import functional as F
+    d = np.load(path)
+    dev = torch.device("cuda:0")
+    T = lambda a, dt=np.float32: torch.from_numpy(np.ascontiguousarray(a.astype(dt))).to(dev)
+    S, sr = int(d["max_samples"]), float(d["sr"])
+    vol, tf, cam = T(d["vol"]), T(d["tf"]), T(d["cam"][None])
+    e, x, r, n = T(d["entry"][None]), T(d["exit"][None]), T(d["rays"][None]), T(d["n"][None], np.int32)
+    ws = F.alloc_workspace(1, d["n"].shape, d["vol"].shape, d["tf"].shape[0], dev) if variant == 0 else None
+    out, steps = F.march_fwd(vol, tf, cam, e, x, r, n, S, sr, variant=variant, workspace=ws)
+    ok = d["n"] != 1
+    same = (steps[0].cpu().numpy() == d["steps"]) | ~ok      # f32 inputs may move a termination decision by one sample
+    assert same.mean() > 0.98
+    assert np.abs(out[0].cpu().numpy() - d["rgba"]).max(-1)[same & ok].max() <= 1e-5
+    g = d["grad_out"].copy(); g[~same] = 0.0
+    dv, dt = F.march_bwd(vol, tf, cam, e, x, r, n, S, sr, T(g[None]), out, variant=variant, workspace=ws)
+    if same.all():
+        dv_ref, dt_ref = d["dvol"], d["dtf"]
+    else:  # the rays that decided differently are taken out on both sides (their gradient is zeroed)
+        from oracle import oracle as O
+        dv_ref, dt_ref = O.march_bwd(d["vol"], d["tf"], d["cam"], d["entry"], d["exit"], d["rays"], d["n"], S, sr, g)
+    assert np.abs(dv.cpu().numpy() - dv_ref).max() <= 1e-4 * np.abs(dv_ref).max()
+    assert np.abs(dt.cpu().numpy() - dt_ref).max() <= 1e-4 * np.abs(dt_ref).max()
