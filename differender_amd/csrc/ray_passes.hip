@@ -188,71 +188,97 @@ __global__ __launch_bounds__(256) void ray_alpha_kernel(BrickParams<VT> P) {
     if (P.pp_first) P.ws_steps[p] = nmarch;  // alive (so far): every planned sample is live
 }
 
-// P2b: the rays whose accumulated alpha crosses 0.99 (ws_steps == -1, crossing segment and alpha before it parked in
-// the not-yet-written output buffer). One WAVE per ray: 64 consecutive samples per pass -- positions, centre taps (the
-// lanes read neighbouring voxels) and TF lookups in parallel, then the exact sequential recurrence
-// A <- fma(1 - A, op_s, A) of VR.py:318-349 over the 64 opacities (a one-thread-per-ray loop spent ~370 dependent
-// global gathers per ray at sampling rate 8). Passes whose total transmittance keeps alpha clear of the threshold are
-// skipped with the (re-associated) wave product; the pass that can cross is evaluated in F2's sequential arithmetic.
+// P2b: the rays whose accumulated alpha crosses 0.99 (ws_steps == -1; the first sample of the crossing segment and the
+// alpha before it are parked in the not-yet-written output buffer). One WAVE per ray, 64 consecutive samples per pass:
+// positions, centre taps (the lanes read neighbouring voxels) and TF lookups (LDS) in parallel, then
+//   round 0  an inclusive wave scan of the transmittances (DPP, 6 steps) gives the alpha after every sample of the pass,
+//            re-associated: ~1e-7 off the sequential value, like the parked start. The first lane at or above 0.99 is the
+//            terminating sample -- unless the alpha there, or the one before it, lies within 2e-6 of the threshold:
+//   round 1  (0.4-3 % of the terminating rays) the exact sequential recurrence A <- fma(1 - A, op_s, A) of VR.py:267-302
+//            from the ray's FIRST sample, 64 opacities per pass walked with v_readlane: the decision is then the oracle's,
+//            bit for bit (deviation D3 of DESIGN.md does not arise on this path).
+// (Round 1 of the build walked every crossing segment with the v_readlane loop, ~35 cycles per sample with one lane's
+// worth of work: 2.7 ms of the reference-style sr-8 ground-truth render; a one-lane-per-ray walk is worse still, its
+// dependent gathers take ~1 us per step.)
+__device__ __forceinline__ float wave_incl_prod(float v) {  // inclusive product over the lanes 0..lane
+    { const float o = __int_as_float(__builtin_amdgcn_update_dpp(0x3f800000, __float_as_int(v), 0x111, 0xf, 0xf, false)); v *= o; }
+    { const float o = __int_as_float(__builtin_amdgcn_update_dpp(0x3f800000, __float_as_int(v), 0x112, 0xf, 0xf, false)); v *= o; }
+    { const float o = __int_as_float(__builtin_amdgcn_update_dpp(0x3f800000, __float_as_int(v), 0x114, 0xf, 0xf, false)); v *= o; }
+    { const float o = __int_as_float(__builtin_amdgcn_update_dpp(0x3f800000, __float_as_int(v), 0x118, 0xf, 0xf, false)); v *= o; }
+    { const float o = __int_as_float(__builtin_amdgcn_update_dpp(0x3f800000, __float_as_int(v), 0x142, 0xa, 0xf, false)); v *= o; }  // row_bcast:15 -> rows 1, 3
+    { const float o = __int_as_float(__builtin_amdgcn_update_dpp(0x3f800000, __float_as_int(v), 0x143, 0xc, 0xf, false)); v *= o; }  // row_bcast:31 -> rows 2, 3
+    return v;
+}
 template <typename VT, int MODE>
 __global__ __launch_bounds__(256) void ray_cross_kernel(BrickParams<VT> P) {
+    extern __shared__ __attribute__((aligned(16))) float4 lds_tf[];
     const int view = blockIdx.y;
-    if (P.vflags[view] == 0u) return;  // uniform
+    if (P.vflags[view] == 0u) return;  // uniform: no ray of this view can terminate
+    const float4 *tfg = P.tf + view * P.tf_vs;
+    for (int k = threadIdx.x; k < P.R; k += 256) lds_tf[k] = tfg[k];
+    __syncthreads();
     const int NP = P.W * P.H;
     const int lane = threadIdx.x & 63;
-    // waves walk over the rays (a bounded grid: gated off, the launch costs a few thousand workgroup exits)
-    for (int pl = blockIdx.x * 4 + (threadIdx.x >> 6); pl < NP; pl += 4 * (int)gridDim.x) {  // wave-uniform
-    const size_t p = (size_t)view * NP + pl;
-    if (P.ws_steps[p] != -1) continue;  // wave-uniform: no crossing to resolve
-    const float4 parked = reinterpret_cast<const float4 *>(P.out)[p];
-    RayGeom rg;
-    load_ray(P.entry, P.exit_, P.rays, P.nsamp, p, rg);
-    const int nmarch = (MODE == DR_MODE_DIFF && rg.n > P.S) ? P.S : rg.n;
     VolView<VT> vol = P.vol;
     vol.p += view * P.vol_vs;
-    const float4 *tfg = P.tf + view * P.tf_vs;
     const f3 cam = make_f3(P.cam[3 * view], P.cam[3 * view + 1], P.cam[3 * view + 2]);
-    // Round 1 starts at the crossing segment with the alpha the (re-associated) partial composites give, ~1e-7 off
-    // the sequential value. If the decision it reaches is closer to the threshold than that error could matter
-    // (2e-6), round 2 repeats the recurrence from the first sample in exact sequential arithmetic -- the decision
-    // is then the oracle's, bit for bit (deviation D3 of DESIGN.md does not arise on this path).
-    float A = parked.x;
-    int s = __float_as_int(parked.y);
-    for (int round = 0; round < 2; ++round) {
-        float A_prev = A;
-        bool done = false;
-        for (int base = s; base < nmarch && !done; base += 64) {
-            const int sl = base + lane;
-            float op = 0.0f;
-            if (sl < nmarch) {
-                Sample sm;
-                sample_pos(rg, cam.x, cam.y, cam.z, sl, sm.px, sm.py, sm.pz);
-                classify(vol, tfg, P.R, P.tf_len, P.inv_sr, sm);
-                op = (MODE == DR_MODE_NONDIFF && !(sm.a > 1e-3f)) ? 0.0f : sm.op;  // skipped sample: A unchanged (fma(T, 0, A) == A)
+    // waves walk over the rays (a bounded grid: gated off, the launch costs a few thousand workgroup exits)
+    for (int pl = blockIdx.x * 4 + (threadIdx.x >> 6); pl < NP; pl += 4 * (int)gridDim.x) {  // wave-uniform
+        const size_t p = (size_t)view * NP + pl;
+        if (P.ws_steps[p] != -1) continue;  // wave-uniform: no crossing to resolve
+        const float4 parked = reinterpret_cast<const float4 *>(P.out)[p];
+        RayGeom rg;
+        load_ray(P.entry, P.exit_, P.rays, P.nsamp, p, rg);
+        const int nmarch = (MODE == DR_MODE_DIFF && rg.n > P.S) ? P.S : rg.n;
+        float A = parked.x;
+        int s = __float_as_int(parked.y);
+        for (int round = 0; round < 2; ++round) {
+            float A_prev = A;
+            bool done = false;
+            for (int base = s; base < nmarch && !done; base += 64) {  // uniform
+                const int sl = base + lane;
+                float op = 0.0f;
+                if (sl < nmarch) {
+                    Sample sm;
+                    sample_pos(rg, cam.x, cam.y, cam.z, sl, sm.px, sm.py, sm.pz);
+                    classify(vol, lds_tf, P.R, P.tf_len, P.inv_sr, sm);
+                    op = (MODE == DR_MODE_NONDIFF && !(sm.a > 1e-3f)) ? 0.0f : sm.op;  // skipped sample: A unchanged (fma(T, 0, A) == A)
+                }
+                const int cnt = min(64, nmarch - base);
+                if (round == 0) {
+                    if (!(A < 0.99f)) { done = true; break; }  // (the parked alpha itself may sit above the threshold)
+                    // alpha after every sample of the pass: A_i = A + (1 - A) (1 - prod_{j <= i} (1 - op_j)); inactive lanes: op = 0
+                    const float Ai = fmaf(1.0f - A, 1.0f - wave_incl_prod(1.0f - op), A);
+                    const unsigned long long over = __ballot(!(Ai < 0.99f));
+                    if (over == 0ull) { A_prev = A = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Ai), 63)); s += cnt; continue; }
+                    const int ix = __ffsll((long long)over) - 1;  // first sample at or above the threshold: the last live one
+                    if (ix > 0) A_prev = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Ai), ix - 1));
+                    A = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Ai), ix));
+                    s += ix + 1;
+                    done = true;
+                } else {
+                    for (int i = 0; i < cnt; ++i) {  // uniform
+                        if (!(A < 0.99f)) { done = true; break; }
+                        const float opi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(op), i));
+                        A_prev = A;
+                        A = fmaf(1.0f - A, opi, A);
+                        ++s;
+                    }
+                }
             }
-            const int cnt = min(64, nmarch - base);
-            if (round == 0) {
-                // Transmittance of the whole pass (wave product): if even its end stays clear of the threshold (by far
-                // more than re-association can move it) no sample of the pass terminates the ray: skip the sequential part.
-                float Tw = 1.0f - op;  // inactive lanes: op = 0
-                for (int o = 32; o > 0; o >>= 1) Tw *= __shfl_xor(Tw, o);
-                const float A_end = fmaf(1.0f - A, 1.0f - Tw, A);
-                if (A < 0.99f && A_end < 0.99f - 1e-4f) { A_prev = A = A_end; s += cnt; continue; }  // uniform
+            // decided at A (>= 0.99, or the ray ran out of samples) with A_prev (< 0.99) before it
+            const bool ambiguous = fabsf(A - 0.99f) < 2e-6f || fabsf(A_prev - 0.99f) < 2e-6f;
+#ifdef DR_CROSS_STATS
+            if (lane == 0) {  // diagnostics (tools/cross_stats.py): rays resolved, rays that needed the exact restart, samples walked
+                atomicAdd(&P.stats[ST_TIMING + 16 + round], 1u);
+                atomicAdd(reinterpret_cast<unsigned long long *>(P.stats + ST_TIMING + 20) + round,
+                          (unsigned long long)(s - (round == 0 ? __float_as_int(parked.y) : 0)));
             }
-            for (int i = 0; i < cnt; ++i) {  // uniform
-                if (!(A < 0.99f)) { done = true; break; }
-                const float opi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(op), i));
-                A_prev = A;
-                A = fmaf(1.0f - A, opi, A);
-                ++s;
-            }
+#endif
+            if (round == 1 || !ambiguous) break;  // uniform
+            A = 0.0f; s = 0;
         }
-        // decided at A (>= 0.99, or the ray ran out of samples) with A_prev (< 0.99) before it
-        const bool ambiguous = fabsf(A - 0.99f) < 2e-6f || fabsf(A_prev - 0.99f) < 2e-6f;
-        if (round == 1 || !ambiguous) break;  // uniform
-        A = 0.0f; s = 0;
-    }
-    if (lane == 0) P.ws_steps[p] = s;
+        if (lane == 0) P.ws_steps[p] = s;
     }
 }
 
@@ -291,12 +317,13 @@ static int ray_alpha_dispatch(const MarchArgs &a, hipStream_t stream, bool cross
     ws_layout(a.workspace, a.n_views, NP, g, &w);
     BrickParams<VT> P = make_brick_params<VT>(a, w);
     const dim3 grid2((NP + 255) / 256, a.n_views), grid3((NP + 3) / 4 < 8192 ? (NP + 3) / 4 : 8192, a.n_views);
+    const size_t lds3 = (size_t)a.R * 16;
     if (a.mode == DR_MODE_DIFF) {
         if (!cross) hipLaunchKernelGGL((ray_alpha_kernel<VT, DR_MODE_DIFF>), grid2, dim3(256), 0, stream, P);
-        else hipLaunchKernelGGL((ray_cross_kernel<VT, DR_MODE_DIFF>), grid3, dim3(256), 0, stream, P);
+        else hipLaunchKernelGGL((ray_cross_kernel<VT, DR_MODE_DIFF>), grid3, dim3(256), lds3, stream, P);
     } else {
         if (!cross) hipLaunchKernelGGL((ray_alpha_kernel<VT, DR_MODE_NONDIFF>), grid2, dim3(256), 0, stream, P);
-        else hipLaunchKernelGGL((ray_cross_kernel<VT, DR_MODE_NONDIFF>), grid3, dim3(256), 0, stream, P);
+        else hipLaunchKernelGGL((ray_cross_kernel<VT, DR_MODE_NONDIFF>), grid3, dim3(256), lds3, stream, P);
     }
     return (int)hipGetLastError();
 }

@@ -73,10 +73,21 @@ def test_hip_matches_autograd(hiplib, path, variant):
     assert np.abs(out[0].cpu().numpy() - d["rgba"]).max(-1)[same & ok].max() <= 1e-5
     g = d["grad_out"].copy(); g[~same] = 0.0
     dv, dt = F.march_bwd(vol, tf, cam, e, x, r, n, S, sr, T(g[None]), out, variant=variant, workspace=ws)
+    dv, dt = dv.cpu().numpy(), dt.cpu().numpy()
+    from oracle import oracle as O
+    f4 = np.float32
+    args32 = (d["vol"].astype(f4), d["tf"].astype(f4), d["cam"].astype(f4), d["entry"].astype(f4), d["exit"].astype(f4),
+              d["rays"].astype(f4), d["n"])
+    dv32, dt32 = O.march_bwd(*args32, S, sr, g.astype(f4))
+    # parity proper: the f32 oracle on the fixture's inputs
+    assert np.abs(dv - dv32).max() <= 1e-4 * np.abs(dv32).max()
+    assert np.abs(dt - dt32).max() <= 1e-4 * np.abs(dt32).max()
+    # against the float64 autograd vectors themselves: float32 evaluation of the normal (a difference of trilinear taps
+    # 2e-3 apart, on a volume with 2 % noise) is itself ~1e-3 of the maximum away from float64 -- the f32 oracle is too
     if same.all():
         dv_ref, dt_ref = d["dvol"], d["dtf"]
     else:  # the rays that decided differently are taken out on both sides (their gradient is zeroed)
-        from oracle import oracle as O
         dv_ref, dt_ref = O.march_bwd(d["vol"], d["tf"], d["cam"], d["entry"], d["exit"], d["rays"], d["n"], S, sr, g)
-    assert np.abs(dv.cpu().numpy() - dv_ref).max() <= 1e-4 * np.abs(dv_ref).max()
-    assert np.abs(dt.cpu().numpy() - dt_ref).max() <= 1e-4 * np.abs(dt_ref).max()
+    assert np.abs(dv - dv_ref).max() <= 5e-3 * np.abs(dv_ref).max()
+    assert np.abs(dt - dt_ref).max() <= 5e-3 * np.abs(dt_ref).max()
+    assert np.abs(dv - dv_ref).max() <= 3.0 * np.abs(dv32 - dv_ref).max() + 1e-4 * np.abs(dv_ref).max()
