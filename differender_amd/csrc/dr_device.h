@@ -165,6 +165,19 @@ __device__ __forceinline__ void sample_pos_rcp(float t0, float exit_, float nm1,
     px = fmaf(t, vx, cx); py = fmaf(t, vy, cy); pz = fmaf(t, vz, cz);
 }
 
+// (1 - a)^(1/sr) of VR.py:284-285. The exponent is uniform per launch; the reference's scripts use sampling rates 1, 4, 8
+// and 16 (OPT.py:49,67, ND.py:27, Raycaster.raycast_nondiff's default 4x): for 1/sr = 2^-k the power is k correctly
+// rounded square roots (total error < 1 ulp, ~10 instructions each) instead of the ~100-instruction powf -- which at
+// sampling rate 8 was most of the arithmetic of the alpha pre-pass.
+__device__ __forceinline__ float pow_inv_sr(float base, float inv_sr) {
+    if (inv_sr == 1.0f) return base;
+    if (inv_sr == 0.5f) return sqrtf(base);
+    if (inv_sr == 0.25f) return sqrtf(sqrtf(base));
+    if (inv_sr == 0.125f) return sqrtf(sqrtf(sqrtf(base)));
+    if (inv_sr == 0.0625f) return sqrtf(sqrtf(sqrtf(sqrtf(base))));
+    return powf(base, inv_sr);
+}
+
 // VR.py:205-219 + 284-285. tf is a [R][4] table (LDS or global). sm.I must be set.
 __device__ __forceinline__ void classify_from_I(const float4 *tf, int R, float tf_len, float inv_sr, Sample &sm) {
     sm.xtf = sm.I * tf_len;
@@ -174,8 +187,7 @@ __device__ __forceinline__ void classify_from_I(const float4 *tf, int R, float t
     float4 t0 = tf[sm.lo], t1 = tf[sm.hi];
     sm.r = mixf(t0.x, t1.x, sm.fr); sm.g = mixf(t0.y, t1.y, sm.fr);
     sm.b = mixf(t0.z, t1.z, sm.fr); sm.a = mixf(t0.w, t1.w, sm.fr);
-    float base = 1.0f - sm.a;
-    sm.op = 1.0f - ((inv_sr == 1.0f) ? base : powf(base, inv_sr));
+    sm.op = 1.0f - pow_inv_sr(1.0f - sm.a, inv_sr);
 }
 template <typename VT>
 __device__ __forceinline__ void classify(const VolView<VT> &v, const float4 *tf, int R, float tf_len, float inv_sr,

@@ -245,6 +245,9 @@ __global__ __launch_bounds__(256) void ray_cross_kernel(BrickParams<VT> P) {
                     op = (MODE == DR_MODE_NONDIFF && !(sm.a > 1e-3f)) ? 0.0f : sm.op;  // skipped sample: A unchanged (fma(T, 0, A) == A)
                 }
                 const int cnt = min(64, nmarch - base);
+#ifdef DR_CROSS_ONEPASS
+                if (base > s) { done = true; break; }  // (timing experiment only)
+#endif
                 if (round == 0) {
                     if (!(A < 0.99f)) { done = true; break; }  // (the parked alpha itself may sit above the threshold)
                     // alpha after every sample of the pass: A_i = A + (1 - A) (1 - prod_{j <= i} (1 - op_j)); inactive lanes: op = 0
@@ -276,6 +279,9 @@ __global__ __launch_bounds__(256) void ray_cross_kernel(BrickParams<VT> P) {
             }
 #endif
             if (round == 1 || !ambiguous) break;  // uniform
+#ifdef DR_CROSS_NORESTART
+            break;  // (timing experiment only: wrong decisions for ambiguous rays)
+#endif
             A = 0.0f; s = 0;
         }
         if (lane == 0) P.ws_steps[p] = s;
