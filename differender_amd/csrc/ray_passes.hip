@@ -222,67 +222,91 @@ __global__ __launch_bounds__(256) void ray_cross_kernel(BrickParams<VT> P) {
     VolView<VT> vol = P.vol;
     vol.p += view * P.vol_vs;
     const f3 cam = make_f3(P.cam[3 * view], P.cam[3 * view + 1], P.cam[3 * view + 2]);
-    // waves walk over the rays (a bounded grid: gated off, the launch costs a few thousand workgroup exits)
+    // one ray per wave; everything the wave may need is requested at once (the flag decides afterwards)
     for (int pl = blockIdx.x * 4 + (threadIdx.x >> 6); pl < NP; pl += 4 * (int)gridDim.x) {  // wave-uniform
         const size_t p = (size_t)view * NP + pl;
-        if (P.ws_steps[p] != -1) continue;  // wave-uniform: no crossing to resolve
+        const int flag = P.ws_steps[p];
         const float4 parked = reinterpret_cast<const float4 *>(P.out)[p];
         RayGeom rg;
         load_ray(P.entry, P.exit_, P.rays, P.nsamp, p, rg);
+        if (flag != -1) continue;  // wave-uniform: no crossing to resolve
         const int nmarch = (MODE == DR_MODE_DIFF && rg.n > P.S) ? P.S : rg.n;
-        float A = parked.x;
+        // opacity of sample sl (0 beyond the ray's end; a skipped nondiff sample leaves A unchanged: fma(T, 0, A) == A)
+        auto opacity = [&](int sl) -> float {
+            if (sl >= nmarch) return 0.0f;
+            Sample sm;
+            sample_pos(rg, cam.x, cam.y, cam.z, sl, sm.px, sm.py, sm.pz);
+            classify(vol, lds_tf, P.R, P.tf_len, P.inv_sr, sm);
+            return (MODE == DR_MODE_NONDIFF && !(sm.a > 1e-3f)) ? 0.0f : sm.op;
+        };
+        float A = parked.x, A_prev = A;
         int s = __float_as_int(parked.y);
-        for (int round = 0; round < 2; ++round) {
-            float A_prev = A;
-            bool done = false;
-            for (int base = s; base < nmarch && !done; base += 64) {  // uniform
-                const int sl = base + lane;
-                float op = 0.0f;
-                if (sl < nmarch) {
-                    Sample sm;
-                    sample_pos(rg, cam.x, cam.y, cam.z, sl, sm.px, sm.py, sm.pz);
-                    classify(vol, lds_tf, P.R, P.tf_len, P.inv_sr, sm);
-                    op = (MODE == DR_MODE_NONDIFF && !(sm.a > 1e-3f)) ? 0.0f : sm.op;  // skipped sample: A unchanged (fma(T, 0, A) == A)
-                }
-                const int cnt = min(64, nmarch - base);
-#ifdef DR_CROSS_ONEPASS
-                if (base > s) { done = true; break; }  // (timing experiment only)
+        // ---- round 0: re-associated alphas of 64 samples per pass
+        for (int base = s; base < nmarch && A < 0.99f; base += 64) {  // uniform
+            const float op = opacity(base + lane);
+            // alpha after every sample of the pass: A_i = A + (1 - A) (1 - prod_{j <= i} (1 - op_j))
+            const float Ai = fmaf(1.0f - A, 1.0f - wave_incl_prod(1.0f - op), A);
+            const unsigned long long over = __ballot(!(Ai < 0.99f));
+            if (over == 0ull) { A_prev = A = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Ai), 63)); s += min(64, nmarch - base); continue; }
+            const int ix = __ffsll((long long)over) - 1;  // first sample at or above the threshold: the last live one
+            A_prev = ix > 0 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Ai), ix - 1)) : A;
+            A = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Ai), ix));
+            s += ix + 1;
+            break;
+        }
+        // decided at A (>= 0.99, or the ray ran out of samples) with A_prev (< 0.99) before it
+        bool ambiguous = fabsf(A - 0.99f) < 2e-6f || fabsf(A_prev - 0.99f) < 2e-6f;
+#ifdef DR_CROSS_STATS
+        if (lane == 0) {  // diagnostics (tools/cross_stats.py): rays resolved, rays that needed the exact restart, samples walked
+            atomicAdd(&P.stats[ST_TIMING + 16], 1u);
+            atomicAdd(reinterpret_cast<unsigned long long *>(P.stats + ST_TIMING + 20), (unsigned long long)(s - __float_as_int(parked.y)));
+        }
 #endif
-                if (round == 0) {
-                    if (!(A < 0.99f)) { done = true; break; }  // (the parked alpha itself may sit above the threshold)
-                    // alpha after every sample of the pass: A_i = A + (1 - A) (1 - prod_{j <= i} (1 - op_j)); inactive lanes: op = 0
-                    const float Ai = fmaf(1.0f - A, 1.0f - wave_incl_prod(1.0f - op), A);
-                    const unsigned long long over = __ballot(!(Ai < 0.99f));
-                    if (over == 0ull) { A_prev = A = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Ai), 63)); s += cnt; continue; }
-                    const int ix = __ffsll((long long)over) - 1;  // first sample at or above the threshold: the last live one
-                    if (ix > 0) A_prev = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Ai), ix - 1));
-                    A = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Ai), ix));
-                    s += ix + 1;
-                    done = true;
-                } else {
+#ifdef DR_CROSS_NORESTART
+        ambiguous = false;  // (timing experiment only: wrong decisions for ambiguous rays)
+#endif
+        if (ambiguous) {
+            // ---- round 1: the exact sequential recurrence from the first sample, 256 samples' gathers in flight per step.
+            // In sequential f32 arithmetic alpha can STAGNATE just below the threshold: once (1 - A) * op_s is under half
+            // an ulp of A, fma(1 - A, op_s, A) returns A again, for every sample whose opacity is no larger (the product
+            // is monotone in op_s). These are the rays that get here -- the re-associated alpha crossed, the sequential
+            // one does not -- and they then march to their last sample: if even the largest opacity of a pass leaves A
+            // unchanged, so do all 64.
+            A = 0.0f; s = 0;
+            bool done = false;
+            for (int base = 0; base < nmarch && !done; base += 256) {  // uniform
+                float op4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) op4[j] = opacity(base + 64 * j + lane);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int cnt = min(64, nmarch - (base + 64 * j));
+                    if (cnt <= 0 || done) continue;  // uniform
+                    float opmax = op4[j];
+                    for (int o = 32; o > 0; o >>= 1) opmax = fmaxf(opmax, __shfl_xor(opmax, o));
+                    if (A < 0.99f && fmaf(1.0f - A, opmax, A) == A) {  // uniform
+#ifdef DR_CROSS_STATS
+                        if (lane == 0) atomicAdd(&P.stats[ST_TIMING + 18], 1u);
+#endif
+                        s += cnt; continue;
+                    }
+#ifdef DR_CROSS_STATS
+                    if (lane == 0) atomicAdd(&P.stats[ST_TIMING + 19], 1u);
+#endif
                     for (int i = 0; i < cnt; ++i) {  // uniform
                         if (!(A < 0.99f)) { done = true; break; }
-                        const float opi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(op), i));
-                        A_prev = A;
+                        const float opi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(op4[j]), i));
                         A = fmaf(1.0f - A, opi, A);
                         ++s;
                     }
                 }
             }
-            // decided at A (>= 0.99, or the ray ran out of samples) with A_prev (< 0.99) before it
-            const bool ambiguous = fabsf(A - 0.99f) < 2e-6f || fabsf(A_prev - 0.99f) < 2e-6f;
 #ifdef DR_CROSS_STATS
-            if (lane == 0) {  // diagnostics (tools/cross_stats.py): rays resolved, rays that needed the exact restart, samples walked
-                atomicAdd(&P.stats[ST_TIMING + 16 + round], 1u);
-                atomicAdd(reinterpret_cast<unsigned long long *>(P.stats + ST_TIMING + 20) + round,
-                          (unsigned long long)(s - (round == 0 ? __float_as_int(parked.y) : 0)));
+            if (lane == 0) {
+                atomicAdd(&P.stats[ST_TIMING + 17], 1u);
+                atomicAdd(reinterpret_cast<unsigned long long *>(P.stats + ST_TIMING + 20) + 1, (unsigned long long)s);
             }
 #endif
-            if (round == 1 || !ambiguous) break;  // uniform
-#ifdef DR_CROSS_NORESTART
-            break;  // (timing experiment only: wrong decisions for ambiguous rays)
-#endif
-            A = 0.0f; s = 0;
         }
         if (lane == 0) P.ws_steps[p] = s;
     }
@@ -322,7 +346,7 @@ static int ray_alpha_dispatch(const MarchArgs &a, hipStream_t stream, bool cross
     Workspace w;
     ws_layout(a.workspace, a.n_views, NP, g, &w);
     BrickParams<VT> P = make_brick_params<VT>(a, w);
-    const dim3 grid2((NP + 255) / 256, a.n_views), grid3((NP + 3) / 4 < 8192 ? (NP + 3) / 4 : 8192, a.n_views);
+    const dim3 grid2((NP + 255) / 256, a.n_views), grid3((NP + 3) / 4 < 65535 ? (NP + 3) / 4 : 65535, a.n_views);
     const size_t lds3 = (size_t)a.R * 16;
     if (a.mode == DR_MODE_DIFF) {
         if (!cross) hipLaunchKernelGGL((ray_alpha_kernel<VT, DR_MODE_DIFF>), grid2, dim3(256), 0, stream, P);
