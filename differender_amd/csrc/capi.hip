@@ -24,7 +24,7 @@ const char *dr_error_string(int code) {
 
 size_t dr_workspace_bytes(int n_views, int W, int H, int VX, int VY, int VZ, int R) {
     if (n_views <= 0 || W <= 0 || H <= 0 || VX < 2 || VY < 2 || VZ < 2 || R < 1) return 0;
-    if (!brick_path_supported(VX, VY, VZ, R)) return 0;
+    if (!brick_path_supported(VX, VY, VZ, R) || !brick_image_supported(W, H, VX, VY, VZ)) return 0;
     return brick_workspace_bytes(n_views, W, H, VX, VY, VZ);
 }
 
@@ -81,7 +81,8 @@ int dr_march_fwd_rows(const void *vol, int vol_dtype, int VX, int VY, int VZ, in
     if (variant < DR_VARIANT_AUTO || variant > DR_VARIANT_BASELINE) return DR_EINVAL;
     a.mode = mode; a.out = out_rgba; a.steps = steps;
     a.fov_rad = fov_rad; a.near_plane = near_plane; a.workspace = workspace; a.workspace_bytes = workspace_bytes;
-    if (variant != DR_VARIANT_BASELINE && workspace && brick_path_supported(VX, VY, VZ, R)) {
+    if (variant != DR_VARIANT_BASELINE && workspace && brick_path_supported(VX, VY, VZ, R) &&
+        brick_image_supported(W, H, VX, VY, VZ)) {
         if (workspace_bytes < brick_workspace_bytes(n_views, W, H, VX, VY, VZ)) return DR_EINVAL;
         if (flat_strides_ok(sx, sy, sz)) return launch_march_fwd_flat(a, (hipStream_t)stream);
     }
@@ -129,7 +130,7 @@ int dr_march_bwd_rows(const void *vol, int vol_dtype, int VX, int VY, int VZ, in
     a.d_tf = d_tf; a.dtf_vs = dtf_view_stride;
     a.fov_rad = fov_rad; a.near_plane = near_plane; a.workspace = workspace; a.workspace_bytes = workspace_bytes;
     if (dr_march_bwd_variant(VX, VY, VZ, R, sx, sy, sz, dsx, dsy, dsz, d_vol != nullptr, variant, workspace != nullptr) ==
-        DR_VARIANT_AUTO) {
+            DR_VARIANT_AUTO && brick_image_supported(W, H, VX, VY, VZ)) {
         if (workspace_bytes < brick_workspace_bytes(n_views, W, H, VX, VY, VZ)) return DR_EINVAL;
         return launch_march_bwd_flat(a, (hipStream_t)stream);
     }

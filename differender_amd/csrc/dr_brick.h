@@ -6,10 +6,14 @@
 // so they touch at most the neighbouring cell: the LDS box of a brick is BRK+3 voxels wide
 // (one voxel below, two above).
 //
-// Layer of a brick = Manhattan distance (in bricks) from the brick that holds the camera. Along any ray
-// the per-axis coordinates move monotonically away from the camera, so the bricks a ray visits have
-// strictly increasing layers: per-(ray, layer) partial composites can be combined front to back without
-// knowing which brick produced them.
+// Layer of a brick FOR A RAY = Manhattan distance (in bricks) from the brick that holds the ray's FIRST sample.
+// Along a line every coordinate is monotone, so the bricks a ray visits have strictly increasing layers:
+// per-(ray, layer) partial composites can be combined front to back without knowing which brick produced
+// them, and a ray needs at most NBx+NBy+NBz-2 layers. This holds wherever the ray starts -- also for a camera
+// inside the volume, whose rays begin BEHIND the eye (the reference does not clip tmin at 0, VR.py:28-53).
+// (Each brick also has a camera-based layer -- distance from the camera's brick -- used only to run the alpha
+// pre-pass front to back in groups of bricks; for a camera outside the volume it is the ray's layer plus a per-ray
+// constant.)
 #pragma once
 #include "dr_device.h"
 
@@ -61,12 +65,49 @@ __device__ __forceinline__ int cam_brick(float cam, float sc) {
 }
 __device__ __forceinline__ int axis_layer_min(int cb, int NB) { return cb < 0 ? -cb : (cb > NB - 1 ? cb - (NB - 1) : 0); }
 
-// A ray is "regular" when the brick pipeline may handle it; the others (degenerate single-sample rays,
-// camera inside the box) are marched whole by the per-ray pass. Must be evaluated identically in every pass.
-__device__ __forceinline__ bool ray_is_regular(int n, float entry) { return n >= 2 && entry >= 0.0f; }
+// A ray is "regular" when the brick pipeline handles it; the others -- single-sample rays, whose positions are 0/0 in the
+// reference (VR.py:279-280) -- are marched whole by the per-ray pass. Must be evaluated identically in every pass.
+__device__ __forceinline__ bool ray_is_regular(int n) { return n >= 2; }
+
+// Brick that holds sample 0 of a ray (position cam + t0 * vd: mix(t0, exit, 0) == t0 exactly, VR.py:277-280), from the
+// canonical cell computation.
+__device__ __forceinline__ void entry_brick(float scx, float scy, float scz, f3 cam, f3 vd, float t0, int &ebx, int &eby,
+                                            int &ebz) {
+    float fr;
+    int x0, y0, z0;
+    axis_coord(fmaf(t0, vd.x, cam.x), scx, x0, fr);
+    axis_coord(fmaf(t0, vd.y, cam.y), scy, y0, fr);
+    axis_coord(fmaf(t0, vd.z, cam.z), scz, z0, fr);
+    ebx = x0 / BRK; eby = y0 / BRK; ebz = z0 / BRK;
+}
+__device__ __forceinline__ int ray_layer(int bx, int by, int bz, int ebx, int eby, int ebz) {
+    return abs(bx - ebx) + abs(by - eby) + abs(bz - ebz);
+}
+// camera-based layer of a brick (phases of the alpha pre-pass): distance from the camera's (unclamped) brick
+__device__ __forceinline__ int camera_layer(int bx, int by, int bz, f3 cam, float scx, float scy, float scz, int NBx, int NBy,
+                                            int NBz) {
+    const int cbx = cam_brick(cam.x, scx), cby = cam_brick(cam.y, scy), cbz = cam_brick(cam.z, scz);
+    const int lmin = axis_layer_min(cbx, NBx) + axis_layer_min(cby, NBy) + axis_layer_min(cbz, NBz);
+    return abs(bx - cbx) + abs(by - cby) + abs(bz - cbz) - lmin;
+}
 
 // trilinear tap from the LDS box; identical arithmetic to tri_sample (x -> y -> z lerps)
 __device__ __forceinline__ float tri_lds(const float *box, int base, float fx, float fy, float fz) {
+#ifdef DR_EXP_B64
+    // TIMING EXPERIMENT ONLY (wrong values for odd z): the (z, z+1) pair of every corner column as one 8-byte read
+    const float2 *b2 = reinterpret_cast<const float2 *>(box);
+    const int h = base >> 1;
+    const float2 p00 = b2[h], p10 = b2[h + (BOX_SX >> 1)], p01 = b2[h + (BOX_SY >> 1)], p11 = b2[h + ((BOX_SX + BOX_SY) >> 1)];
+    {
+        float a = mixf(p00.x, p10.x, fx);
+        float b = mixf(p01.x, p11.x, fx);
+        float zl = mixf(a, b, fy);
+        a = mixf(p00.y, p10.y, fx);
+        b = mixf(p01.y, p11.y, fx);
+        float zh = mixf(a, b, fy);
+        return mixf(zl, zh, fz);
+    }
+#endif
     float a = mixf(box[base], box[base + BOX_SX], fx);
     float b = mixf(box[base + BOX_SY], box[base + BOX_SX + BOX_SY], fx);
     float zl = mixf(a, b, fy);

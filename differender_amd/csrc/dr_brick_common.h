@@ -24,7 +24,10 @@ struct BrickParams {
     uint8_t *rayflag;    // [view][NP]: 1 = irregular ray (marched whole by F2 / B2)
     int32_t *ws_steps;   // [view][NP]: live samples per ray (F2 -> B1)
     unsigned int *stats; // workspace header, words ST_* below
-    unsigned int *vflags; // [view] 1 if some ray of the view may reach alpha >= 0.99 (the alpha pre-pass runs for it)
+    unsigned int *vflags; // [view] 1 if some ray of the view may reach alpha >= 0.99 (the alpha pre-pass runs for it);
+                          // [n_views + view] 1 if the camera sits inside (or on) the volume: rays start behind the eye, the
+                          // camera-based brick layers are not monotone along them and the pre-pass runs as ONE phase
+    int n_views;
     int use_live;        // forward: ws_steps holds each ray's exact live sample count (from the alpha pre-pass)
     int pp_l0, pp_l1, pp_first;  // alpha pre-pass phase: brick layers [pp_l0, pp_l1); later phases skip terminated rays
     const struct BrickCtxRec *ctx;  // [view][brick]: brick geometry + pixel rectangle, filled once per forward call
@@ -47,8 +50,8 @@ enum {
 };
 
 struct BrickCtx {
-    int bx, by, bz, layer;
-    int ox, oy, oz;               // voxel index of LDS box element 0 along each axis (16*b - 1)
+    int bx, by, bz, layer;        // layer: camera-based (pre-pass phases only; see dr_brick.h)
+    int ox, oy, oz;               // voxel index of LDS box element 0 along each axis (12*b - 1)
     float lo[3], hi[3];           // world AABB of the brick's cells, with slack
     int i0, i1, j0, j1;           // candidate pixel rectangle (inclusive); empty if i0 > i1
     int live;                     // from the workspace record (see BrickCtxRec)
@@ -85,9 +88,7 @@ __device__ __forceinline__ void brick_setup(const BrickParams<VT> &P, int b, f3 
     const BrickGrid &g = P.g;
     c.bz = b % g.NBz; c.by = (b / g.NBz) % g.NBy; c.bx = b / (g.NBz * g.NBy);
     c.ox = c.bx * BRK - 1; c.oy = c.by * BRK - 1; c.oz = c.bz * BRK - 1;
-    const int cbx = cam_brick(cam.x, P.vol.scx), cby = cam_brick(cam.y, P.vol.scy), cbz = cam_brick(cam.z, P.vol.scz);
-    const int lmin = axis_layer_min(cbx, g.NBx) + axis_layer_min(cby, g.NBy) + axis_layer_min(cbz, g.NBz);
-    c.layer = abs(c.bx - cbx) + abs(c.by - cby) + abs(c.bz - cbz) - lmin;
+    c.layer = camera_layer(c.bx, c.by, c.bz, cam, P.vol.scx, P.vol.scy, P.vol.scz, g.NBx, g.NBy, g.NBz);
     const int bb[3] = {c.bx, c.by, c.bz};
     const int nb[3] = {g.NBx, g.NBy, g.NBz};
     const float sc[3] = {P.vol.scx, P.vol.scy, P.vol.scz};
@@ -174,7 +175,10 @@ static __global__ __launch_bounds__(256) void brick_ctx_kernel(BrickParams<VT> P
         if (forward) {
             const unsigned int flag = n_max > 0.0f ? may_terminate(P.tf + view * P.tf_vs, P.R, P.inv_sr, n_max) : 0u;
             if (threadIdx.x == 0) {
+                const float cx = P.cam[3 * view], cy = P.cam[3 * view + 1], cz = P.cam[3 * view + 2];
+                const float lim = 1.0f + 1e-3f;
                 P.vflags[view] = flag;
+                P.vflags[P.n_views + view] = (fabsf(cx) <= lim && fabsf(cy) <= lim && fabsf(cz) <= lim) ? 1u : 0u;
                 if (view == 0) { P.stats[ST_REPAIR] = 0u; P.stats[ST_BASELINE_RAYS] = 0u; P.stats[ST_MARK] = DR_CTX_MARK; }
             }
         } else if (view == 0) {
@@ -395,7 +399,7 @@ static inline size_t ws_layout(void *base, int n_views, int NP, const BrickGrid 
     if (w) w->stats = reinterpret_cast<unsigned int *>(b + o);
     o += ST_WORDS * 4;
     if (w) w->vflags = reinterpret_cast<unsigned int *>(b + o);
-    o += align16((size_t)n_views * 4);
+    o += align16((size_t)n_views * 8);
     if (w) w->seg_rgba = reinterpret_cast<float4 *>(b + o);
     o += nseg * 16;
     if (w) { w->seg_cnt = reinterpret_cast<uint16_t *>(b + o); w->cnt_bytes = nseg * 2; }
@@ -428,7 +432,7 @@ static inline BrickParams<VT> make_brick_params(const MarchArgs &a, const Worksp
     const double near_h = 2.0 * tan(a.fov_rad) * a.near_plane;
     P.near_ = (float)a.near_plane; P.near_h = (float)near_h; P.near_w = (float)(near_h * ((double)P.imgW / (double)a.H));
     P.g = make_brick_grid(a.VX, a.VY, a.VZ);
-    P.seg_rgba = w.seg_rgba; P.seg_cnt = w.seg_cnt; P.rayflag = w.rayflag; P.stats = w.stats; P.vflags = w.vflags; P.ws_steps = w.ws_steps;
+    P.seg_rgba = w.seg_rgba; P.seg_cnt = w.seg_cnt; P.rayflag = w.rayflag; P.stats = w.stats; P.vflags = w.vflags; P.n_views = a.n_views; P.ws_steps = w.ws_steps;
     P.use_live = a.use_live; P.ctx = w.ctx;
     P.pp_l0 = a.pp_l0; P.pp_l1 = a.pp_l1; P.pp_first = a.pp_first;
     P.out = a.out; P.steps = a.steps;

@@ -35,6 +35,7 @@ int launch_march_bwd_baseline(const MarchArgs &a, hipStream_t stream);
 
 // Brick-centric kernels (DR_VARIANT_AUTO): LDS-staged bricks, per-(ray,layer) partial composites.
 bool brick_path_supported(int VX, int VY, int VZ, int R);
+bool brick_image_supported(int W, int H, int VX, int VY, int VZ);  // [layer][pixel] slot indices stay below 2^31
 size_t brick_workspace_bytes(int n_views, int W, int H, int VX, int VY, int VZ);
 int launch_ray_compose(const MarchArgs &a, hipStream_t stream);      // F2
 int launch_ray_alpha(const MarchArgs &a, hipStream_t stream);        // alpha pre-pass: per-ray composition of one phase

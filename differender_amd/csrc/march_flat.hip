@@ -67,6 +67,7 @@ struct FlatLds {
     float4 *tf; float *box; unsigned long long *dbox; unsigned long long *dtf;
     float4 *ray0;   // (t0, exit, (float)(n-1), RN(1/(n-1)))
     float4 *ray1;   // (vx, vy, vz, bits(pixel index))
+    int *segi;      // workspace slot of the segment within its view: ray's layer of this brick * NP + pixel
     int *s_rel;     // first sample index of the segment minus its flat offset
     int *offs;      // per wave: flat index of each segment's first sample, then the wave's total (index entry + wave)
     int *valid;     // in-brick samples of each segment (forward)
@@ -83,6 +84,7 @@ __host__ __device__ constexpr size_t flat_fixed_bytes(bool want_vol) {
     if (BWD && want_vol) s += ((size_t)BOX_LDS * 8 + 15) / 16 * 16;
     s += (size_t)EC * 32;
     s += (size_t)EC * 4 + (((size_t)EC + 8) * 4 + 15) / 16 * 16 + (size_t)EC * 4 + (size_t)EC * 4;  // (live | slen)
+    s += (size_t)EC * 4;  // segi
     if (BWD) s += 64;  // gmax, gmin per wave
     return s;
 }
@@ -101,6 +103,7 @@ __device__ __forceinline__ FlatLds flat_carve(unsigned char *smem, int R) {
     L.ray0 = reinterpret_cast<float4 *>(smem + o); o += (size_t)EC * 16;
     L.ray1 = reinterpret_cast<float4 *>(smem + o); o += (size_t)EC * 16;
     L.s_rel = reinterpret_cast<int *>(smem + o); o += (size_t)EC * 4;
+    L.segi = reinterpret_cast<int *>(smem + o); o += (size_t)EC * 4;
     L.offs = reinterpret_cast<int *>(smem + o); o += align16((EC + 8) * 4);  // per wave: its entries' offsets + end marker
     L.valid = reinterpret_cast<int *>(smem + o); o += (size_t)EC * 4;
     L.slen = nullptr;
@@ -200,11 +203,11 @@ struct CandData {
     bool have;
     int pl; size_t p;
     int n; float entry, exit_, vx, vy, vz;
-    int live, scnt; unsigned char rflag;
+    int live; unsigned char rflag;
 };
 template <typename VT, int MODE, bool BWD, bool ALPHA>
 __device__ __forceinline__ void cand_load(const BrickParams<VT> &P, const BrickCtx &c, int view, int cbase, int ncand,
-                                          size_t seg_base, CandData &d) {
+                                          CandData &d) {
     constexpr int EC = BWD ? FEC_BWD : FEC_FWD;
     constexpr int FNW = (BWD ? FNT_BWD : FNT_FWD) / 64, CW = EC / FNW;  // candidates per wave and round
     const int NP = P.W * P.H;
@@ -216,7 +219,7 @@ __device__ __forceinline__ void cand_load(const BrickParams<VT> &P, const BrickC
     const int cc = cbase + lane_ * FNW + ((lane_ & 1) ? FNW - 1 - wave_ : wave_);  // dealt back and forth: -1.3 %
     d.have = lane_ < CW && cc < ncand;
     d.pl = 0; d.p = 0; d.n = 0; d.entry = -1.0f; d.exit_ = 0.f; d.vx = d.vy = d.vz = 0.f;
-    d.live = 0; d.scnt = 0; d.rflag = 0;
+    d.live = 0; d.rflag = 0;
     if (!d.have) return;
     // cc / nj without the ~25-instruction integer division while the rectangle is small (always, unless the camera sits
     // inside the volume of a > 2-megapixel image): the float quotient of cc + 0.5 stays >= 0.5/nj away from an integer,
@@ -230,10 +233,8 @@ __device__ __forceinline__ void cand_load(const BrickParams<VT> &P, const BrickC
     d.exit_ = P.exit_[d.p];
     d.vx = P.rays[3 * d.p]; d.vy = P.rays[3 * d.p + 1]; d.vz = P.rays[3 * d.p + 2];
     if (BWD || (!ALPHA && P.use_live) || (ALPHA && !P.pp_first)) d.live = P.ws_steps[d.p];
-    if (BWD) {  // (the three float4 of the coarse tape / gradients are fetched when the entry is written: the
-        d.rflag = P.rayflag[d.p];  //  backward kernel is register-bound and they would be held across the box staging)
-        d.scnt = P.seg_cnt[seg_base + d.pl];
-    }
+    if (BWD) d.rflag = P.rayflag[d.p];  // (the three float4 of the coarse tape / gradients are fetched per chunk: the
+                                        //  backward kernel is register-bound and they would be held across the box staging)
 }
 
 // inclusive sum of an int over the wave (DPP; lanes without a source add 0)
@@ -254,7 +255,7 @@ __device__ __forceinline__ int wave_incl_sum(int v) {
 // rounding -- is reproducible.
 template <typename VT, int MODE, bool BWD, int FNT, bool ALPHA = false, int KS = 1>
 __device__ __forceinline__ void flat_build_entries(const BrickParams<VT> &P, const BrickCtx &c, f3 cam, int view,
-                                                   const CandData &d, size_t seg_base, FlatLds &L, int &nE, int &M) {
+                                                   const CandData &d, FlatLds &L, int &nE, int &M) {
     constexpr int EC = BWD ? FEC_BWD : FEC_FWD;
     constexpr int FNW = FNT / 64, CW = EC / FNW;
     static_assert(CW <= 64 && CW * FNW == EC, "one candidate per lane and round");
@@ -266,13 +267,13 @@ __device__ __forceinline__ void flat_build_entries(const BrickParams<VT> &P, con
     const f3 vd = make_f3(d.vx, d.vy, d.vz);
     if (d.have) {
         const int n = d.n;
-        bool ok = ray_is_regular(n, d.entry);
+        bool ok = ray_is_regular(n);
         int nmarch = (MODE == DR_MODE_DIFF && n > P.S) ? P.S : n;
         if (!BWD && !ALPHA && ok && P.use_live && P.vflags[view] != 0u)
             nmarch = min(nmarch, live);  // exact live count from the alpha pre-pass: dead samples are not marched
         if (ALPHA && !P.pp_first && live == -1) ok = false;  // terminated in an earlier phase of the pre-pass
         if (BWD && ok) {
-            ok = !d.rflag && d.scnt != 0;  // irregular ray / no sample in this brick
+            ok = !d.rflag;  // a ray the per-ray pass marched whole (repaired by the count check): B2 handles it
             nmarch = min(nmarch, live);
         }
         if (ok) {
@@ -292,6 +293,10 @@ __device__ __forceinline__ void flat_build_entries(const BrickParams<VT> &P, con
         const int off = incl - flen;
         L.ray0[slot] = make_float4(t0, exit_, nm1, 1.0f / nm1);  // n >= 2 (ray_is_regular)
         L.ray1[slot] = make_float4(vd.x, vd.y, vd.z, __int_as_float(pl));
+        // the ray's layer of this brick (dr_brick.h): distance from the brick of the ray's first sample
+        int ebx, eby, ebz;
+        entry_brick(P.vol.scx, P.vol.scy, P.vol.scz, cam, vd, t0, ebx, eby, ebz);
+        L.segi[slot] = ray_layer(c.bx, c.by, c.bz, ebx, eby, ebz) * (P.W * P.H) + pl;
         L.s_rel[slot] = s0 - off;
         L.offs[slot + wave_] = off;
         if (!BWD) L.slen[slot] = s1 - s0;
@@ -552,7 +557,9 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
     BrickCtx c;
     brick_ctx_load(P.ctx + (size_t)view * gridDim.x + blockIdx.x, c);  // uniform address: scalar loads
     if (c.i0 > c.i1 || c.j0 > c.j1) return;  // uniform: the brick projects outside the image
-    if (ALPHA && (c.layer < P.pp_l0 || c.layer >= P.pp_l1)) return;  // uniform: not in this phase of the pre-pass
+    if (ALPHA) {  // uniform: is this brick part of this phase of the pre-pass? (camera inside the volume: one phase, all bricks)
+        if (P.vflags[gridDim.y + view] ? !P.pp_first : (c.layer < P.pp_l0 || c.layer >= P.pp_l1)) return;
+    }
     // backward after a flat forward: bricks in which the forward marched nothing (rays terminated before them) have no work
     if (BWD && !DR_PHASE_TIMING && c.live == 0 && P.stats[ST_MARK] == DR_CTX_MARK) return;  // uniform
 
@@ -563,14 +570,14 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
     VolView<VT> vol = P.vol;
     vol.p += view * P.vol_vs;
     const int NP = P.W * P.H;
-    const size_t seg_base = ((size_t)view * P.g.NL + c.layer) * NP;
+    const size_t seg_view = (size_t)view * P.g.NL * NP;  // this view's [layer][pixel] slots
     const int ncand = (c.i1 - c.i0 + 1) * (c.j1 - c.j0 + 1);
 #if DR_PHASE_TIMING
     const long long tk0 = clock64();
     long long tk2 = 0;
 #endif
     CandData cd;
-    cand_load<VT, MODE, BWD, ALPHA>(P, c, view, 0, ncand, seg_base, cd);  // ray buffers of the first round's candidates
+    cand_load<VT, MODE, BWD, ALPHA>(P, c, view, 0, ncand, cd);  // ray buffers of the first round's candidates
     BoxStage<FNT> stage;
     FixScale fs;
     int nE0, M0;
@@ -579,7 +586,7 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
     // anything when there are none.
     const bool lazy = (!BWD && !ALPHA && P.use_live && P.vflags[view] != 0u) || (ALPHA && !P.pp_first);  // uniform
     if (lazy) {
-        flat_build_entries<VT, MODE, BWD, FNT, ALPHA, KS>(P, c, cam, view, cd, seg_base, L, nE0, M0);
+        flat_build_entries<VT, MODE, BWD, FNT, ALPHA, KS>(P, c, cam, view, cd, L, nE0, M0);
         if (!__syncthreads_or(nE0 > 0) && ncand <= EC) return;  // uniform: no wave found a segment
         box_issue<VT, FNT>(P, vol, c, P.tf + view * P.tf_vs, stage);
     } else {
@@ -594,7 +601,7 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
                 if ((threadIdx.x & 63) == 0) { L.gmax[threadIdx.x >> 6] = gm; L.gmax[8 + (threadIdx.x >> 6)] = gn; }
             }
         }
-        flat_build_entries<VT, MODE, BWD, FNT, ALPHA, KS>(P, c, cam, view, cd, seg_base, L, nE0, M0);  // ... while the segments are listed
+        flat_build_entries<VT, MODE, BWD, FNT, ALPHA, KS>(P, c, cam, view, cd, L, nE0, M0);  // ... while the segments are listed
     }
     box_commit<VT, FNT>(P, vol, c, P.tf + view * P.tf_vs, stage, L);
     __syncthreads();
@@ -623,8 +630,8 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
     for (int cbase = 0; cbase < ncand; cbase += EC) {
         int nE = nE0, M = M0;
         if (cbase > 0) {
-            cand_load<VT, MODE, BWD, ALPHA>(P, c, view, cbase, ncand, seg_base, cd);
-            flat_build_entries<VT, MODE, BWD, FNT, ALPHA, KS>(P, c, cam, view, cd, seg_base, L, nE, M);  // syncs inside
+            cand_load<VT, MODE, BWD, ALPHA>(P, c, view, cbase, ncand, cd);
+            flat_build_entries<VT, MODE, BWD, FNT, ALPHA, KS>(P, c, cam, view, cd, L, nE, M);  // syncs inside
         }
         any = any || nE > 0;
         // this wave's own segment table: entries [ea, eb), flat samples [0, M); offsets live at index entry + wave
@@ -657,7 +664,7 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
             float4 pf_pre = make_float4(0.f, 0.f, 0.f, 0.f), pf_go = pf_pre, pf_of = pf_pre;
             if (BWD && act) {
                 const int plq = __float_as_int(r1.w);
-                pf_pre = P.seg_rgba[seg_base + plq];
+                pf_pre = P.seg_rgba[seg_view + L.segi[e]];
                 pf_go = reinterpret_cast<const float4 *>(P.grad_out)[(size_t)view * NP + plq];
                 pf_of = reinterpret_cast<const float4 *>(P.out_fwd)[(size_t)view * NP + plq];
             }
@@ -705,7 +712,7 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
                     const int cntp = (int)cf[0];
                     const int before = cntp ? atomicAdd(&L.valid[e], cntp) : L.valid[e];
                     if (seg_end && before + cntp > 0)
-                        P.seg_rgba[seg_base + __float_as_int(r1.w)] = make_float4(0.f, 0.f, 0.f, 1.0f - Tl);
+                        P.seg_rgba[seg_view + L.segi[e]] = make_float4(0.f, 0.f, 0.f, 1.0f - Tl);
                 }
                 continue;
             }
@@ -796,7 +803,7 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
                     // a (ray, layer) slot belongs to the one brick that holds samples of the ray: a candidate
                     // segment without any in-brick sample must not touch it
                     if (seg_end && before + cntp > 0)
-                        P.seg_rgba[seg_base + __float_as_int(r1.w)] = make_float4(inc.c0, inc.c1, inc.c2, inc.a);
+                        P.seg_rgba[seg_view + L.segi[e]] = make_float4(inc.c0, inc.c1, inc.c2, inc.a);
                 }
             } else {
                 SampleAdj ad;
@@ -898,7 +905,7 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
             bool some = false;
             for (int e = ea + lane; e < eb; e += 64) {
                 const int v = L.valid[e];
-                if (v > 0) { P.seg_cnt[seg_base + __float_as_int(L.ray1[e].w)] = (uint16_t)min(v, 65535); some = true; }
+                if (v > 0) { P.seg_cnt[seg_view + L.segi[e]] = (uint16_t)min(v, 65535); some = true; }
             }
             if (!ALPHA && __any(some) && lane == 0)  // tell the backward that this brick holds live samples of the view
                 const_cast<BrickCtxRec *>(P.ctx)[(size_t)view * gridDim.x + blockIdx.x].live = 1;
@@ -951,6 +958,10 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
 bool flat_strides_ok(int64_t sx, int64_t sy, int64_t sz) {
     const int64_t lim = ((int64_t)1 << 31) / (3 * BOX);
     return sx >= 0 && sy >= 0 && sz >= 0 && sx < lim && sy < lim && sz < lim;
+}
+bool brick_image_supported(int W, int H, int VX, int VY, int VZ) {
+    const BrickGrid g = make_brick_grid(VX, VY, VZ);
+    return (long long)g.NL * W * H < (1ll << 31);
 }
 bool brick_path_supported(int VX, int VY, int VZ, int R) {
     const int m = VX > VY ? (VX > VZ ? VX : VZ) : (VY > VZ ? VY : VZ);

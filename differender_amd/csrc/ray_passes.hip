@@ -16,18 +16,24 @@
 namespace dr {
 
 // ------------------------------------------------------------------------------------------------ F2
-// Layer (dr_brick.h) of the brick that holds sample s of a ray. Layers grow monotonically along a ray, so the
-// bricks of samples [0, n) all have layers between those of sample 0 and sample n-1: the per-ray passes only look
-// at that range of the [layer][pixel] workspace (typically 45-60 of 127 layers at 512^3).
+// Brick that holds sample s of a ray (canonical cell computation). A ray's layers (dr_brick.h) run from 0 -- the brick
+// of its first sample -- to the layer of its last marched sample: the per-ray passes only look at that range of the
+// [layer][pixel] workspace (typically 45-60 of 127 layers at 512^3).
 template <typename VT>
-__device__ __forceinline__ int sample_layer(const BrickParams<VT> &P, const RayGeom &rg, f3 cam, int s) {
+__device__ __forceinline__ void sample_brick(const BrickParams<VT> &P, const RayGeom &rg, f3 cam, int s, int &bx, int &by, int &bz) {
     float px, py, pz, fr;
     int x0, y0, z0;
     sample_pos(rg, cam.x, cam.y, cam.z, s, px, py, pz);
     axis_coord(px, P.vol.scx, x0, fr); axis_coord(py, P.vol.scy, y0, fr); axis_coord(pz, P.vol.scz, z0, fr);
-    const int cbx = cam_brick(cam.x, P.vol.scx), cby = cam_brick(cam.y, P.vol.scy), cbz = cam_brick(cam.z, P.vol.scz);
-    const int lmin = axis_layer_min(cbx, P.g.NBx) + axis_layer_min(cby, P.g.NBy) + axis_layer_min(cbz, P.g.NBz);
-    return abs(x0 / BRK - cbx) + abs(y0 / BRK - cby) + abs(z0 / BRK - cbz) - lmin;
+    bx = x0 / BRK; by = y0 / BRK; bz = z0 / BRK;
+}
+// layer of the ray's last marched sample (= number of layers the per-ray passes walk, minus one)
+template <typename VT>
+__device__ __forceinline__ int last_layer(const BrickParams<VT> &P, const RayGeom &rg, f3 cam, int nmarch, int &ebx, int &eby, int &ebz) {
+    int bx, by, bz;
+    sample_brick(P, rg, cam, 0, ebx, eby, ebz);
+    sample_brick(P, rg, cam, nmarch - 1, bx, by, bz);
+    return min(ray_layer(bx, by, bz, ebx, eby, ebz), P.g.NL - 1);
 }
 
 template <typename VT, int MODE>
@@ -55,47 +61,41 @@ __global__ __launch_bounds__(256) void ray_compose_kernel(BrickParams<VT> P) {
         int nmarch = (MODE == DR_MODE_DIFF && rg.n > P.S) ? P.S : rg.n;
         const int nfull = nmarch;
         const size_t seg0 = (size_t)view * P.g.NL * NP + pl;
-        bool regular = ray_is_regular(rg.n, rg.entry);
-        // with an alpha pre-pass the bricks marched exactly the live samples of the ray: no crossing to look for
+        bool regular = ray_is_regular(rg.n);
+        // with an alpha pre-pass the bricks marched exactly the live samples of the ray
         const bool use_live = P.use_live && P.vflags[view] != 0u;
         if (regular && use_live) nmarch = min(nmarch, P.ws_steps[p]);
-        int l_lo = 0, l_hi = P.g.NL - 1;
+        int l_hi = -1;
         if (regular && nmarch > 0) {
-            l_lo = max(sample_layer(P, rg, cam, 0), 0);
-            l_hi = min(sample_layer(P, rg, cam, nmarch - 1), P.g.NL - 1);
+            int ebx, eby, ebz;
+            l_hi = last_layer(P, rg, cam, nmarch, ebx, eby, ebz);
         }
         if (regular) {
-            // safety net: the segments must account for every sample, else march this ray whole
+            // Composite the partials front to back, leaving the prefix before each segment for the backward. Without a
+            // pre-pass no ray can reach alpha 0.99 (may_terminate() bounds it below 0.98), so there is no crossing to look
+            // for. Safety net: the segments must account for every sample, else this ray is marched whole below.
             int total = 0;
-            for (int l = l_lo; l <= l_hi; ++l) total += P.seg_cnt[seg0 + (size_t)l * NP];
-            if (total != nmarch) { regular = false; nmarch = nfull; atomicAdd(&P.stats[ST_REPAIR], 1u); }
-        }
-        int s_from = 0, s_to = 0;  // samples to march one by one with early termination
-        if (!regular) {
-            flag = 1; s_to = nmarch;
-        } else {
-            int sacc = 0;
-            steps = nmarch;
-            for (int l = l_lo; l <= l_hi; ++l) {
+            for (int l = 0; l <= l_hi; ++l) {
                 const size_t si = seg0 + (size_t)l * NP;
                 const int cnt = P.seg_cnt[si];
                 if (cnt == 0) continue;
                 const float4 sg = P.seg_rgba[si];
                 if (MODE == DR_MODE_DIFF) P.seg_rgba[si] = make_float4(C0, C1, C2, A);  // prefix for the backward
                 const float T = 1.0f - A;
-                const float A_after = fmaf(T, sg.w, A);
-                if (!use_live && !(A_after < 0.99f)) {  // alpha crosses 0.99 inside this segment
-                    s_from = sacc; s_to = sacc + cnt;
-                    break;
-                }
                 C0 = fmaf(T, sg.x, C0); C1 = fmaf(T, sg.y, C1); C2 = fmaf(T, sg.z, C2);
-                A = A_after;
-                sacc += cnt;
+                A = fmaf(T, sg.w, A);
+                total += cnt;
             }
+            steps = nmarch;
+            if (total != nmarch) { regular = false; nmarch = nfull; atomicAdd(&P.stats[ST_REPAIR], 1u); }
         }
-        if (s_to > s_from) {
-            steps = s_from;
-            for (int s = s_from; s < s_to; ++s) {
+        if (!regular) {
+            // single-sample rays (and repaired ones): the sequential march of the baseline kernels
+            flag = 1;
+            C0 = C1 = C2 = A = 0.f;
+            steps = 0;
+            atomicAdd(&P.stats[ST_BASELINE_RAYS], 1u);
+            for (int s = 0; s < nmarch; ++s) {
                 if (!(A < 0.99f)) break;
                 Sample sm;
                 sample_pos(rg, cam.x, cam.y, cam.z, s, sm.px, sm.py, sm.pz);
@@ -108,27 +108,6 @@ __global__ __launch_bounds__(256) void ray_compose_kernel(BrickParams<VT> P) {
                 C1 = fmaf(T, sm.L * sm.g * sm.op, C1);
                 C2 = fmaf(T, sm.L * sm.b * sm.op, C2);
                 A = fmaf(T, sm.op, A);
-            }
-            // a regular ray that crossed 0.99 exactly on the last sample of its segment keeps marching
-            // nothing further: later segments are ignored (their first sample would see A >= 0.99).
-            if (!flag && A < 0.99f) {
-                // the partial composite crossed 0.99 but the exact recurrence did not (rounding): fall
-                // back to marching the rest of the ray sample by sample.
-                for (int s = s_to; s < nmarch; ++s) {
-                    if (!(A < 0.99f)) break;
-                    Sample sm;
-                    sample_pos(rg, cam.x, cam.y, cam.z, s, sm.px, sm.py, sm.pz);
-                    classify(vol, lds_tf, P.R, P.tf_len, P.inv_sr, sm);
-                    ++steps;
-                    if (MODE == DR_MODE_NONDIFF && !(sm.a > 1e-3f)) continue;
-                    shade(vol, light, vd, MODE == DR_MODE_DIFF, sm);
-                    const float T = 1.0f - A;
-                    C0 = fmaf(T, sm.L * sm.r * sm.op, C0);
-                    C1 = fmaf(T, sm.L * sm.g * sm.op, C1);
-                    C2 = fmaf(T, sm.L * sm.b * sm.op, C2);
-                    A = fmaf(T, sm.op, A);
-                }
-                flag = 1;  // its stored prefixes beyond s_to are stale: let B2 handle the whole ray
             }
         }
     }
@@ -159,7 +138,9 @@ __global__ __launch_bounds__(256) void ray_alpha_kernel(BrickParams<VT> P) {
     RayGeom rg;
     load_ray(P.entry, P.exit_, P.rays, P.nsamp, p, rg);
     const int nmarch = (MODE == DR_MODE_DIFF && rg.n > P.S) ? P.S : rg.n;
-    if (ray_is_regular(rg.n, rg.entry)) {
+    const bool inside = P.vflags[P.n_views + view] != 0u;  // camera inside the volume: the pre-pass is one phase
+    if (inside && !P.pp_first) return;                      // uniform
+    if (ray_is_regular(rg.n)) {
         // state carried from phase to phase in the (not yet written) output buffer: alpha so far, samples so far
         float4 *park = reinterpret_cast<float4 *>(P.out) + p;
         float A = 0.f;
@@ -167,8 +148,16 @@ __global__ __launch_bounds__(256) void ray_alpha_kernel(BrickParams<VT> P) {
         if (!P.pp_first) { const float4 st = *park; A = st.x; sacc = __float_as_int(st.y); }
         const size_t seg0 = (size_t)view * P.g.NL * NP + pl;
         const f3 cam = make_f3(P.cam[3 * view], P.cam[3 * view + 1], P.cam[3 * view + 2]);
-        const int l_lo = max(max(sample_layer(P, rg, cam, 0), 0), P.pp_l0);
-        const int l_hi = min(min(sample_layer(P, rg, cam, nmarch - 1), P.g.NL - 1), P.pp_l1 - 1);
+        // this phase's bricks have camera-based layers [pp_l0, pp_l1); along a ray from a camera outside the volume
+        // those are the ray's own layers plus the camera-based layer of its first brick
+        int ebx, eby, ebz;
+        int l_hi = last_layer(P, rg, cam, nmarch, ebx, eby, ebz);
+        int l_lo = 0;
+        if (!inside) {
+            const int off = camera_layer(ebx, eby, ebz, cam, P.vol.scx, P.vol.scy, P.vol.scz, P.g.NBx, P.g.NBy, P.g.NBz);
+            l_lo = max(P.pp_l0 - off, 0);
+            l_hi = min(l_hi, P.pp_l1 - 1 - off);
+        }
         for (int l = l_lo; l <= l_hi; ++l) {
             const size_t si = seg0 + (size_t)l * NP;
             const int cnt = P.seg_cnt[si];

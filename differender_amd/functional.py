@@ -36,6 +36,8 @@ def bwd_is_sanitised(vol, tf, d_vol, workspace):
     reference and want the reference's nan_to_num."""
     if workspace is None:
         return False
+    if workspace.numel() == 0:
+        return False
     sv = vol.stride()[-3:]
     sd = d_vol.stride()[-3:] if d_vol is not None else (0, 0, 0)
     return N.lib().dr_march_bwd_variant(*(int(v) for v in vol.shape[-3:]), int(tf.shape[-2]), *sv, *sd,

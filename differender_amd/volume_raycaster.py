@@ -14,6 +14,7 @@ Differences from the reference that a caller can observe (all documented in DESI
   * flat-normal samples contribute no normal-path gradient instead of NaN (H3).
 """
 import math
+import warnings
 
 import torch
 
@@ -105,6 +106,33 @@ class VolumeRaycaster:
         self.get_final_image = _Kernel(self._get_final_image, self._get_final_image_grad)
         self._jitter_seed = 0
         self._sr = 1.0
+        self._stats_host, self._stats_event, self._stats_rays = None, None, 0
+        self.last_stats = None         # workspace header of the most recent forward whose snapshot has arrived (int32 x32)
+        self._warned_fallback = False
+
+    def _watch_workspace(self, workspace, n_rays):
+        """Keeps an eye on the fast path's fallback counter without ever synchronising: a 128-byte snapshot of the
+        workspace header is copied to pinned memory after a forward, and looked at when a LATER call finds it
+        complete. Warns once if more than 1 % of the rays had to be marched one by one (single-sample rays or rays whose
+        segments failed the count check: correct, but the 10-40x slower kernels)."""
+        if workspace is None:
+            return
+        if self._stats_event is not None and self._stats_event.query():
+            self.last_stats = self._stats_host.clone()
+            slow = int(self.last_stats[2])
+            if slow > 0.01 * self._stats_rays and not self._warned_fallback:
+                self._warned_fallback = True
+                warnings.warn(f"differender_amd: {slow} of {self._stats_rays} rays were marched by the per-ray fallback "
+                              "kernels in a recent render (functional.workspace_stats): expect a slow-down",
+                              RuntimeWarning, stacklevel=3)
+            self._stats_event = None
+        if self._stats_event is None:
+            if self._stats_host is None:
+                self._stats_host = torch.empty(32, dtype=torch.int32, pin_memory=True)
+            self._stats_host.copy_(workspace[:128].view(torch.int32), non_blocking=True)
+            self._stats_event = torch.cuda.Event()
+            self._stats_event.record()
+            self._stats_rays = int(n_rays)
 
     def _field_shape(self, name):
         if name.startswith("volume"):
@@ -217,6 +245,7 @@ class RaycastFunction(torch.autograd.Function):
         ctx.workspace = ws  # coarse tape of the forward (per-segment prefixes), consumed by backward
         ctx.vr, ctx.sampling_rate, ctx.batched, ctx.jitter_seed = vr, sampling_rate, is_batched, seed
         vr._steps = steps if is_batched else steps[0]
+        vr._watch_workspace(ws, n.numel())
         return out if is_batched else out[0]
 
     @staticmethod

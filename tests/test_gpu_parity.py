@@ -354,11 +354,13 @@ def test_tf_optimisation_with_fused_epilogue(oracle, F):
     assert losses[-1] < 0.5 * losses[0], losses
 
 
-@pytest.mark.parametrize("cam", [(0.2, 0.1, 0.3), (0.9, 0.3, -1.15), (0.0, 1.6, 0.05)],
-                         ids=["inside", "near-corner", "above-nearly-along-y"])
+@pytest.mark.parametrize("cam", [(0.2, 0.1, 0.3), (0.9, 0.3, -1.15), (0.0, 1.6, 0.05), (-0.95, 0.9, 0.97), (1.0, 0.0, 0.0)],
+                         ids=["inside", "near-corner", "above-nearly-along-y", "inside-corner", "on-a-face"])
 def test_unusual_cameras(oracle, F, cam):
-    """Camera inside the box (every ray irregular -> marched individually), very close to it (bricks project to
-    large pixel rectangles: several listing rounds per brick) and nearly along the up vector."""
+    """Camera inside the box (every ray starts BEHIND the eye: the reference does not clip tmin at 0, VR.py:28-53),
+    very close to it (bricks project to large pixel rectangles: several listing rounds per brick), nearly along the up
+    vector. All of them run through the brick pipeline: a ray's layers count from the brick of its own first sample,
+    and only single-sample rays are left to the per-ray fallback."""
     vol, tf, _ = scene(oracle, N=40, R=32, alpha=0.04)
     tf[:, 3] = np.linspace(0.01, 0.1, 32)
     cam = np.array(cam, np.float32)
@@ -368,6 +370,11 @@ def test_unusual_cameras(oracle, F, cam):
     e, x, r, n = gpu_setup(F, cam, WH, vol.shape)
     assert np.array_equal(n[0].cpu().numpy(), n0)
     out, steps = F.march_fwd(T(vol), T(tf), T(cam[None]), e, x, r, n, 1 << 20, 1.0)
+    if F.variant == 0:
+        from differender_amd.functional import workspace_stats
+        st = workspace_stats(F._ws)
+        assert int(st[0]) == 0, "rays failed the sample-count check"
+        assert int(st[2]) == int((n0 == 1).sum()), "only single-sample rays may take the per-ray fallback"
     o = out[0].cpu().numpy()
     same = steps[0].cpu().numpy() == sref
     assert same.mean() > 0.99
@@ -378,6 +385,22 @@ def test_unusual_cameras(oracle, F, cam):
     dv, dt = F.march_bwd(T(vol), T(tf), T(cam[None]), e, x, r, n, 1 << 20, 1.0, T(g[None]), out)
     ok, err = grad_close(dv.cpu().numpy(), dv0, 2e-4); assert ok, err
     ok, err = grad_close(dt.cpu().numpy(), dt0, 2e-4); assert ok, err
+
+
+@pytest.mark.parametrize("mode,sr", [(0, 1.0), (1, 4.0)], ids=["diff", "nondiff_sr4"])
+def test_camera_inside_with_early_termination(oracle, F, mode, sr):
+    """Inside the volume with an opaque TF: rays start behind the eye, the alpha pre-pass runs as one phase, and the
+    termination decisions are still the oracle's."""
+    vol, tf, _ = scene(oracle, N=48, tf="peaks", R=64)
+    tf[:, 3] = np.linspace(0.0, 0.5, 64)
+    cam = np.array([0.3, -0.2, 0.25], np.float32)
+    WH = (56, 48)
+    ref, sref, out, steps, (e0, x0, r0, n0), _ = _fwd_both(oracle, F, vol, tf, cam, WH, sr=sr, mode=mode)
+    assert (e0[n0 > 0] < 0).all(), "every ray of a camera inside the box starts at negative t"
+    assert (sref < n0)[n0 > 40].mean() > 0.3
+    same = steps == sref
+    assert same.mean() > 0.995
+    assert np.abs(out - ref).max(-1)[same].max() <= FWD_TOL
 
 
 @pytest.mark.parametrize("vshape,WH,R", [((2, 2, 2), (8, 8), 2), ((5, 7, 3), (3, 5), 1), ((13, 12, 14), (1, 1), 4),
