@@ -8,6 +8,12 @@
 
 namespace dr {
 
+// Overflow work item: candidates [c0, c1) of one brick of one view (march_flat.hip, brick_flat_items_kernel).
+struct BrickItem { int view, brick, c0, c1; };
+constexpr int ITEM_CAP = 1 << 16;     // items the workspace holds (a 512^2 view from inside a 512^3 volume makes ~30 000)
+constexpr int CTX_MAIN_CAND = 1024;   // = MAIN_CAND / ITEM_CAND of march_flat.hip
+constexpr int CTX_ITEM_CAND = 1024;
+
 template <typename VT>
 struct BrickParams {
     VolView<VT> vol; int64_t vol_vs;
@@ -31,6 +37,7 @@ struct BrickParams {
     int use_live;        // forward: ws_steps holds each ray's exact live sample count (from the alpha pre-pass)
     int pp_l0, pp_l1, pp_first;  // alpha pre-pass phase: brick layers [pp_l0, pp_l1); later phases skip terminated rays
     const struct BrickCtxRec *ctx;  // [view][brick]: brick geometry + pixel rectangle, filled once per forward call
+    BrickItem *items;               // overflow work items of heavy bricks (count in stats[ST_NITEMS])
     float *out; int32_t *steps;
     const float *grad_out, *out_fwd;
     GradView dvol; int64_t dvol_vs;
@@ -43,6 +50,7 @@ enum {
     ST_GCAP = 1,           // backward: bits of the robust cap on |grad_out| (gradstat_kernel + brick_ctx_kernel)
     ST_BASELINE_RAYS = 2,  // rays the per-ray fallback marched in the last forward (irregular rays + repaired ones)
     ST_MARK = 3,           // DR_CTX_MARK once the flat forward has written brick records and live flags
+    ST_NITEMS = 5,         // overflow work items of the last forward (heavy bricks: see BrickItem); zeroed with seg_cnt
     ST_F64_BRICKS = 4,     // backward: (view, brick) pairs whose d_volume box accumulated in double (wide local range of |grad_out|)
     ST_TIMING = 16,        // DR_PHASE_TIMING: u64 x3 forward phases, u64 x3 backward phases, u64 backward lifetime
     ST_HIST = 64,          // backward: 256-bin histogram of the exponents of grad_out's finite non-zero components
@@ -103,19 +111,44 @@ __device__ __forceinline__ void brick_setup(const BrickParams<VT> &P, int b, f3 
     const f3 vdir = normalized3(make_f3(-cam.x, -cam.y, -cam.z));
     const f3 right = normalized3(cross3b(vdir, make_f3(0.f, 1.f, 0.f)));
     const f3 up = normalized3(cross3b(right, vdir));
+    // Which pixels' LINES (the reference marches from tmin even when it is negative: a camera inside the volume sees
+    // samples behind the eye, VR.py:28-53) can meet the brick? The pinhole map X -> (u, v) is the same central projection
+    // on both sides of the eye, so the part of the brick in front of it (depth >= eps) and the part behind it
+    // (depth <= -eps) are each convex and project into the bounding box of their vertices: the brick's corners on that
+    // side plus the points where its 12 edges cross the plane depth = +-eps (those land far outside the image unless the
+    // edge passes close to the eye, and are clipped to it below). The sliver |depth| < eps holds less than a sample
+    // spacing of any line; a miss there would be caught by the per-ray sample-count check.
     float pxmin = 1e30f, pxmax = -1e30f, pymin = 1e30f, pymax = -1e30f;
-    bool behind = false;
+    const float eps = 1e-3f;
+    const float ku = P.near_ / P.near_w, kv = P.near_ / P.near_h;
+    f3 dk[8];
+    float dep[8], du[8], dv[8];
     for (int k = 0; k < 8; ++k) {
-        const f3 d = make_f3(((k & 1) ? c.hi[0] : c.lo[0]) - cam.x, ((k & 2) ? c.hi[1] : c.lo[1]) - cam.y,
-                             ((k & 4) ? c.hi[2] : c.lo[2]) - cam.z);
-        const float depth = dot3(d, vdir);
-        if (!(depth > 1e-3f)) { behind = true; continue; }
-        const float u = dot3(d, right) / depth * (P.near_ / P.near_w);
-        const float v = dot3(d, up) / depth * (P.near_ / P.near_h);
-        const float px = (u + 0.5f) * (float)P.imgW - 0.5f, py = (v + 0.5f) * (float)P.H - 0.5f;  // full-image rows
-        pxmin = fminf(pxmin, px); pxmax = fmaxf(pxmax, px); pymin = fminf(pymin, py); pymax = fmaxf(pymax, py);
+        dk[k] = make_f3(((k & 1) ? c.hi[0] : c.lo[0]) - cam.x, ((k & 2) ? c.hi[1] : c.lo[1]) - cam.y,
+                        ((k & 4) ? c.hi[2] : c.lo[2]) - cam.z);
+        dep[k] = dot3(dk[k], vdir); du[k] = dot3(dk[k], right); dv[k] = dot3(dk[k], up);
     }
-    if (behind) { c.i0 = 0; c.i1 = P.W - 1; c.j0 = 0; c.j1 = P.H - 1; return; }
+    auto project = [&](float r, float u_, float depth) {  // (r, u_) = components along right / up
+        const float inv = 1.0f / depth;
+        const float px = (r * inv * ku + 0.5f) * (float)P.imgW - 0.5f, py = (u_ * inv * kv + 0.5f) * (float)P.H - 0.5f;  // full-image rows
+        pxmin = fminf(pxmin, px); pxmax = fmaxf(pxmax, px); pymin = fminf(pymin, py); pymax = fmaxf(pymax, py);
+    };
+    for (int k = 0; k < 8; ++k)
+        if (fabsf(dep[k]) >= eps) project(du[k], dv[k], dep[k]);
+    for (int k = 0; k < 8; ++k) {
+        for (int bit = 1; bit < 8; bit <<= 1) {
+            const int j = k | bit;
+            if (j == k) continue;  // each edge once: from the corner with the bit clear
+            for (int sgn = -1; sgn <= 1; sgn += 2) {
+                const float pl = (float)sgn * eps;
+                if ((dep[k] - pl) * (dep[j] - pl) < 0.0f) {
+                    const float t = (pl - dep[k]) / (dep[j] - dep[k]);
+                    project(fmaf(t, du[j] - du[k], du[k]), fmaf(t, dv[j] - dv[k], dv[k]), pl);
+                }
+            }
+        }
+    }
+    if (!(pxmin <= pxmax)) { c.i0 = 0; c.i1 = P.W - 1; c.j0 = 0; c.j1 = P.H - 1; return; }  // (a brick thinner than the sliver)
     pxmin = fmaxf(pxmin, -2.0f); pymin = fmaxf(pymin, -2.0f);
     pxmax = fminf(pxmax, (float)P.imgW + 2.0f); pymax = fminf(pymax, (float)P.H + 2.0f);
     // Pixel (i, j) has its ray through (px, py) = (i, j) exactly (the inverse of ray_setup's mapping), and the brick
@@ -196,6 +229,14 @@ static __global__ __launch_bounds__(256) void brick_ctx_kernel(BrickParams<VT> P
     r.i0 = c.i0; r.i1 = c.i1; r.j0 = c.j0; r.j1 = c.j1; r.pad1 = 0;
     r.live = forward ? 0 : out[(size_t)view * nbricks + b].live;
     out[(size_t)view * nbricks + b] = r;
+    if (forward && c.i0 <= c.i1 && c.j0 <= c.j1) {
+        // a brick with more candidate pixels than the main launch takes: cut the rest into work items
+        const int ncand = (c.i1 - c.i0 + 1) * (c.j1 - c.j0 + 1);
+        for (int c0 = CTX_MAIN_CAND; c0 < ncand; c0 += CTX_ITEM_CAND) {
+            const unsigned int slot = atomicAdd(&P.stats[ST_NITEMS], 1u);
+            if (slot < (unsigned int)ITEM_CAP) P.items[slot] = BrickItem{view, b, c0, min(c0 + CTX_ITEM_CAND, ncand)};
+        }
+    }
 }
 
 // Conservative sample-index range [s0, s1) of ray p inside the brick (exact membership is decided per
@@ -389,6 +430,7 @@ static __global__ __launch_bounds__(256) void gradstat_kernel(const float *x, si
 struct Workspace {
     float4 *seg_rgba; uint16_t *seg_cnt; int32_t *ws_steps; uint8_t *rayflag; unsigned int *stats, *vflags;
     BrickCtxRec *ctx;
+    BrickItem *items;
     size_t cnt_bytes;
 };
 static inline size_t ws_layout(void *base, int n_views, int NP, const BrickGrid &g, Workspace *w) {
@@ -410,6 +452,8 @@ static inline size_t ws_layout(void *base, int n_views, int NP, const BrickGrid 
     o += align16((size_t)n_views * NP);
     if (w) w->ctx = reinterpret_cast<BrickCtxRec *>(b + o);
     o += (size_t)n_views * g.NBx * g.NBy * g.NBz * sizeof(BrickCtxRec);
+    if (w) w->items = reinterpret_cast<BrickItem *>(b + o);
+    o += (size_t)ITEM_CAP * sizeof(BrickItem);
     return o;
 }
 
@@ -433,7 +477,7 @@ static inline BrickParams<VT> make_brick_params(const MarchArgs &a, const Worksp
     P.near_ = (float)a.near_plane; P.near_h = (float)near_h; P.near_w = (float)(near_h * ((double)P.imgW / (double)a.H));
     P.g = make_brick_grid(a.VX, a.VY, a.VZ);
     P.seg_rgba = w.seg_rgba; P.seg_cnt = w.seg_cnt; P.rayflag = w.rayflag; P.stats = w.stats; P.vflags = w.vflags; P.n_views = a.n_views; P.ws_steps = w.ws_steps;
-    P.use_live = a.use_live; P.ctx = w.ctx;
+    P.use_live = a.use_live; P.ctx = w.ctx; P.items = w.items;
     P.pp_l0 = a.pp_l0; P.pp_l1 = a.pp_l1; P.pp_first = a.pp_first;
     P.out = a.out; P.steps = a.steps;
     P.grad_out = a.grad_out; P.out_fwd = a.out_fwd;

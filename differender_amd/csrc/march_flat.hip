@@ -516,15 +516,15 @@ __device__ __forceinline__ void scatter_sample(unsigned long long *dbox, const T
 // non-finite component or above the robust cap do not count (their contributions take the exact clamped path). All loads
 // of a thread are independent and issued together with the box staging.
 template <typename VT, int FNT>
-__device__ __forceinline__ void cand_grad_range(const BrickParams<VT> &P, const BrickCtx &c, int view, int ncand, float &gmax,
-                                                float &gmin) {
+__device__ __forceinline__ void cand_grad_range(const BrickParams<VT> &P, const BrickCtx &c, int view, int c_lo, int ncand,
+                                                float &gmax, float &gmin) {
     const float cap = __uint_as_float(P.stats[ST_GCAP]);
     const size_t vb = (size_t)view * P.W * P.H;
     const float4 *go4 = reinterpret_cast<const float4 *>(P.grad_out) + vb;
     const int nj = c.j1 - c.j0 + 1;
     const float rnj = __builtin_amdgcn_rcpf((float)nj);
     gmax = 0.0f; gmin = 3.0e38f;
-    for (int cc = threadIdx.x; cc < ncand; cc += FNT) {
+    for (int cc = c_lo + threadIdx.x; cc < ncand; cc += FNT) {
         const int qi = (ncand < (1 << 21)) ? (int)(((float)cc + 0.5f) * rnj) : cc / nj;  // see cand_load
         const int pl = (c.i0 + qi) * P.H + c.j0 + (cc - qi * nj);
         const float4 g = go4[pl];
@@ -544,21 +544,26 @@ __device__ __forceinline__ float wave_min_f(float v) {
 }
 
 // ALPHA (forward only): the alpha pre-pass -- centre tap + TF only, the partial of a segment is its accumulated alpha.
+// One work item: the candidate pixels [c_lo, c_hi) of one brick of one view (c_hi is clamped to the brick's candidate
+// count). The main launch gives every brick its first MAIN_CAND candidates; bricks with more -- a camera close to or
+// inside the volume: the brick around the eye is a candidate of every pixel -- had the rest cut into items of ITEM_CAND
+// candidates by brick_ctx_kernel, which a second, small launch works off (brick_flat_items_kernel). Without that, the few
+// bricks next to the camera would each be one workgroup's job: 61 ms instead of 6 for a 512^2 view from inside a 512^3 volume.
 template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, bool ALPHA = false, int KF = 1>
-__global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FWD_WAVES) void brick_flat_kernel(BrickParams<VT> P) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (ALPHA && P.vflags[blockIdx.y] == 0u) return;  // uniform: no ray of this view can terminate early
+__device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsigned char *smem, const int brick, const int view,
+                                                const int c_lo, const int c_hi) {
+    if (ALPHA && P.vflags[view] == 0u) return;  // uniform: no ray of this view can terminate early
     constexpr int EC = BWD ? FEC_BWD : FEC_FWD;
     constexpr int FNT = BWD ? FNT_BWD : FNT_FWD;
     constexpr int FNW = FNT / 64;
     constexpr int KS = BWD ? 1 : KF;  // consecutive samples per lane (forward and alpha pre-pass)
-    const int view = blockIdx.y;
+    const int nbricks = P.g.NBx * P.g.NBy * P.g.NBz;
     const f3 cam = make_f3(P.cam[3 * view], P.cam[3 * view + 1], P.cam[3 * view + 2]);
     BrickCtx c;
-    brick_ctx_load(P.ctx + (size_t)view * gridDim.x + blockIdx.x, c);  // uniform address: scalar loads
+    brick_ctx_load(P.ctx + (size_t)view * nbricks + brick, c);  // uniform address: scalar loads
     if (c.i0 > c.i1 || c.j0 > c.j1) return;  // uniform: the brick projects outside the image
     if (ALPHA) {  // uniform: is this brick part of this phase of the pre-pass? (camera inside the volume: one phase, all bricks)
-        if (P.vflags[gridDim.y + view] ? !P.pp_first : (c.layer < P.pp_l0 || c.layer >= P.pp_l1)) return;
+        if (P.vflags[P.n_views + view] ? !P.pp_first : (c.layer < P.pp_l0 || c.layer >= P.pp_l1)) return;
     }
     // backward after a flat forward: bricks in which the forward marched nothing (rays terminated before them) have no work
     if (BWD && !DR_PHASE_TIMING && c.live == 0 && P.stats[ST_MARK] == DR_CTX_MARK) return;  // uniform
@@ -571,13 +576,15 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
     vol.p += view * P.vol_vs;
     const int NP = P.W * P.H;
     const size_t seg_view = (size_t)view * P.g.NL * NP;  // this view's [layer][pixel] slots
-    const int ncand = (c.i1 - c.i0 + 1) * (c.j1 - c.j0 + 1);
+    const int ncand_all = (c.i1 - c.i0 + 1) * (c.j1 - c.j0 + 1);
+    const int ncand = min(ncand_all, c_hi);  // this item's candidates: [c_lo, ncand)
+    if (c_lo >= ncand) return;               // uniform
 #if DR_PHASE_TIMING
     const long long tk0 = clock64();
     long long tk2 = 0;
 #endif
     CandData cd;
-    cand_load<VT, MODE, BWD, ALPHA>(P, c, view, 0, ncand, cd);  // ray buffers of the first round's candidates
+    cand_load<VT, MODE, BWD, ALPHA>(P, c, view, c_lo, ncand, cd);  // ray buffers of the first round's candidates
     BoxStage<FNT> stage;
     FixScale fs;
     int nE0, M0;
@@ -587,11 +594,11 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
     const bool lazy = (!BWD && !ALPHA && P.use_live && P.vflags[view] != 0u) || (ALPHA && !P.pp_first);  // uniform
     if (lazy) {
         flat_build_entries<VT, MODE, BWD, FNT, ALPHA, KS>(P, c, cam, view, cd, L, nE0, M0);
-        if (!__syncthreads_or(nE0 > 0) && ncand <= EC) return;  // uniform: no wave found a segment
+        if (!__syncthreads_or(nE0 > 0) && ncand - c_lo <= EC) return;  // uniform: no wave found a segment
         box_issue<VT, FNT>(P, vol, c, P.tf + view * P.tf_vs, stage);
     } else {
         float gm = 0.0f, gn = 3.0e38f;
-        if (BWD && WANT_VOL) cand_grad_range<VT, FNT>(P, c, view, ncand, gm, gn);  // upstream gradients of the candidates,
+        if (BWD && WANT_VOL) cand_grad_range<VT, FNT>(P, c, view, c_lo, ncand, gm, gn);  // upstream gradients of the candidates,
         box_issue<VT, FNT>(P, vol, c, P.tf + view * P.tf_vs, stage);      // voxel box + TF: in flight ...
         if (BWD) {
             if (WANT_VOL) for (int k = threadIdx.x; k < BOX_LDS; k += FNT) L.dbox[k] = 0ull;
@@ -627,9 +634,9 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     bool any = false;
 
-    for (int cbase = 0; cbase < ncand; cbase += EC) {
+    for (int cbase = c_lo; cbase < ncand; cbase += EC) {
         int nE = nE0, M = M0;
-        if (cbase > 0) {
+        if (cbase > c_lo) {
             cand_load<VT, MODE, BWD, ALPHA>(P, c, view, cbase, ncand, cd);
             flat_build_entries<VT, MODE, BWD, FNT, ALPHA, KS>(P, c, cam, view, cd, L, nE, M);  // syncs inside
         }
@@ -908,7 +915,7 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
                 if (v > 0) { P.seg_cnt[seg_view + L.segi[e]] = (uint16_t)min(v, 65535); some = true; }
             }
             if (!ALPHA && __any(some) && lane == 0)  // tell the backward that this brick holds live samples of the view
-                const_cast<BrickCtxRec *>(P.ctx)[(size_t)view * gridDim.x + blockIdx.x].live = 1;
+                const_cast<BrickCtxRec *>(P.ctx)[(size_t)view * nbricks + brick].live = 1;
         }
     }
 #if DR_PHASE_TIMING
@@ -953,6 +960,26 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
 #endif
 }
 
+constexpr int MAIN_CAND = CTX_MAIN_CAND;  // candidates of a brick the main launch handles (4 listing rounds); the rest become items
+constexpr int ITEM_GRID = 1024;  // workgroups of the overflow launch (they loop over the items)
+
+template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, bool ALPHA = false, int KF = 1>
+__global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FWD_WAVES) void brick_flat_kernel(BrickParams<VT> P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    brick_flat_body<VT, MODE, BWD, WANT_VOL, WANT_TF, ALPHA, KF>(P, smem, blockIdx.x, blockIdx.y, 0, MAIN_CAND);
+}
+// the overflow items of heavy bricks (all views), worked off by a fixed, small grid
+template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, bool ALPHA = false, int KF = 1>
+__global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FWD_WAVES) void brick_flat_items_kernel(BrickParams<VT> P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n_items = min((int)P.stats[ST_NITEMS], ITEM_CAP);
+    for (int it = blockIdx.x; it < n_items; it += gridDim.x) {  // uniform
+        const BrickItem item = P.items[it];
+        brick_flat_body<VT, MODE, BWD, WANT_VOL, WANT_TF, ALPHA, KF>(P, smem, item.brick, item.view, item.c0, item.c1);
+        __syncthreads();  // the next item reuses the LDS
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host
 // in-box element offsets are computed in 32 bits: 3 * (BOX-1) * max|stride| must stay below 2^31
 bool flat_strides_ok(int64_t sx, int64_t sy, int64_t sz) {
@@ -969,6 +996,15 @@ bool brick_path_supported(int VX, int VY, int VZ, int R) {
     return flat_lds_bytes<true>(R, true, true) <= 160 * 1024;
 }
 
+// one pass over the bricks: the main launch (one workgroup per brick and view) + the overflow items of heavy bricks
+#define DR_LAUNCH_BOTH(MODE_, BWD_, VOL_, TF_, ALPHA_, K_, NT_)                                                                       \
+    {                                                                                                                                 \
+        if ((e = allow_lds(brick_flat_kernel<VT, MODE_, BWD_, VOL_, TF_, ALPHA_, K_>, lds)) != hipSuccess) return (int)e;             \
+        if ((e = allow_lds(brick_flat_items_kernel<VT, MODE_, BWD_, VOL_, TF_, ALPHA_, K_>, lds)) != hipSuccess) return (int)e;       \
+        hipLaunchKernelGGL((brick_flat_kernel<VT, MODE_, BWD_, VOL_, TF_, ALPHA_, K_>), grid1, dim3(NT_), lds, stream, P);            \
+        hipLaunchKernelGGL((brick_flat_items_kernel<VT, MODE_, BWD_, VOL_, TF_, ALPHA_, K_>), dim3(ITEM_GRID), dim3(NT_), lds, stream, P); \
+    }
+
 template <typename VT>
 static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     const BrickGrid g = make_brick_grid(a.VX, a.VY, a.VZ);
@@ -983,6 +1019,7 @@ static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
 #endif
     e = hipMemsetAsync(w.seg_cnt, 0, w.cnt_bytes, stream);
     if (e != hipSuccess) return (int)e;
+    if ((e = hipMemsetAsync(w.stats + ST_NITEMS, 0, 4, stream)) != hipSuccess) return (int)e;  // brick_ctx_kernel appends the items
     const size_t lds = flat_lds_bytes<false>(a.R, false, false);
     const int nbricks = g.NBx * g.NBy * g.NBz;
     const dim3 grid1(nbricks, a.n_views);
@@ -1011,11 +1048,9 @@ static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
             pa.pp_l0 = g.NL * gi / G; pa.pp_l1 = g.NL * (gi + 1) / G; pa.pp_first = gi == 0;
             P.pp_l0 = pa.pp_l0; P.pp_l1 = pa.pp_l1; P.pp_first = pa.pp_first;
             if (a.mode == DR_MODE_DIFF) {
-                if ((e = allow_lds(brick_flat_kernel<VT, DR_MODE_DIFF, false, false, false, true, DR_ALPHA_K>, lds)) != hipSuccess) return (int)e;
-                hipLaunchKernelGGL((brick_flat_kernel<VT, DR_MODE_DIFF, false, false, false, true, DR_ALPHA_K>), grid1, dim3(FNT_FWD), lds, stream, P);
+                DR_LAUNCH_BOTH(DR_MODE_DIFF, false, false, false, true, DR_ALPHA_K, FNT_FWD)
             } else {
-                if ((e = allow_lds(brick_flat_kernel<VT, DR_MODE_NONDIFF, false, false, false, true, DR_ALPHA_K>, lds)) != hipSuccess) return (int)e;
-                hipLaunchKernelGGL((brick_flat_kernel<VT, DR_MODE_NONDIFF, false, false, false, true, DR_ALPHA_K>), grid1, dim3(FNT_FWD), lds, stream, P);
+                DR_LAUNCH_BOTH(DR_MODE_NONDIFF, false, false, false, true, DR_ALPHA_K, FNT_FWD)
             }
             if ((e = hipGetLastError()) != hipSuccess) return (int)e;
             const int rc = launch_ray_alpha(pa, stream);
@@ -1031,11 +1066,7 @@ static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     // Samples per lane: the cross-lane scan and the chunk bookkeeping are paid once per K*64 samples, but lanes K
     // samples apart share fewer LDS words (more read cycles, more bank conflicts). Measured at 512^3: K = 2 wins up
     // at sampling rate 1 (-3 %), K = 4 from 2 on (-13 % at 2, -16 % at 4 and 8 vs K = 1: samples are closer together); K = 8 loses.
-#define DR_LAUNCH_F1(MODE_, K_)                                                                                      \
-    {                                                                                                                \
-        if ((e = allow_lds(brick_flat_kernel<VT, MODE_, false, false, false, false, K_>, lds)) != hipSuccess) return (int)e; \
-        hipLaunchKernelGGL((brick_flat_kernel<VT, MODE_, false, false, false, false, K_>), grid1, dim3(FNT_FWD), lds, stream, P); \
-    }
+#define DR_LAUNCH_F1(MODE_, K_) DR_LAUNCH_BOTH(MODE_, false, false, false, false, K_, FNT_FWD)
     const bool k_hi = a.sr >= 1.75f;
     if (a.mode == DR_MODE_DIFF) { if (k_hi) DR_LAUNCH_F1(DR_MODE_DIFF, DR_FWD_K_HI) else DR_LAUNCH_F1(DR_MODE_DIFF, DR_FWD_K) }
     else { if (k_hi) DR_LAUNCH_F1(DR_MODE_NONDIFF, DR_FWD_K_HI) else DR_LAUNCH_F1(DR_MODE_NONDIFF, DR_FWD_K) }
@@ -1068,16 +1099,9 @@ static int flat_bwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     hipLaunchKernelGGL(gradstat_kernel, dim3((unsigned)(nb > 1024 ? 1024 : nb)), dim3(256), 0, stream, a.grad_out, ng,
                        w.stats + ST_HIST);
     hipLaunchKernelGGL(brick_ctx_kernel<VT>, dim3((grid1.x + 255) / 256, a.n_views), dim3(256), 0, stream, P, w.ctx, (int)grid1.x, 0, 0.0f);
-    if (wv && wt) {
-        if ((e = allow_lds(brick_flat_kernel<VT, DR_MODE_DIFF, true, true, true>, lds)) != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((brick_flat_kernel<VT, DR_MODE_DIFF, true, true, true>), grid1, dim3(FNT_BWD), lds, stream, P);
-    } else if (wv) {
-        if ((e = allow_lds(brick_flat_kernel<VT, DR_MODE_DIFF, true, true, false>, lds)) != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((brick_flat_kernel<VT, DR_MODE_DIFF, true, true, false>), grid1, dim3(FNT_BWD), lds, stream, P);
-    } else {
-        if ((e = allow_lds(brick_flat_kernel<VT, DR_MODE_DIFF, true, false, true>, lds)) != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((brick_flat_kernel<VT, DR_MODE_DIFF, true, false, true>), grid1, dim3(FNT_BWD), lds, stream, P);
-    }
+    if (wv && wt) DR_LAUNCH_BOTH(DR_MODE_DIFF, true, true, true, false, 1, FNT_BWD)
+    else if (wv) DR_LAUNCH_BOTH(DR_MODE_DIFF, true, true, false, false, 1, FNT_BWD)
+    else DR_LAUNCH_BOTH(DR_MODE_DIFF, true, false, true, false, 1, FNT_BWD)
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
     MarchArgs b = a;
     b.only_flagged = w.rayflag;  // B2: irregular rays through the baseline backward
