@@ -205,9 +205,43 @@ struct CandData {
     int n; float entry, exit_, vx, vy, vz;
     int live; unsigned char rflag;
 };
+constexpr int MAIN_CAND = CTX_MAIN_CAND;  // candidates of a brick the main launch handles (4 listing rounds); the rest become items
+
+// Pinhole geometry of a view, for the geometric pre-test of the candidates of HEAVY bricks (more candidate pixels than the
+// main launch takes: the bounding rectangle of a brick next to the eye is mostly pixels whose lines miss it): the line
+// of pixel (i, j) runs along dn + u * rw + v * uh.
+struct CamBasis { f3 dn, rw, uh; bool heavy; };
+template <typename VT>
+__device__ __forceinline__ CamBasis make_cam_basis(const BrickParams<VT> &P, f3 cam, bool heavy) {
+    CamBasis b;
+    b.heavy = heavy;
+    if (!heavy) { b.dn = b.rw = b.uh = make_f3(0.f, 0.f, 0.f); return b; }
+    const f3 vdir = normalized3(make_f3(-cam.x, -cam.y, -cam.z));
+    const f3 right = normalized3(cross3b(vdir, make_f3(0.f, 1.f, 0.f)));
+    const f3 up = normalized3(cross3b(right, vdir));
+    b.dn = make_f3(P.near_ * vdir.x, P.near_ * vdir.y, P.near_ * vdir.z);
+    b.rw = make_f3(P.near_w * right.x, P.near_w * right.y, P.near_w * right.z);
+    b.uh = make_f3(P.near_h * up.x, P.near_h * up.y, P.near_h * up.z);
+    return b;
+}
+// does the LINE cam + t * d (any t) meet the brick's (slack-widened) box?
+__device__ __forceinline__ bool line_meets_brick(const BrickCtx &c, f3 cam, f3 d) {
+    const float o[3] = {cam.x, cam.y, cam.z}, dd[3] = {d.x, d.y, d.z};
+    float ta = -3.0e38f, tb = 3.0e38f;
+    for (int k = 0; k < 3; ++k) {
+        if (fabsf(dd[k]) < 1e-12f) {
+            if (o[k] < c.lo[k] || o[k] > c.hi[k]) return false;
+        } else {
+            const float inv = __builtin_amdgcn_rcpf(dd[k]);
+            const float t1 = (c.lo[k] - o[k]) * inv, t2 = (c.hi[k] - o[k]) * inv;
+            ta = fmaxf(ta, fminf(t1, t2)); tb = fminf(tb, fmaxf(t1, t2));
+        }
+    }
+    return ta <= tb;  // (the box carries BRICK_EPS of slack: far more than the rounding of the stored ray directions)
+}
 template <typename VT, int MODE, bool BWD, bool ALPHA>
 __device__ __forceinline__ void cand_load(const BrickParams<VT> &P, const BrickCtx &c, int view, int cbase, int ncand,
-                                          CandData &d) {
+                                          const CamBasis &cb, f3 cam, CandData &d) {
     constexpr int EC = BWD ? FEC_BWD : FEC_FWD;
     constexpr int FNW = (BWD ? FNT_BWD : FNT_FWD) / 64, CW = EC / FNW;  // candidates per wave and round
     const int NP = P.W * P.H;
@@ -226,6 +260,12 @@ __device__ __forceinline__ void cand_load(const BrickParams<VT> &P, const BrickC
     // its error is <= 2^-22 * ni, so ni * nj < 2^21 is safe (checked exhaustively up to 1100 x 1100 with rcp +- 1 ulp)
     const int qi = (ncand < (1 << 21)) ? (int)(((float)cc + 0.5f) * __builtin_amdgcn_rcpf((float)nj)) : cc / nj;
     const int i = c.i0 + qi, j = c.j0 + (cc - qi * nj);
+    if (cb.heavy) {  // uniform
+        const float u = ((float)(i + P.row0) + 0.5f) / (float)P.imgW - 0.5f, v = ((float)j + 0.5f) / (float)P.H - 0.5f;
+        const f3 dir = make_f3(fmaf(v, cb.uh.x, fmaf(u, cb.rw.x, cb.dn.x)), fmaf(v, cb.uh.y, fmaf(u, cb.rw.y, cb.dn.y)),
+                               fmaf(v, cb.uh.z, fmaf(u, cb.rw.z, cb.dn.z)));
+        if (!line_meets_brick(c, cam, dir)) { d.have = false; return; }
+    }
     d.pl = i * P.H + j;
     d.p = (size_t)view * NP + d.pl;
     d.n = P.nsamp[d.p];
@@ -549,7 +589,7 @@ __device__ __forceinline__ float wave_min_f(float v) {
 // inside the volume: the brick around the eye is a candidate of every pixel -- had the rest cut into items of ITEM_CAND
 // candidates by brick_ctx_kernel, which a second, small launch works off (brick_flat_items_kernel). Without that, the few
 // bricks next to the camera would each be one workgroup's job: 61 ms instead of 6 for a 512^2 view from inside a 512^3 volume.
-template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, bool ALPHA = false, int KF = 1>
+template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, bool ALPHA, int KF, bool HEAVY>
 __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsigned char *smem, const int brick, const int view,
                                                 const int c_lo, const int c_hi) {
     if (ALPHA && P.vflags[view] == 0u) return;  // uniform: no ray of this view can terminate early
@@ -583,8 +623,9 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
     const long long tk0 = clock64();
     long long tk2 = 0;
 #endif
+    const CamBasis cbasis = make_cam_basis(P, cam, HEAVY);  // (only the overflow items of heavy bricks pre-test their candidates)
     CandData cd;
-    cand_load<VT, MODE, BWD, ALPHA>(P, c, view, c_lo, ncand, cd);  // ray buffers of the first round's candidates
+    cand_load<VT, MODE, BWD, ALPHA>(P, c, view, c_lo, ncand, cbasis, cam, cd);  // ray buffers of the first round's candidates
     BoxStage<FNT> stage;
     FixScale fs;
     int nE0, M0;
@@ -637,7 +678,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
     for (int cbase = c_lo; cbase < ncand; cbase += EC) {
         int nE = nE0, M = M0;
         if (cbase > c_lo) {
-            cand_load<VT, MODE, BWD, ALPHA>(P, c, view, cbase, ncand, cd);
+            cand_load<VT, MODE, BWD, ALPHA>(P, c, view, cbase, ncand, cbasis, cam, cd);
             flat_build_entries<VT, MODE, BWD, FNT, ALPHA, KS>(P, c, cam, view, cd, L, nE, M);  // syncs inside
         }
         any = any || nE > 0;
@@ -960,13 +1001,12 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
 #endif
 }
 
-constexpr int MAIN_CAND = CTX_MAIN_CAND;  // candidates of a brick the main launch handles (4 listing rounds); the rest become items
 constexpr int ITEM_GRID = 1024;  // workgroups of the overflow launch (they loop over the items)
 
 template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, bool ALPHA = false, int KF = 1>
 __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FWD_WAVES) void brick_flat_kernel(BrickParams<VT> P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    brick_flat_body<VT, MODE, BWD, WANT_VOL, WANT_TF, ALPHA, KF>(P, smem, blockIdx.x, blockIdx.y, 0, MAIN_CAND);
+    brick_flat_body<VT, MODE, BWD, WANT_VOL, WANT_TF, ALPHA, KF, false>(P, smem, blockIdx.x, blockIdx.y, 0, MAIN_CAND);
 }
 // the overflow items of heavy bricks (all views), worked off by a fixed, small grid
 template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, bool ALPHA = false, int KF = 1>
@@ -975,7 +1015,7 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
     const int n_items = min((int)P.stats[ST_NITEMS], ITEM_CAP);
     for (int it = blockIdx.x; it < n_items; it += gridDim.x) {  // uniform
         const BrickItem item = P.items[it];
-        brick_flat_body<VT, MODE, BWD, WANT_VOL, WANT_TF, ALPHA, KF>(P, smem, item.brick, item.view, item.c0, item.c1);
+        brick_flat_body<VT, MODE, BWD, WANT_VOL, WANT_TF, ALPHA, KF, true>(P, smem, item.brick, item.view, item.c0, item.c1);
         __syncthreads();  // the next item reuses the LDS
     }
 }
