@@ -32,6 +32,12 @@ SIGNATURES = {
     "dr_march_bwd_rows": (_I, [_P, _I, _I, _I, _I, _L, _L, _L, _L, _P, _I, _L, _P, _P, _P, _P, _P,
                                _I, _I, _I, _I, _F, _D, _D, _I, _P, _P, _P, _L, _L, _L, _L, _P, _L, _P, _Z, _I, _I, _P]),
     "dr_march_bwd_variant": (_I, [_I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _I, _I, _I]),
+    "dr_comm_unique_id": (_I, [_P]),
+    "dr_comm_init_rank": (_I, [_c.POINTER(_P), _I, _P, _I]),
+    "dr_comm_init_all": (_I, [_c.POINTER(_P), _I, _c.POINTER(_I)]),
+    "dr_allreduce_f32": (_I, [_P, _P, _Z, _P]),
+    "dr_allreduce_gradients_f32": (_I, [_P, _P, _Z, _P, _Z, _P]),
+    "dr_comm_destroy": (_I, [_P]),
     "dr_mse_loss_grad": (_I, [_P, _P, _L, _F, _P, _P, _P]),
     "dr_tf_momentum_step": (_I, [_P, _P, _P, _I, _F, _F, _F, _P]),
 }
@@ -52,7 +58,7 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.dr_abi_version() != 5:
+        if handle.dr_abi_version() != 6:
             raise ImportError("libdifferender_hip.so ABI version mismatch; rebuild it")
         _lib = handle
     return _lib

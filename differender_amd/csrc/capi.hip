@@ -5,7 +5,44 @@
 #include "../../include/differender_hip.h"
 #include "dr_kernels.h"
 
+#include <mutex>
+#include <unordered_map>
+
 using namespace dr;
+
+namespace dr {
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device, size) instead of on every launch
+hipError_t allow_lds_impl(const void *kernel, size_t bytes) {
+    static std::mutex mu;
+    static std::unordered_map<const void *, std::unordered_map<int, size_t>> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t &have = done[kernel][dev];
+    if (have >= bytes) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) have = bytes;
+    return e;
+}
+}  // namespace dr
+
+namespace {
+// The library runs on the device that owns the caller's buffers, whatever the calling thread's current device is
+// (autograd calls backward from another thread than forward): switch for the duration of the call, restore afterwards.
+struct DeviceOf {
+    int prev = -1, dev = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceOf(const void *device_ptr) {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, device_ptr) != hipSuccess) { (void)hipGetLastError(); return; }  // not a device pointer we know: leave as is
+        dev = attr.device;
+        if (hipGetDevice(&prev) != hipSuccess) { prev = -1; return; }
+        if (prev != dev) err = hipSetDevice(dev); else prev = -1;
+    }
+    ~DeviceOf() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+}  // namespace
 
 extern "C" {
 
@@ -16,6 +53,7 @@ const char *dr_error_string(int code) {
         case 0: return "success";
         case DR_EINVAL: return "differender_hip: invalid argument";
         case DR_EUNSUPPORTED: return "differender_hip: unsupported configuration";
+        case DR_ECOLLECTIVE: return "differender_hip: RCCL reported an error";
         default: break;
     }
     if (code > 0) return hipGetErrorString((hipError_t)code);
@@ -35,6 +73,8 @@ int dr_ray_setup_rows(const float *cam, int n_views, int W, int H, int img_W, in
     if (n_views <= 0 || W <= 0 || H <= 0 || VX < 2 || VY < 2 || VZ < 2) return DR_EINVAL;
     if (n_views > 65535 || !(sampling_rate > 0.0f)) return DR_EINVAL;
     if (row0 < 0 || img_W < W || row0 > img_W - W) return DR_EINVAL;
+    DeviceOf guard(entry);
+    if (guard.err != hipSuccess) return (int)guard.err;
     return (int)launch_ray_setup(cam, n_views, W, H, img_W, row0, VX, VY, VZ, fov_rad, near_plane, sampling_rate,
                                  jitter_seed, view_base, entry, exit_, rays, nsamp, (hipStream_t)stream);
 }
@@ -79,6 +119,8 @@ int dr_march_fwd_rows(const void *vol, int vol_dtype, int VX, int VY, int VZ, in
     a.img_W = img_W; a.row0 = row0;
     if (mode != DR_MODE_DIFF && mode != DR_MODE_NONDIFF) return DR_EINVAL;
     if (variant < DR_VARIANT_AUTO || variant > DR_VARIANT_BASELINE) return DR_EINVAL;
+    DeviceOf guard(vol);
+    if (guard.err != hipSuccess) return (int)guard.err;
     a.mode = mode; a.out = out_rgba; a.steps = steps;
     a.fov_rad = fov_rad; a.near_plane = near_plane; a.workspace = workspace; a.workspace_bytes = workspace_bytes;
     if (variant != DR_VARIANT_BASELINE && workspace && brick_path_supported(VX, VY, VZ, R) &&
@@ -124,6 +166,8 @@ int dr_march_bwd_rows(const void *vol, int vol_dtype, int VX, int VY, int VZ, in
     if (variant < DR_VARIANT_AUTO || variant > DR_VARIANT_BASELINE) return DR_EINVAL;
     if (dtf_view_stride % 4 != 0) return DR_EINVAL;
     if (!d_vol && !d_tf) return 0;  // nothing requested
+    DeviceOf guard(vol);
+    if (guard.err != hipSuccess) return (int)guard.err;
     a.mode = DR_MODE_DIFF;
     a.grad_out = grad_out; a.out_fwd = out_rgba;
     a.d_vol = d_vol; a.dsx = dsx; a.dsy = dsy; a.dsz = dsz; a.dvol_vs = dvol_view_stride;
@@ -153,12 +197,16 @@ int dr_march_bwd(const void *vol, int vol_dtype, int VX, int VY, int VZ, int64_t
 int dr_mse_loss_grad(const float *out_rgba, const float *reference, int64_t n, float inv_norm, float *grad_out,
                      double *loss, void *stream) {
     if (!out_rgba || !reference || n <= 0 || (!grad_out && !loss)) return DR_EINVAL;
+    DeviceOf guard(out_rgba);
+    if (guard.err != hipSuccess) return (int)guard.err;
     return (int)launch_mse_loss_grad(out_rgba, reference, n, inv_norm, grad_out, loss, (hipStream_t)stream);
 }
 
 int dr_tf_momentum_step(float *tf, const float *d_tf, float *momentum, int n, float lr, float gamma, float max_grad,
                         void *stream) {
     if (!tf || !d_tf || !momentum || n <= 0 || !(max_grad >= 0.0f)) return DR_EINVAL;
+    DeviceOf guard(tf);
+    if (guard.err != hipSuccess) return (int)guard.err;
     return (int)launch_tf_momentum_step(tf, d_tf, momentum, n, lr, gamma, max_grad, (hipStream_t)stream);
 }
 

@@ -489,10 +489,12 @@ static inline BrickParams<VT> make_brick_params(const MarchArgs &a, const Worksp
     return P;
 }
 
+// Dynamic LDS above 64 KB needs an explicit opt-in per kernel (and device); asked for once, not on every launch.
+hipError_t allow_lds_impl(const void *kernel, size_t bytes);
 template <typename K>
 static inline hipError_t allow_lds(K kernel, size_t bytes) {
     if (bytes <= 64 * 1024) return hipSuccess;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    return allow_lds_impl(reinterpret_cast<const void *>(kernel), bytes);
 }
 
 

@@ -200,10 +200,11 @@ static MarchParams<VT> make_params(const MarchArgs &a) {
     return P;
 }
 
+hipError_t allow_lds_impl(const void *kernel, size_t bytes);  // capi.hip
 template <typename K>
-static hipError_t big_lds(K kernel, size_t bytes) {  // dynamic LDS above 64 KB needs an explicit opt-in
+static hipError_t big_lds(K kernel, size_t bytes) {  // dynamic LDS above 64 KB needs an explicit opt-in (once per kernel)
     if (bytes <= 64 * 1024) return hipSuccess;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    return allow_lds_impl(reinterpret_cast<const void *>(kernel), bytes);
 }
 
 static dim3 tile_grid(const MarchArgs &a) {

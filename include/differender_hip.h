@@ -8,7 +8,9 @@
  *
  * Conventions
  *  - The library is stateless and re-entrant.  It allocates nothing; every buffer is owned by the
- *    caller (PyTorch on the Python side).  All pointers are DEVICE pointers on the current device.
+ *    caller (PyTorch on the Python side).  All pointers are DEVICE pointers of ONE device; each call runs on
+ *    the device that owns them (hipPointerGetAttributes), whatever the calling thread's current device is --
+ *    autograd runs backward on another thread than forward -- and restores the current device afterwards.
  *  - Work is enqueued on `stream` (a hipStream_t passed as void*); no call synchronises.
  *  - Return value: 0 on success, otherwise a hipError_t value (>0) or a DR_E* code (<0);
  *    dr_error_string() renders both.
@@ -31,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DR_ABI_VERSION 5
+#define DR_ABI_VERSION 6
 
 enum { DR_F32 = 0, DR_F16 = 1 };
 enum { DR_MODE_DIFF = 0, DR_MODE_NONDIFF = 1 };
@@ -42,7 +44,8 @@ enum { DR_VARIANT_AUTO = 0, DR_VARIANT_BASELINE = 1 };
 
 enum {
     DR_EINVAL = -1,      /* bad argument (null pointer, non-positive extent, unknown enum) */
-    DR_EUNSUPPORTED = -2 /* valid request this build cannot serve (e.g. TF too large for LDS) */
+    DR_EUNSUPPORTED = -2, /* valid request this build cannot serve (e.g. TF too large for LDS, RCCL not present) */
+    DR_ECOLLECTIVE = -3   /* RCCL reported an error */
 };
 
 int dr_abi_version(void);
@@ -146,6 +149,23 @@ int dr_march_bwd_rows(const void *vol, int vol_dtype, int VX, int VY, int VZ,
                       float *d_vol, int64_t dsx, int64_t dsy, int64_t dsz, int64_t dvol_view_stride,
                       float *d_tf, int64_t dtf_view_stride,
                       void *workspace, size_t workspace_bytes, int img_W, int row0, void *stream);
+
+/* The one exchange step of the path when views (or image bands) are sharded over the GPUs of a node: an in-place float32
+ * SUM all-reduce of the shared gradients over RCCL / xGMI (the reference is single-device and has no
+ * counterpart). For hosts without torch.distributed -- the Python package itself uses torch's "nccl" backend, which is the
+ * same RCCL. RCCL is dlopen()ed on first use (DR_EUNSUPPORTED if absent); a communicator is an opaque ncclComm_t.
+ *   one process per GPU:   rank 0 calls dr_comm_unique_id(id) and ships the 128 bytes to its peers by any means;
+ *                          every rank: hipSetDevice(its GPU); dr_comm_init_rank(&comm, n_ranks, id, rank)
+ *   one process, n GPUs:   dr_comm_init_all(comms, n, devices) (devices NULL = 0..n-1), then one thread (or a group) per device
+ *   per step:              dr_allreduce_gradients_f32(comm, d_vol, n_vol, d_tf, n_tf, stream)   (either may be NULL)
+ * d_volume must be ONE dense block of n_vol floats (any axis order: the sum is elementwise), as dr_march_bwd fills it when
+ * its strides describe a permutation of a contiguous tensor. The calls are asynchronous on `stream`. */
+int dr_comm_unique_id(void *id128);
+int dr_comm_init_rank(void **comm, int n_ranks, const void *id128, int rank);
+int dr_comm_init_all(void **comms, int n_devices, const int *devices);
+int dr_allreduce_f32(void *comm, float *buf, size_t n, void *stream);
+int dr_allreduce_gradients_f32(void *comm, float *d_vol, size_t n_vol, float *d_tf, size_t n_tf, void *stream);
+int dr_comm_destroy(void *comm);
 
 /* Image loss and its gradient, one pass over the rendered image (the step after the march in an optimisation
  * loop): replaces compute_loss (examples/taichi_volume_raycaster.py:368-373, "EX.py") and the torch mse_loss

@@ -25,8 +25,15 @@ def test_library_exports_every_declared_symbol(hiplib):
     for s in _declared_symbols():
         assert hasattr(raw, s), f"{s} declared in include/differender_hip.h but not exported"
         assert s in N.SIGNATURES, f"{s} has no ctypes signature in differender_amd/_native.py"
-    assert hiplib.dr_abi_version() == 5
+    assert hiplib.dr_abi_version() == 6
     assert b"invalid" in hiplib.dr_error_string(-1)
+
+
+def test_collective_shim_validates_without_loading_rccl(hiplib):
+    assert hiplib.dr_allreduce_f32(None, None, 4, None) == -1
+    assert hiplib.dr_comm_destroy(None) == -1
+    assert hiplib.dr_comm_init_rank(None, 2, None, 0) == -1
+    assert b"RCCL" in hiplib.dr_error_string(-3)
 
 
 def test_argument_validation_needs_no_gpu(hiplib):

@@ -7,10 +7,10 @@ src=differender_amd/csrc; out=ab_libs/obj_$name
 mkdir -p $out
 COMMON="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -munsafe-fp-atomics -ffp-contract=off -fno-slp-vectorize"
 pids=()
-for f in capi ray_setup march_baseline ray_passes march_flat epilogue; do
+for f in capi ray_setup march_baseline ray_passes march_flat epilogue collective; do
   /opt/rocm/bin/hipcc $COMMON "$@" -c $src/$f.hip -o $out/$f.o & pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ab_libs/$name.so $out/*.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ab_libs/$name.so $out/*.o -ldl
 rm -rf $out
 echo built ab_libs/$name.so
