@@ -37,7 +37,8 @@ struct BrickParams {
     int use_live;        // forward: ws_steps holds each ray's exact live sample count (from the alpha pre-pass)
     int pp_l0, pp_l1, pp_first;  // alpha pre-pass phase: brick layers [pp_l0, pp_l1); later phases skip terminated rays
     const struct BrickCtxRec *ctx;  // [view][brick]: brick geometry + pixel rectangle, filled once per forward call
-    BrickItem *items;               // overflow work items of heavy bricks (count in stats[ST_NITEMS])
+    BrickItem *items;               // overflow work items of heavy bricks
+    unsigned int *n_items;          // ... and how many there are
     float *out; int32_t *steps;
     const float *grad_out, *out_fwd;
     GradView dvol; int64_t dvol_vs;
@@ -50,7 +51,7 @@ enum {
     ST_GCAP = 1,           // backward: bits of the robust cap on |grad_out| (gradstat_kernel + brick_ctx_kernel)
     ST_BASELINE_RAYS = 2,  // rays the per-ray fallback marched in the last forward (irregular rays + repaired ones)
     ST_MARK = 3,           // DR_CTX_MARK once the flat forward has written brick records and live flags
-    ST_NITEMS = 5,         // overflow work items of the last forward (heavy bricks: see BrickItem); zeroed with seg_cnt
+    ST_NITEMS = 5,         // diagnostic copy of the number of overflow work items of the last forward (heavy bricks: BrickItem)
     ST_F64_BRICKS = 4,     // backward: (view, brick) pairs whose d_volume box accumulated in double (wide local range of |grad_out|)
     ST_TIMING = 16,        // DR_PHASE_TIMING: u64 x3 forward phases, u64 x3 backward phases, u64 backward lifetime
     ST_HIST = 64,          // backward: 256-bin histogram of the exponents of grad_out's finite non-zero components
@@ -236,7 +237,7 @@ static __global__ __launch_bounds__(256) void brick_ctx_kernel(BrickParams<VT> P
         const int ncand = (c.i1 - c.i0 + 1) * (c.j1 - c.j0 + 1);
         const int item_cand = max(1024, ((P.W * P.H / 64) + 255) & ~255);
         for (int c0 = CTX_MAIN_CAND; c0 < ncand; c0 += item_cand) {
-            const unsigned int slot = atomicAdd(&P.stats[ST_NITEMS], 1u);
+            const unsigned int slot = atomicAdd(P.n_items, 1u);
             if (slot < (unsigned int)ITEM_CAP) P.items[slot] = BrickItem{view, b, c0, min(c0 + item_cand, ncand)};
         }
     }
@@ -415,6 +416,15 @@ __device__ __forceinline__ float fix_to_float(unsigned long long v, const FixSca
     return (float)((double)(long long)v * f.inv);
 }
 
+// Zeroes the segment counts between the alpha pre-pass and the forward march -- only if the pre-pass ran at all (some
+// view's TF can terminate rays); otherwise nothing was written since the forward's first memset.
+static __global__ __launch_bounds__(256) void clear_counts_if_prepass_kernel(uint4 *cnt, size_t n16, const unsigned int *vflags, int n_views) {
+    bool any = false;
+    for (int v = 0; v < n_views; ++v) any = any || vflags[v] != 0u;  // uniform
+    if (!any) return;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) cnt[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 // Exponent histogram of grad_out (finite, non-zero components): 256 bins in the workspace header, zeroed by the
 // caller. One pass over the upstream gradient; brick_ctx_kernel turns it into the robust cap.
 static __global__ __launch_bounds__(256) void gradstat_kernel(const float *x, size_t n, unsigned int *hist) {
@@ -431,7 +441,7 @@ static __global__ __launch_bounds__(256) void gradstat_kernel(const float *x, si
 
 // ------------------------------------------------------------------------------------------------ host
 struct Workspace {
-    float4 *seg_rgba; uint16_t *seg_cnt; int32_t *ws_steps; uint8_t *rayflag; unsigned int *stats, *vflags;
+    float4 *seg_rgba; uint16_t *seg_cnt; int32_t *ws_steps; uint8_t *rayflag; unsigned int *stats, *vflags, *n_items;
     BrickCtxRec *ctx;
     BrickItem *items;
     size_t cnt_bytes;
@@ -447,6 +457,9 @@ static inline size_t ws_layout(void *base, int n_views, int NP, const BrickGrid 
     o += align16((size_t)n_views * 8);
     if (w) w->seg_rgba = reinterpret_cast<float4 *>(b + o);
     o += nseg * 16;
+    // 16 bytes in front of seg_cnt hold the count of overflow work items: the forward's first memset zeroes both
+    if (w) w->n_items = reinterpret_cast<unsigned int *>(b + o);
+    o += 16;
     if (w) { w->seg_cnt = reinterpret_cast<uint16_t *>(b + o); w->cnt_bytes = nseg * 2; }
     o += align16(nseg * 2);
     if (w) w->ws_steps = reinterpret_cast<int32_t *>(b + o);
@@ -480,7 +493,7 @@ static inline BrickParams<VT> make_brick_params(const MarchArgs &a, const Worksp
     P.near_ = (float)a.near_plane; P.near_h = (float)near_h; P.near_w = (float)(near_h * ((double)P.imgW / (double)a.H));
     P.g = make_brick_grid(a.VX, a.VY, a.VZ);
     P.seg_rgba = w.seg_rgba; P.seg_cnt = w.seg_cnt; P.rayflag = w.rayflag; P.stats = w.stats; P.vflags = w.vflags; P.n_views = a.n_views; P.ws_steps = w.ws_steps;
-    P.use_live = a.use_live; P.ctx = w.ctx; P.items = w.items;
+    P.use_live = a.use_live; P.ctx = w.ctx; P.items = w.items; P.n_items = w.n_items;
     P.pp_l0 = a.pp_l0; P.pp_l1 = a.pp_l1; P.pp_first = a.pp_first;
     P.out = a.out; P.steps = a.steps;
     P.grad_out = a.grad_out; P.out_fwd = a.out_fwd;

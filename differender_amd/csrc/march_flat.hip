@@ -1012,7 +1012,8 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
 template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, bool ALPHA = false, int KF = 1>
 __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FWD_WAVES) void brick_flat_items_kernel(BrickParams<VT> P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int n_items = min((int)P.stats[ST_NITEMS], ITEM_CAP);
+    const int n_items = min((int)*P.n_items, ITEM_CAP);
+    if (blockIdx.x == 0 && threadIdx.x == 0) P.stats[ST_NITEMS] = *P.n_items;
     for (int it = blockIdx.x; it < n_items; it += gridDim.x) {  // uniform
         const BrickItem item = P.items[it];
         brick_flat_body<VT, MODE, BWD, WANT_VOL, WANT_TF, ALPHA, KF, true>(P, smem, item.brick, item.view, item.c0, item.c1);
@@ -1057,9 +1058,8 @@ static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
 #if DR_PHASE_TIMING
     if ((e = hipMemsetAsync(w.stats + ST_TIMING, 0, 64, stream)) != hipSuccess) return (int)e;  // the timing slots
 #endif
-    e = hipMemsetAsync(w.seg_cnt, 0, w.cnt_bytes, stream);
+    e = hipMemsetAsync(w.n_items, 0, 16 + w.cnt_bytes, stream);  // the item counter (brick_ctx_kernel appends) and seg_cnt behind it
     if (e != hipSuccess) return (int)e;
-    if ((e = hipMemsetAsync(w.stats + ST_NITEMS, 0, 4, stream)) != hipSuccess) return (int)e;  // brick_ctx_kernel appends the items
     const size_t lds = flat_lds_bytes<false>(a.R, false, false);
     const int nbricks = g.NBx * g.NBy * g.NBz;
     const dim3 grid1(nbricks, a.n_views);
@@ -1098,7 +1098,9 @@ static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
         }
         const int rc2 = launch_ray_cross(a, stream);
         if (rc2) return rc2;
-        if ((e = hipMemsetAsync(w.seg_cnt, 0, w.cnt_bytes, stream)) != hipSuccess) return (int)e;
+        const size_t n16 = (w.cnt_bytes + 15) / 16;  // (seg_cnt is 16-byte aligned and padded)
+        hipLaunchKernelGGL(clear_counts_if_prepass_kernel, dim3((unsigned)((n16 + 255) / 256 < 4096 ? (n16 + 255) / 256 : 4096)), dim3(256), 0,
+                           stream, reinterpret_cast<uint4 *>(w.seg_cnt), n16, w.vflags, a.n_views);
     }
     MarchArgs b = a;
     b.use_live = prepass ? 1 : 0;

@@ -74,17 +74,24 @@ __global__ __launch_bounds__(256) void ray_compose_kernel(BrickParams<VT> P) {
             // Composite the partials front to back, leaving the prefix before each segment for the backward. Without a
             // pre-pass no ray can reach alpha 0.99 (may_terminate() bounds it below 0.98), so there is no crossing to look
             // for. Safety net: the segments must account for every sample, else this ray is marched whole below.
+            // (four layers per step, their loads issued together: the walk is a chain of memory latencies otherwise)
             int total = 0;
-            for (int l = 0; l <= l_hi; ++l) {
-                const size_t si = seg0 + (size_t)l * NP;
-                const int cnt = P.seg_cnt[si];
-                if (cnt == 0) continue;
-                const float4 sg = P.seg_rgba[si];
-                if (MODE == DR_MODE_DIFF) P.seg_rgba[si] = make_float4(C0, C1, C2, A);  // prefix for the backward
-                const float T = 1.0f - A;
-                C0 = fmaf(T, sg.x, C0); C1 = fmaf(T, sg.y, C1); C2 = fmaf(T, sg.z, C2);
-                A = fmaf(T, sg.w, A);
-                total += cnt;
+            for (int l = 0; l <= l_hi; l += 4) {
+                int cnt[4];
+                float4 sg[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) cnt[k] = (l + k <= l_hi) ? (int)P.seg_cnt[seg0 + (size_t)(l + k) * NP] : 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sg[k] = cnt[k] ? P.seg_rgba[seg0 + (size_t)(l + k) * NP] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (cnt[k] == 0) continue;
+                    if (MODE == DR_MODE_DIFF) P.seg_rgba[seg0 + (size_t)(l + k) * NP] = make_float4(C0, C1, C2, A);  // prefix for the backward
+                    const float T = 1.0f - A;
+                    C0 = fmaf(T, sg[k].x, C0); C1 = fmaf(T, sg[k].y, C1); C2 = fmaf(T, sg[k].z, C2);
+                    A = fmaf(T, sg[k].w, A);
+                    total += cnt[k];
+                }
             }
             steps = nmarch;
             if (total != nmarch) { regular = false; nmarch = nfull; atomicAdd(&P.stats[ST_REPAIR], 1u); }

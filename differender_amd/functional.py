@@ -93,7 +93,8 @@ def alloc_workspace(n_views, out_shape, vol_shape, R, device):
 def workspace_stats(workspace):
     """Diagnostics the last forward left in the workspace header: [0] = rays whose segments failed the
     sample-count check and were marched individually (expected 0), [2] = all rays the per-ray fallback marched
-    (those plus the irregular ones: single-sample rays)."""
+    (those plus the irregular ones: single-sample rays), [4] = bricks whose d_volume box accumulated in double (last
+    backward), [5] = overflow work items heavy bricks were cut into."""
     return workspace[:32].view(torch.int32).cpu()
 
 
