@@ -183,7 +183,7 @@ def traffic_bytes(pm, want_bwd_kernel):
     this access pattern: tools/microbench/fetch_calib.hip, profiles/r01_fetch_calibration.txt). WRITE_SIZE is exact for
     16-B stores and float atomics. Both are in KB. Memory-side requests include Infinity-Cache hits: an upper bound."""
     for k, v in pm.items():
-        if "brick_flat_kernel" not in k or "FETCH_SIZE" not in v:
+        if "brick_flat_kernel<" not in k or "FETCH_SIZE" not in v:
             continue
         targs = [t.strip(" >") for t in k.split("<")[1].split(",")]  # <VT, MODE, BWD, VOL, TF, ALPHA, K>
         if len(targs) >= 6 and targs[5] == "true":

@@ -818,6 +818,13 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                         }
                     }
                     vm_fwd[j] = __ballot(vj);
+#ifdef DR_LANE_STATS
+                    if (lane == 0 && j < ks) {  // lane slots issued / holding a listed sample / holding an in-brick sample
+                        atomicAdd(reinterpret_cast<unsigned long long *>(P.stats + ST_TIMING + 32), 64ull);
+                        atomicAdd(reinterpret_cast<unsigned long long *>(P.stats + ST_TIMING + 34), (unsigned long long)__popcll(__ballot(actj)));
+                        atomicAdd(reinterpret_cast<unsigned long long *>(P.stats + ST_TIMING + 36), (unsigned long long)__popcll(vm_fwd[j]));
+                    }
+#endif
                     el = (j == 0) ? ej : over(el, ej);  // over(x, 0) == x exactly
                 }
             }
@@ -1087,6 +1094,8 @@ static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
         for (int gi = 0; gi < G; ++gi) {
             pa.pp_l0 = g.NL * gi / G; pa.pp_l1 = g.NL * (gi + 1) / G; pa.pp_first = gi == 0;
             P.pp_l0 = pa.pp_l0; P.pp_l1 = pa.pp_l1; P.pp_first = pa.pp_first;
+            // (several bricks per workgroup would quarter the cost of this launch when it is gated off -- 27 us of workgroup
+            // exits at 512^3 -- but the looped kernel needs 96 VGPRs instead of 66 and is 3-5 % slower when it runs)
             if (a.mode == DR_MODE_DIFF) {
                 DR_LAUNCH_BOTH(DR_MODE_DIFF, false, false, false, true, DR_ALPHA_K, FNT_FWD)
             } else {

@@ -342,7 +342,7 @@ static int ray_alpha_dispatch(const MarchArgs &a, hipStream_t stream, bool cross
     Workspace w;
     ws_layout(a.workspace, a.n_views, NP, g, &w);
     BrickParams<VT> P = make_brick_params<VT>(a, w);
-    const dim3 grid2((NP + 255) / 256, a.n_views), grid3((NP + 3) / 4 < 65535 ? (NP + 3) / 4 : 65535, a.n_views);
+    const dim3 grid2((NP + 255) / 256, a.n_views), grid3((NP + 3) / 4 < 16384 ? (NP + 3) / 4 : 16384, a.n_views);
     const size_t lds3 = (size_t)a.R * 16;
     if (a.mode == DR_MODE_DIFF) {
         if (!cross) hipLaunchKernelGGL((ray_alpha_kernel<VT, DR_MODE_DIFF>), grid2, dim3(256), 0, stream, P);
