@@ -6,7 +6,7 @@ TAG=${1:-r01}; shift
 OUT=gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-BENCH="python bench.py --steps 5 --warmup 2 --no-cpu-baseline $@"
+BENCH="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --pmc off $@"
 echo "== kernel trace =="
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_full.csv
@@ -15,7 +15,7 @@ import csv
 rows = list(csv.DictReader(open("$OUT/kernel_stats_full.csv")))
 with open("$OUT/kernel_stats.csv", "w") as f:
     w = csv.writer(f); w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
-    for r in rows[:14]:
+    for r in [r for r in rows if "dr::" in r["Name"] or "rocclr" in r["Name"]]:
         w.writerow([r["Name"][:110], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
 print(open("$OUT/kernel_stats.csv").read())
 PY
