@@ -48,13 +48,11 @@ struct BrickParams {
 // Workspace header (32-bit words). Written by the device only; read back by functional.workspace_stats().
 enum {
     ST_REPAIR = 0,         // rays whose segments failed the sample-count check and were marched whole (expected 0)
-    ST_GCAP = 1,           // backward: bits of the robust cap on |grad_out| (gradstat_kernel + brick_ctx_kernel)
     ST_BASELINE_RAYS = 2,  // rays the per-ray fallback marched in the last forward (irregular rays + repaired ones)
     ST_MARK = 3,           // DR_CTX_MARK once the flat forward has written brick records and live flags
     ST_NITEMS = 5,         // diagnostic copy of the number of overflow work items of the last forward (heavy bricks: BrickItem)
     ST_F64_BRICKS = 4,     // backward: (view, brick) pairs whose d_volume box accumulated in double (wide local range of |grad_out|)
     ST_TIMING = 16,        // DR_PHASE_TIMING: u64 x3 forward phases, u64 x3 backward phases, u64 backward lifetime
-    ST_HIST = 64,          // backward: 256-bin histogram of the exponents of grad_out's finite non-zero components
     ST_WORDS = 512         // header size in words (2 KiB)
 };
 
@@ -179,28 +177,9 @@ __device__ __forceinline__ unsigned int may_terminate(const float4 *t, int R, fl
     const float remain = powf(1.0f - op, n_max);  // transmittance left after the longest possible ray
     return (remain <= 0.02f) ? 1u : 0u;           // 0.01 is the exact bound; keep a margin
 }
-// Robust cap on |grad_out| from the exponent histogram (one wave): 2^12 times the upper edge of the bin that holds the
-// 99th percentile of the finite non-zero components. Pixels above it (a stray 1e30, an overflowed loss) do not set
-// any brick's fixed-point scale; their own contributions take the exact clamped path.
-__device__ __forceinline__ unsigned int grad_cap_bits(const unsigned int *hist) {
-    const int lane = threadIdx.x & 63;
-    unsigned int h[4], tot = 0;
-    for (int k = 0; k < 4; ++k) { h[k] = hist[4 * lane + k]; tot += h[k]; }
-    unsigned int incl = tot;
-    for (int o = 1; o < 64; o <<= 1) { const unsigned int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-    const unsigned int total = __shfl(incl, 63);
-    if (total == 0u) return __float_as_uint(1.0f);
-    const unsigned int want = total - total / 100u;   // first bin at which the cumulative count reaches 99 %
-    unsigned int cum = incl - tot;
-    int bin = 1000;
-    for (int k = 0; k < 4; ++k) { cum += h[k]; if (bin == 1000 && cum >= want) bin = 4 * lane + k; }
-    for (int o = 32; o > 0; o >>= 1) bin = min(bin, __shfl_xor(bin, o));
-    const int e = min(bin + 1 + 12, 254);             // upper edge of the bin (2^(bin-126)) times 2^12
-    return (unsigned int)e << 23;
-}
-// forward = 1 additionally initialises the workspace header for this call: repair counter, per-view "may terminate"
-// flags (n_max > 0: the alpha pre-pass is available) and the mark -- no separate memset / flag kernel.
-// forward = 0 (backward) turns the exponent histogram of grad_out into the cap (ST_GCAP).
+// Also initialises the workspace header for this call: counters, per-view "may terminate" flags (n_max > 0: the alpha
+// pre-pass is available) and the mark -- no separate memset / flag kernel. Runs once per forward; the backward of the same
+// inputs reuses the records (and the live flags the forward march leaves in them).
 template <typename VT>
 static __global__ __launch_bounds__(256) void brick_ctx_kernel(BrickParams<VT> P, BrickCtxRec *out, int nbricks, int forward,
                                                               float n_max) {
@@ -213,11 +192,8 @@ static __global__ __launch_bounds__(256) void brick_ctx_kernel(BrickParams<VT> P
                 const float lim = 1.0f + 1e-3f;
                 P.vflags[view] = flag;
                 P.vflags[P.n_views + view] = (fabsf(cx) <= lim && fabsf(cy) <= lim && fabsf(cz) <= lim) ? 1u : 0u;
-                if (view == 0) { P.stats[ST_REPAIR] = 0u; P.stats[ST_BASELINE_RAYS] = 0u; P.stats[ST_MARK] = DR_CTX_MARK; }
+                if (view == 0) { P.stats[ST_REPAIR] = 0u; P.stats[ST_BASELINE_RAYS] = 0u; P.stats[ST_F64_BRICKS] = 0u; P.stats[ST_MARK] = DR_CTX_MARK; }
             }
-        } else if (view == 0) {
-            const unsigned int cap = grad_cap_bits(P.stats + ST_HIST);
-            if (threadIdx.x == 0) { P.stats[ST_GCAP] = cap; P.stats[ST_F64_BRICKS] = 0u; }
         }
     }
     if (b >= nbricks) return;
@@ -322,16 +298,16 @@ __device__ __forceinline__ void load_ray(const float *entry, const float *exit_,
 // ds_add_f32 is serialised on gfx950 (193 cycles per wave-instruction whatever the addresses), ds_add_u64 takes 9-12 and
 // ds_add_f64 16-20, twice that per conflicting address (tools/microbench/lds_atomic_bench,
 // profiles/r02_microbench_lds_atomics.txt). Every accumulator is one 64-bit word, used in one of two formats:
-//   FIXED   64-bit fixed point with one scale PER BRICK (2^28 / the largest |grad_out| among the brick's candidate
-//           pixels), 32-bit addends rounded to nearest under a wave-uniform magnitude test, exact 64-bit addends
-//           otherwise. The fast format (d_volume at 512^3: 6.6 ms against 7.5 ms with doubles), but a contribution below
+//   FIXED   64-bit fixed point with one scale PER BRICK (2^28 / the largest finite |grad_out| among the brick's candidate
+//           pixels), 32-bit addends rounded to nearest under a wave-uniform magnitude test, 64-bit addends otherwise. The fast format (d_volume at 512^3: 6.6 ms against 7.5 ms with doubles), but a contribution below
 //           2^-29 of the brick's largest upstream gradient is lost.
 //   DOUBLE  the f32 contribution is widened (v_cvt_f64_f32: the cost of the float -> int conversion) and added with
 //           ds_add_f64: no scale, no dynamic-range limit.
 // d_tf always accumulates in DOUBLE (few conflicts after the run sums: it is the faster format there). d_volume uses
 // FIXED unless the brick's candidate pixels span more than 2^DR_MIXED_BITS in |grad_out| (smallest non-zero against
 // largest): then a voxel touched only by the small-gradient rays would lose precision, and the brick switches to
-// DOUBLE (brick-uniform branch; stats[ST_F64_BRICKS] counts them).
+// DOUBLE (brick-uniform branch; stats[ST_F64_BRICKS] counts them). A stray 1e30 or an infinity in grad_out is just such a
+// range: its brick goes to DOUBLE, where its ray's contributions are clamped and every other ray's stay exact.
 #ifndef DR_MIXED_BITS
 #define DR_MIXED_BITS 6
 #endif
@@ -359,8 +335,8 @@ struct FixScale {
     float lim;   // adjoints are clamped to +-lim = 2^20 * gmax (keeps every sum inside 63 bits)
     double inv;  // 2^-shift
 };
-// gmax = the largest |grad_out| component among the brick's candidate pixels (outliers above the robust cap excluded):
-// every brick has its own scale, so the resolution follows the local magnitude of the upstream gradient.
+// gmax = the largest |grad_out| component among the brick's candidate pixels: every brick has its own scale, so the
+// resolution follows the local magnitude of the upstream gradient.
 __device__ __forceinline__ FixScale make_fix_scale(float gmax) {
     if (!(gmax > 0.0f) || !(gmax < 3.0e38f)) gmax = 1.0f;  // all-zero upstream gradient
     int e;
@@ -423,20 +399,6 @@ static __global__ __launch_bounds__(256) void clear_counts_if_prepass_kernel(uin
     for (int v = 0; v < n_views; ++v) any = any || vflags[v] != 0u;  // uniform
     if (!any) return;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) cnt[i] = make_uint4(0u, 0u, 0u, 0u);
-}
-
-// Exponent histogram of grad_out (finite, non-zero components): 256 bins in the workspace header, zeroed by the
-// caller. One pass over the upstream gradient; brick_ctx_kernel turns it into the robust cap.
-static __global__ __launch_bounds__(256) void gradstat_kernel(const float *x, size_t n, unsigned int *hist) {
-    __shared__ unsigned int lh[256];
-    lh[threadIdx.x] = 0u;
-    __syncthreads();
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const unsigned int e = (__float_as_uint(x[i]) >> 23) & 0xffu;
-        if (e != 0u && e != 255u) atomicAdd(&lh[e], 1u);
-    }
-    __syncthreads();
-    if (lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------------ host

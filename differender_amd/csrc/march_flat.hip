@@ -552,13 +552,12 @@ __device__ __forceinline__ void scatter_sample(unsigned long long *dbox, const T
 }
 
 // Backward: the largest and the smallest non-zero |grad_out| (per pixel: its largest component) over the brick's
-// candidate pixels whose rays hit the volume, per thread (the caller reduces them over the workgroup). Pixels with a
-// non-finite component or above the robust cap do not count (their contributions take the exact clamped path). All loads
-// of a thread are independent and issued together with the box staging.
+// candidate pixels whose rays hit the volume, per thread (the caller reduces them over the workgroup). A NaN component is
+// ignored (that ray's adjoints are dropped); an infinite or absurd one simply makes the range huge, which sends the brick to
+// double accumulators. All loads of a thread are independent and issued together with the box staging.
 template <typename VT, int FNT>
 __device__ __forceinline__ void cand_grad_range(const BrickParams<VT> &P, const BrickCtx &c, int view, int c_lo, int ncand,
                                                 float &gmax, float &gmin) {
-    const float cap = __uint_as_float(P.stats[ST_GCAP]);
     const size_t vb = (size_t)view * P.W * P.H;
     const float4 *go4 = reinterpret_cast<const float4 *>(P.grad_out) + vb;
     const int nj = c.j1 - c.j0 + 1;
@@ -569,9 +568,8 @@ __device__ __forceinline__ void cand_grad_range(const BrickParams<VT> &P, const 
         const int pl = (c.i0 + qi) * P.H + c.j0 + (cc - qi * nj);
         const float4 g = go4[pl];
         const int n = P.nsamp[vb + pl];
-        const float a = fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w)));
-        const bool bad = !(fabsf(g.x) <= cap) || !(fabsf(g.y) <= cap) || !(fabsf(g.z) <= cap) || !(fabsf(g.w) <= cap);
-        if (!bad && n > 0 && a > 0.0f) { gmax = fmaxf(gmax, a); gmin = fminf(gmin, a); }
+        const float a = fmaxf(fmaxf(fabsf(g.x), fabsf(g.y)), fmaxf(fabsf(g.z), fabsf(g.w)));  // (NaN-suppressing)
+        if (n > 0 && a > 0.0f) { gmax = fmaxf(gmax, a); gmin = fminf(gmin, a); }
     }
 }
 __device__ __forceinline__ float wave_max_f(float v) {
@@ -661,7 +659,6 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
 #pragma unroll
         for (int k = 0; k < FNW; ++k) { gm = fmaxf(gm, L.gmax[k]); gn = fminf(gn, L.gmax[8 + k]); }
         acc64 = __builtin_amdgcn_readfirstlane((int)(gn * (float)(1 << DR_MIXED_BITS) < gm)) != 0;
-        if (!(gm > 0.0f)) gm = __uint_as_float(P.stats[ST_GCAP]);  // only outliers (or zeros) in this brick
         fs = make_fix_scale(gm);
         if (acc64 && threadIdx.x == 0) atomicAdd(&P.stats[ST_F64_BRICKS], 1u);
     }
@@ -1175,14 +1172,7 @@ static int flat_bwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     const size_t lds = flat_lds_bytes<true>(a.R, wv, wt);
     const dim3 grid1(g.NBx * g.NBy * g.NBz, a.n_views);
     hipError_t e = hipSuccess;
-    // robust cap on |grad_out| (exponent histogram -> 99th percentile x 2^12), then the brick records
-    e = hipMemsetAsync(w.stats + ST_HIST, 0, 256 * 4, stream);
-    if (e != hipSuccess) return (int)e;
-    const size_t ng = (size_t)a.n_views * NP * 4;
-    const size_t nb = (ng + 256 * 4 - 1) / (256 * 4);
-    hipLaunchKernelGGL(gradstat_kernel, dim3((unsigned)(nb > 1024 ? 1024 : nb)), dim3(256), 0, stream, a.grad_out, ng,
-                       w.stats + ST_HIST);
-    hipLaunchKernelGGL(brick_ctx_kernel<VT>, dim3((grid1.x + 255) / 256, a.n_views), dim3(256), 0, stream, P, w.ctx, (int)grid1.x, 0, 0.0f);
+    // (the brick records, live flags and work items are the forward's: same inputs, same workspace)
     if (wv && wt) DR_LAUNCH_BOTH(DR_MODE_DIFF, true, true, true, false, 1, FNT_BWD)
     else if (wv) DR_LAUNCH_BOTH(DR_MODE_DIFF, true, true, false, false, 1, FNT_BWD)
     else DR_LAUNCH_BOTH(DR_MODE_DIFF, true, false, true, false, 1, FNT_BWD)
