@@ -13,6 +13,7 @@ struct BrickItem { int view, brick, c0, c1; };
 constexpr int ITEM_CAP = 1 << 18;     // items the workspace holds, 4 MB (a 512^2 view from inside a 512^3 volume makes ~160 000;
                                       // items beyond the cap are dropped: their rays fail the count check and are marched whole)
 constexpr int CTX_MAIN_CAND = 1024;   // candidates of a brick the main launch takes (= MAIN_CAND of march_flat.hip)
+constexpr int CTX_ITEM_MAX_CAND = 4096;  // candidates per item at most (its list of hits: 16-bit offsets, 8 KB of LDS -- two backward workgroups still fit a CU)
 
 template <typename VT>
 struct BrickParams {
@@ -208,10 +209,10 @@ static __global__ __launch_bounds__(256) void brick_ctx_kernel(BrickParams<VT> P
     out[(size_t)view * nbricks + b] = r;
     if (forward && c.i0 <= c.i1 && c.j0 <= c.j1) {
         // a brick with more candidate pixels than the main launch takes: cut the rest into work items
-        // (item size: at least 1024 candidates, and large enough that one full-image brick makes at most 64 items; most
-        // candidates of such bricks fail the geometric pre-test of cand_load at once)
+        // (item size: 1024 to 4096 candidates, a full-image brick makes at most 64 items up to 512^2 pixels; most candidates of
+        // such bricks fail the item's geometric pre-test and cost nothing further)
         const int ncand = (c.i1 - c.i0 + 1) * (c.j1 - c.j0 + 1);
-        const int item_cand = max(1024, ((P.W * P.H / 64) + 255) & ~255);
+        const int item_cand = min(max(1024, ((P.W * P.H / 64) + 255) & ~255), CTX_ITEM_MAX_CAND);
         for (int c0 = CTX_MAIN_CAND; c0 < ncand; c0 += item_cand) {
             const unsigned int slot = atomicAdd(P.n_items, 1u);
             if (slot < (unsigned int)ITEM_CAP) P.items[slot] = BrickItem{view, b, c0, min(c0 + item_cand, ncand)};

@@ -206,6 +206,8 @@ struct CandData {
     int live; unsigned char rflag;
 };
 constexpr int MAIN_CAND = CTX_MAIN_CAND;  // candidates of a brick the main launch handles (4 listing rounds); the rest become items
+constexpr int ITEM_MAX_CAND = CTX_ITEM_MAX_CAND;  // candidates per overflow item at most (its list of hits lives in LDS: 2 B each)
+constexpr size_t ITEM_EXTRA_LDS = (size_t)ITEM_MAX_CAND * 2 + 16;
 
 // Pinhole geometry of a view, for the geometric pre-test of the candidates of HEAVY bricks (more candidate pixels than the
 // main launch takes: the bounding rectangle of a brick next to the eye is mostly pixels whose lines miss it): the line
@@ -239,9 +241,11 @@ __device__ __forceinline__ bool line_meets_brick(const BrickCtx &c, f3 cam, f3 d
     }
     return ta <= tb;  // (the box carries BRICK_EPS of slack: far more than the rounding of the stored ray directions)
 }
+// `hits` (overflow items of heavy bricks): the item's candidates that passed the geometric pre-test, as offsets from c_lo;
+// the rounds then run over [0, number of hits) instead of over the raw candidate range.
 template <typename VT, int MODE, bool BWD, bool ALPHA>
 __device__ __forceinline__ void cand_load(const BrickParams<VT> &P, const BrickCtx &c, int view, int cbase, int ncand,
-                                          const CamBasis &cb, f3 cam, CandData &d) {
+                                          const unsigned short *hits, int c_lo, int ncand_all, CandData &d) {
     constexpr int EC = BWD ? FEC_BWD : FEC_FWD;
     constexpr int FNW = (BWD ? FNT_BWD : FNT_FWD) / 64, CW = EC / FNW;  // candidates per wave and round
     const int NP = P.W * P.H;
@@ -250,22 +254,17 @@ __device__ __forceinline__ void cand_load(const BrickParams<VT> &P, const BrickC
     // go to different waves, so the waves of a workgroup get nearly equal shares of the brick's samples (the
     // slowest wave has 1.03 x the mean)
     const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
-    const int cc = cbase + lane_ * FNW + ((lane_ & 1) ? FNW - 1 - wave_ : wave_);  // dealt back and forth: -1.3 %
+    int cc = cbase + lane_ * FNW + ((lane_ & 1) ? FNW - 1 - wave_ : wave_);  // dealt back and forth: -1.3 %
     d.have = lane_ < CW && cc < ncand;
     d.pl = 0; d.p = 0; d.n = 0; d.entry = -1.0f; d.exit_ = 0.f; d.vx = d.vy = d.vz = 0.f;
     d.live = 0; d.rflag = 0;
     if (!d.have) return;
+    if (hits) cc = c_lo + (int)hits[cc];
     // cc / nj without the ~25-instruction integer division while the rectangle is small (always, unless the camera sits
     // inside the volume of a > 2-megapixel image): the float quotient of cc + 0.5 stays >= 0.5/nj away from an integer,
     // its error is <= 2^-22 * ni, so ni * nj < 2^21 is safe (checked exhaustively up to 1100 x 1100 with rcp +- 1 ulp)
-    const int qi = (ncand < (1 << 21)) ? (int)(((float)cc + 0.5f) * __builtin_amdgcn_rcpf((float)nj)) : cc / nj;
+    const int qi = (ncand_all < (1 << 21)) ? (int)(((float)cc + 0.5f) * __builtin_amdgcn_rcpf((float)nj)) : cc / nj;
     const int i = c.i0 + qi, j = c.j0 + (cc - qi * nj);
-    if (cb.heavy) {  // uniform
-        const float u = ((float)(i + P.row0) + 0.5f) / (float)P.imgW - 0.5f, v = ((float)j + 0.5f) / (float)P.H - 0.5f;
-        const f3 dir = make_f3(fmaf(v, cb.uh.x, fmaf(u, cb.rw.x, cb.dn.x)), fmaf(v, cb.uh.y, fmaf(u, cb.rw.y, cb.dn.y)),
-                               fmaf(v, cb.uh.z, fmaf(u, cb.rw.z, cb.dn.z)));
-        if (!line_meets_brick(c, cam, dir)) { d.have = false; return; }
-    }
     d.pl = i * P.H + j;
     d.p = (size_t)view * NP + d.pl;
     d.n = P.nsamp[d.p];
@@ -556,15 +555,16 @@ __device__ __forceinline__ void scatter_sample(unsigned long long *dbox, const T
 // ignored (that ray's adjoints are dropped); an infinite or absurd one simply makes the range huge, which sends the brick to
 // double accumulators. All loads of a thread are independent and issued together with the box staging.
 template <typename VT, int FNT>
-__device__ __forceinline__ void cand_grad_range(const BrickParams<VT> &P, const BrickCtx &c, int view, int c_lo, int ncand,
-                                                float &gmax, float &gmin) {
+__device__ __forceinline__ void cand_grad_range(const BrickParams<VT> &P, const BrickCtx &c, int view, int r_lo, int r_hi,
+                                                const unsigned short *hits, int c_lo, int ncand_all, float &gmax, float &gmin) {
     const size_t vb = (size_t)view * P.W * P.H;
     const float4 *go4 = reinterpret_cast<const float4 *>(P.grad_out) + vb;
     const int nj = c.j1 - c.j0 + 1;
     const float rnj = __builtin_amdgcn_rcpf((float)nj);
     gmax = 0.0f; gmin = 3.0e38f;
-    for (int cc = c_lo + threadIdx.x; cc < ncand; cc += FNT) {
-        const int qi = (ncand < (1 << 21)) ? (int)(((float)cc + 0.5f) * rnj) : cc / nj;  // see cand_load
+    for (int idx = r_lo + threadIdx.x; idx < r_hi; idx += FNT) {
+        const int cc = hits ? c_lo + (int)hits[idx] : idx;
+        const int qi = (ncand_all < (1 << 21)) ? (int)(((float)cc + 0.5f) * rnj) : cc / nj;  // see cand_load
         const int pl = (c.i0 + qi) * P.H + c.j0 + (cc - qi * nj);
         const float4 g = go4[pl];
         const int n = P.nsamp[vb + pl];
@@ -621,9 +621,43 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
     const long long tk0 = clock64();
     long long tk2 = 0;
 #endif
-    const CamBasis cbasis = make_cam_basis(P, cam, HEAVY);  // (only the overflow items of heavy bricks pre-test their candidates)
+    // The rounds run over candidate indices [r_lo, r_hi). An overflow item of a heavy brick first puts its candidates through
+    // the geometric pre-test (most of the bounding rectangle of a brick next to the eye are pixels whose lines miss it) and
+    // runs its rounds over the compacted list of hits, in LDS behind the regular layout; no hit, no work.
+    const unsigned short *hits = nullptr;
+    int r_lo = c_lo, r_hi = ncand;
+    if (HEAVY) {
+        unsigned short *hl = reinterpret_cast<unsigned short *>(smem + align16(flat_lds_bytes<BWD>(P.R, WANT_VOL, WANT_TF)));
+        int *nhit = reinterpret_cast<int *>(hl + ITEM_MAX_CAND);
+        if (threadIdx.x == 0) *nhit = 0;
+        __syncthreads();
+        const CamBasis cbasis = make_cam_basis(P, cam, true);
+        const int nj = c.j1 - c.j0 + 1;
+        const float rnj = __builtin_amdgcn_rcpf((float)nj);
+        for (int c0 = c_lo; c0 < ncand; c0 += FNT) {  // uniform
+            const int cc = c0 + (int)threadIdx.x;
+            bool hit = false;
+            if (cc < ncand) {
+                const int qi = (ncand_all < (1 << 21)) ? (int)(((float)cc + 0.5f) * rnj) : cc / nj;
+                const int i = c.i0 + qi, j = c.j0 + (cc - qi * nj);
+                const float u = ((float)(i + P.row0) + 0.5f) / (float)P.imgW - 0.5f, v = ((float)j + 0.5f) / (float)P.H - 0.5f;
+                const f3 dir = make_f3(fmaf(v, cbasis.uh.x, fmaf(u, cbasis.rw.x, cbasis.dn.x)), fmaf(v, cbasis.uh.y, fmaf(u, cbasis.rw.y, cbasis.dn.y)),
+                                       fmaf(v, cbasis.uh.z, fmaf(u, cbasis.rw.z, cbasis.dn.z)));
+                hit = line_meets_brick(c, cam, dir);
+            }
+            const unsigned long long hm = __ballot(hit);
+            int base = 0;
+            if ((threadIdx.x & 63) == 0 && hm) base = atomicAdd(nhit, __popcll(hm));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (hit) hl[base + __popcll(hm & ((1ull << (threadIdx.x & 63)) - 1ull))] = (unsigned short)(cc - c_lo);
+        }
+        __syncthreads();
+        hits = hl;
+        r_lo = 0; r_hi = *nhit;
+        if (r_hi == 0) return;  // uniform
+    }
     CandData cd;
-    cand_load<VT, MODE, BWD, ALPHA>(P, c, view, c_lo, ncand, cbasis, cam, cd);  // ray buffers of the first round's candidates
+    cand_load<VT, MODE, BWD, ALPHA>(P, c, view, r_lo, r_hi, hits, c_lo, ncand_all, cd);  // ray buffers of the first round's candidates
     BoxStage<FNT> stage;
     FixScale fs;
     int nE0, M0;
@@ -633,11 +667,11 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
     const bool lazy = (!BWD && !ALPHA && P.use_live && P.vflags[view] != 0u) || (ALPHA && !P.pp_first);  // uniform
     if (lazy) {
         flat_build_entries<VT, MODE, BWD, FNT, ALPHA, KS>(P, c, cam, view, cd, L, nE0, M0);
-        if (!__syncthreads_or(nE0 > 0) && ncand - c_lo <= EC) return;  // uniform: no wave found a segment
+        if (!__syncthreads_or(nE0 > 0) && r_hi - r_lo <= EC) return;  // uniform: no wave found a segment
         box_issue<VT, FNT>(P, vol, c, P.tf + view * P.tf_vs, stage);
     } else {
         float gm = 0.0f, gn = 3.0e38f;
-        if (BWD && WANT_VOL) cand_grad_range<VT, FNT>(P, c, view, c_lo, ncand, gm, gn);  // upstream gradients of the candidates,
+        if (BWD && WANT_VOL) cand_grad_range<VT, FNT>(P, c, view, r_lo, r_hi, hits, c_lo, ncand_all, gm, gn);  // upstream gradients of the candidates,
         box_issue<VT, FNT>(P, vol, c, P.tf + view * P.tf_vs, stage);      // voxel box + TF: in flight ...
         if (BWD) {
             if (WANT_VOL) for (int k = threadIdx.x; k < BOX_LDS; k += FNT) L.dbox[k] = 0ull;
@@ -672,10 +706,10 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     bool any = false;
 
-    for (int cbase = c_lo; cbase < ncand; cbase += EC) {
+    for (int cbase = r_lo; cbase < r_hi; cbase += EC) {
         int nE = nE0, M = M0;
-        if (cbase > c_lo) {
-            cand_load<VT, MODE, BWD, ALPHA>(P, c, view, cbase, ncand, cbasis, cam, cd);
+        if (cbase > r_lo) {
+            cand_load<VT, MODE, BWD, ALPHA>(P, c, view, cbase, r_hi, hits, c_lo, ncand_all, cd);
             flat_build_entries<VT, MODE, BWD, FNT, ALPHA, KS>(P, c, cam, view, cd, L, nE, M);  // syncs inside
         }
         any = any || nE > 0;
@@ -1078,9 +1112,9 @@ bool brick_path_supported(int VX, int VY, int VZ, int R) {
 #define DR_LAUNCH_BOTH(MODE_, BWD_, VOL_, TF_, ALPHA_, K_, NT_)                                                                       \
     {                                                                                                                                 \
         if ((e = allow_lds(brick_flat_kernel<VT, MODE_, BWD_, VOL_, TF_, ALPHA_, K_>, lds)) != hipSuccess) return (int)e;             \
-        if ((e = allow_lds(brick_flat_items_kernel<VT, MODE_, BWD_, VOL_, TF_, ALPHA_, K_>, lds)) != hipSuccess) return (int)e;       \
+        if ((e = allow_lds(brick_flat_items_kernel<VT, MODE_, BWD_, VOL_, TF_, ALPHA_, K_>, align16(lds) + ITEM_EXTRA_LDS)) != hipSuccess) return (int)e; \
         hipLaunchKernelGGL((brick_flat_kernel<VT, MODE_, BWD_, VOL_, TF_, ALPHA_, K_>), DR_GRID1, dim3(NT_), lds, stream, P);         \
-        hipLaunchKernelGGL((brick_flat_items_kernel<VT, MODE_, BWD_, VOL_, TF_, ALPHA_, K_>), dim3(ITEM_GRID), dim3(NT_), lds, stream, P); \
+        hipLaunchKernelGGL((brick_flat_items_kernel<VT, MODE_, BWD_, VOL_, TF_, ALPHA_, K_>), dim3(ITEM_GRID), dim3(NT_), align16(lds) + ITEM_EXTRA_LDS, stream, P); \
     }
 
 template <typename VT>
