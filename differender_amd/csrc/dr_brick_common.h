@@ -299,9 +299,9 @@ __device__ __forceinline__ void load_ray(const float *entry, const float *exit_,
 // ds_add_f32 is serialised on gfx950 (193 cycles per wave-instruction whatever the addresses), ds_add_u64 takes 9-12 and
 // ds_add_f64 16-20, twice that per conflicting address (tools/microbench/lds_atomic_bench,
 // profiles/r02_microbench_lds_atomics.txt). Every accumulator is one 64-bit word, used in one of two formats:
-//   FIXED   64-bit fixed point with one scale PER BRICK (2^28 / the largest finite |grad_out| among the brick's candidate
-//           pixels), 32-bit addends rounded to nearest under a wave-uniform magnitude test, 64-bit addends otherwise. The fast format (d_volume at 512^3: 6.6 ms against 7.5 ms with doubles), but a contribution below
-//           2^-29 of the brick's largest upstream gradient is lost.
+//   FIXED   64-bit fixed point with one scale PER BRICK (2^40 / the largest finite |grad_out| among the brick's candidate
+//           pixels) and block-floating-point addends per wave (below). The fast format (d_volume at 512^3: 6.6 ms against
+//           7.5 ms with doubles); a contribution below 2^-41 of the brick's largest upstream gradient is lost.
 //   DOUBLE  the f32 contribution is widened (v_cvt_f64_f32: the cost of the float -> int conversion) and added with
 //           ds_add_f64: no scale, no dynamic-range limit.
 // d_tf always accumulates in DOUBLE (few conflicts after the run sums: it is the faster format there). d_volume uses
@@ -326,28 +326,33 @@ __device__ __forceinline__ float acc_f64_to_float(unsigned long long v) {
 }
 
 // FIXED format --------------------------------------------------------------------------------------------
-// value = x * 2^shift, stored as a two's-complement int64. fx_hi = 2^(shift-32) is passed around as a float.
+// value = x * 2^shift, stored as a two's-complement int64; shift = DR_FIX_BITS - exponent(gmax), gmax = the largest
+// |grad_out| component among the brick's candidate pixels (every brick has its own scale). The unit 2^-shift is 2^-40 of
+// gmax; sums stay inside 63 bits as long as no addend exceeds lim = 2^12 * gmax (2^10 such addends fit) -- the rare
+// sample beyond that goes straight to global memory (B1). Addends are BLOCK FLOATING POINT per wave: the 64 samples of
+// a pass share the exponent of the largest adjoint among them, each addend is rounded to nearest to 31 bits below that
+// (v_cvt_rpi_i32_f32) and shifted up into the 64-bit word -- three VALU instructions per add, a resolution of 2^-31 of
+// the wave's own largest adjoint (f32 atomics: 2^-24 of the running SUM), no bias, deterministic.
 #ifndef DR_FIX_BITS
-#define DR_FIX_BITS 28
+#define DR_FIX_BITS 40
 #endif
+#define DR_FIX_LIM_BITS 12
 struct FixScale {
-    float hi;    // 2^(shift-32): x*hi has the high word in its integer part, the low word in its fraction
-    float lo;    // 2^shift
-    float lim;   // adjoints are clamped to +-lim = 2^20 * gmax (keeps every sum inside 63 bits)
+    int shift;   // value = x * 2^shift
+    float lim;   // adjoints beyond +-lim = 2^12 * gmax do not go through the box
     double inv;  // 2^-shift
+    int sh;      // wave-uniform, set per pass (fix_wave_scale): addend = cvt(x * 2^(shift - sh)) << sh, 1 <= sh <= 31
 };
-// gmax = the largest |grad_out| component among the brick's candidate pixels: every brick has its own scale, so the
-// resolution follows the local magnitude of the upstream gradient.
 __device__ __forceinline__ FixScale make_fix_scale(float gmax) {
     if (!(gmax > 0.0f) || !(gmax < 3.0e38f)) gmax = 1.0f;  // all-zero upstream gradient
     int e;
     frexpf(gmax, &e);            // gmax < 2^e
-    const int shift = DR_FIX_BITS - e;    // gmax * 2^shift < 2^DR_FIX_BITS
+    e = e < -80 ? -80 : e;       // (a unit of 2^-120 is below anything an f32 adjoint resolves; keeps 2^(shift - sh) finite)
     FixScale f;
-    f.hi = ldexpf(1.0f, shift - 32);
-    f.lo = ldexpf(1.0f, shift);
-    f.lim = ldexpf(1.0f, e + 20);
-    f.inv = ldexp(1.0, -shift);
+    f.shift = DR_FIX_BITS - e;   // gmax * 2^shift < 2^DR_FIX_BITS
+    f.lim = ldexpf(1.0f, e + DR_FIX_LIM_BITS);
+    f.inv = ldexp(1.0, -f.shift);
+    f.sh = 1;
     return f;
 }
 // A NaN adjoint (NaN pixel in grad_out, NaN voxel) contributes nothing: the reference lets it poison every voxel and
@@ -361,34 +366,28 @@ __device__ __forceinline__ int cvt_rn_i32(float x) {
     asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(q) : "v"(x));
     return q;
 }
-// Wide conversion (any magnitude inside the clamp): split x*2^(shift-32) into integer and fraction.
-__device__ __forceinline__ void fix_add_wide(unsigned long long *p, float x, const FixScale &f) {
-    // + 2^-33 = half a unit of 2^-shift: the truncation below then rounds to nearest instead of toward -infinity (where
-    // |t| >= 2^-8 the sum is t itself: such values have no bits below 2^-shift to begin with)
-    const float t = fmaf(x, f.hi, 1.16415321826934814453125e-10f);
-    const float hf = floorf(t);
-    const unsigned int lo = (unsigned int)((t - hf) * 4294967296.0f);  // fraction in [0,1): exact product
-    const unsigned long long v = ((unsigned long long)(unsigned int)(int)hf << 32) | lo;
+// The pass's scale from the largest adjoint magnitude of the wave (bmax >= every |addend| of the pass, wave-uniform, finite,
+// <= 4 lim): returns the factor 2^(shift - sh) the adjoints are multiplied with once, and sets f.sh.
+__device__ __forceinline__ float fix_wave_scale(float bmax, FixScale &f) {
+    // bmax < 2^eb; addends < 2^30 after scaling by 2^(30 - eb): sh = shift - (30 - eb), kept in [1, 31]
+    const int eb = (bmax > 0.0f) ? (int)((__float_as_uint(bmax) >> 23) & 0xff) - 126 : -126;  // (a denormal bmax counts as 2^-126)
+    int sh = f.shift - 30 + eb;
+    sh = sh < 1 ? 1 : (sh > 31 ? 31 : sh);  // sh > 31 cannot happen below 4 lim (DR_FIX_BITS + DR_FIX_LIM_BITS + 2 - 30 <= 31)
+    f.sh = sh;
+    return ldexpf(1.0f, f.shift - sh);
+}
+// x already carries the factor 2^(shift - sh) and |x| < 2^31
+__device__ __forceinline__ void fix_add_scaled(unsigned long long *p, float x, const FixScale &f) {
+    const int q = cvt_rn_i32(x);
+    const unsigned int lo = (unsigned int)q << f.sh;
+    const int hi = q >> (32 - f.sh);  // arithmetic: the sign extension
+    const unsigned long long v = ((unsigned long long)(unsigned int)hi << 32) | lo;
 #ifdef DR_ABL_NOATOMIC
     asm volatile("" :: "v"(p), "v"(v));
 #else
     atomicAdd(p, v);  // ds_add_u64
 #endif
 }
-// Common case: |x * 2^shift| < 2^31 -- one multiply, one float->int conversion (rounded to the nearest 2^-shift), a sign
-// extension. Callers test the magnitude once per sample (fix_fits) and pick WIDE under a wave-uniform branch.
-__device__ __forceinline__ bool fix_fits(float absmax, const FixScale &f) { return absmax * f.lo < 2147483520.0f; }
-template <bool WIDE, bool PRE = false>  // PRE: x already carries the factor 2^shift
-__device__ __forceinline__ void fix_add_t(unsigned long long *p, float x, const FixScale &f) {
-    if (WIDE) { fix_add_wide(p, x, f); return; }
-    const int q = cvt_rn_i32(PRE ? x : x * f.lo);  // <= half a unit of 2^-shift (~2e-9 of the brick's max|grad_out|) per add, unbiased
-#ifdef DR_ABL_NOATOMIC
-    asm volatile("" :: "v"(p), "v"((unsigned long long)(long long)q));
-#else
-    atomicAdd(p, (unsigned long long)(long long)q);  // ds_add_u64
-#endif
-}
-__device__ __forceinline__ void fix_add(unsigned long long *p, float x, const FixScale &f) { fix_add_wide(p, x, f); }
 __device__ __forceinline__ float fix_to_float(unsigned long long v, const FixScale &f) {
     return (float)((double)(long long)v * f.inv);
 }

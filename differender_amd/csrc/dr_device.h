@@ -165,17 +165,43 @@ __device__ __forceinline__ void sample_pos_rcp(float t0, float exit_, float nm1,
     px = fmaf(t, vx, cx); py = fmaf(t, vy, cy); pz = fmaf(t, vz, cz);
 }
 
-// (1 - a)^(1/sr) of VR.py:284-285. The exponent is uniform per launch; the reference's scripts use sampling rates 1, 4, 8
-// and 16 (OPT.py:49,67, ND.py:27, Raycaster.raycast_nondiff's default 4x): for 1/sr = 2^-k the power is k correctly
-// rounded square roots (total error < 1 ulp, ~10 instructions each) instead of the ~100-instruction powf -- which at
-// sampling rate 8 was most of the arithmetic of the alpha pre-pass.
+// (1 - a)^(1/sr) of VR.py:284-285 -- a SPECIFIED function shared with the oracle (oracle/dr_oracle.c, dro_pow_inv_sr),
+// because `ti.pow` is CUDA's approximate __powf in the reference (not a pinned function) and the result is ill-conditioned
+// in f32: one ulp of the power is a relative 1e-4 of the opacity at sampling rate 16 and small alpha, and whether a ray
+// crosses alpha 0.99 at sample s or s + 1 can hinge on it. Both sides evaluate, bit for bit:
+//   * 1/sr = 2^-k (sampling rates 2, 4, 8, 16 -- with 1, all the rates of the reference's scripts: OPT.py:49,67, ND.py:27,
+//     raycast_nondiff's default 4x): k correctly rounded square roots. Total error < 1 ulp, ~10 instructions each instead
+//     of the ~100 of powf, which at sampling rate 8 was most of the arithmetic of the alpha pre-pass.
+//   * any other exponent: exp2(y * log2(x)) in DOUBLE precision from IEEE +, -, *, / only (an atanh series for the
+//     logarithm, a Taylor polynomial for the exponential; relative error < 1e-11), rounded once to float: the
+//     correctly rounded power but for ~1e-4 of the arguments, and the same float on any IEEE platform always.
+__device__ __forceinline__ float pow_spec(float x, float y) {
+    if (!(x > 0.0f)) return (x == 0.0f) ? 0.0f : __builtin_nanf("");
+    const long long bits = __double_as_longlong((double)x);
+    int e = (int)((bits >> 52) & 0x7ff) - 1023;
+    double m = __longlong_as_double((bits & 0x000fffffffffffffll) | 0x3ff0000000000000ll);  // [1, 2)
+    if (m > 1.4142135623730951) { m *= 0.5; e += 1; }                                          // [0.707, 1.414]
+    const double z = (m - 1.0) / (m + 1.0), z2 = z * z;                                        // |z| <= 0.172
+    double p = 2.0 / 13.0;
+    p = p * z2 + 2.0 / 11.0; p = p * z2 + 2.0 / 9.0; p = p * z2 + 2.0 / 7.0; p = p * z2 + 2.0 / 5.0;
+    p = p * z2 + 2.0 / 3.0; p = p * z2 + 2.0;
+    const double t = (double)y * ((double)e + (p * z) * 1.4426950408889634);                  // y * log2(x)
+    if (!(t > -160.0)) return 0.0f;
+    if (!(t < 128.0)) return __builtin_inff();
+    const double n = __builtin_rint(t), r = (t - n) * 0.6931471805599453;                      // |r| <= 0.347
+    double q = 1.0 / 39916800.0;
+    q = q * r + 1.0 / 3628800.0; q = q * r + 1.0 / 362880.0; q = q * r + 1.0 / 40320.0; q = q * r + 1.0 / 5040.0;
+    q = q * r + 1.0 / 720.0; q = q * r + 1.0 / 120.0; q = q * r + 1.0 / 24.0; q = q * r + 1.0 / 6.0;
+    q = q * r + 0.5; q = q * r + 1.0; q = q * r + 1.0;
+    return (float)(q * __longlong_as_double((long long)((int)n + 1023) << 52));
+}
 __device__ __forceinline__ float pow_inv_sr(float base, float inv_sr) {
     if (inv_sr == 1.0f) return base;
     if (inv_sr == 0.5f) return sqrtf(base);
     if (inv_sr == 0.25f) return sqrtf(sqrtf(base));
     if (inv_sr == 0.125f) return sqrtf(sqrtf(sqrtf(base)));
     if (inv_sr == 0.0625f) return sqrtf(sqrtf(sqrtf(sqrtf(base))));
-    return powf(base, inv_sr);
+    return pow_spec(base, inv_sr);
 }
 
 // VR.py:205-219 + 284-285. tf is a [R][4] table (LDS or global). sm.I must be set.

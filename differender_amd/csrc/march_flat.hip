@@ -445,6 +445,17 @@ __device__ __forceinline__ int scan_max(int v, int lane) {
     { const int o = dpp_i<0x143>(v); if (lane >= 32) v = max(v, o); }
     return v;
 }
+// largest of a non-negative float over the wave, wave-uniform (DPP; non-negative floats order like their bit patterns)
+__device__ __forceinline__ float wave_max_nonneg(float x) {
+    int v = __float_as_int(x);
+    { const int o = dpp_i<0x111>(v); v = max(v, o); }   // row_shr:1 (bound_ctrl: lanes without a source read 0)
+    { const int o = dpp_i<0x112>(v); v = max(v, o); }
+    { const int o = dpp_i<0x114>(v); v = max(v, o); }
+    { const int o = dpp_i<0x118>(v); v = max(v, o); }   // lane 15 of every row: the row's maximum
+    { const int o = dpp_i<0x142>(v); v = max(v, o); }   // row_bcast:15
+    { const int o = dpp_i<0x143>(v); v = max(v, o); }   // row_bcast:31 -> lane 63: the wave's maximum
+    return __int_as_float(__builtin_amdgcn_readlane(v, 63));
+}
 __device__ __forceinline__ Over readlane_over(const Over &v, int lane) {
     Over r;
     r.c0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.c0), lane));
@@ -467,32 +478,37 @@ __device__ __forceinline__ Over shfl_up1_over(const Over &v) {
 }
 
 // How a d_volume contribution reaches its LDS accumulator (dr_brick_common.h, "LDS gradient accumulators")
-enum { ACC_FIX = 0,       // FIXED, 32-bit addend, value already carries the factor 2^shift
-       ACC_FIX_WIDE = 1,  // FIXED, exact 64-bit addend (some adjoint of the wave is large, non-finite values were clamped)
-       ACC_F64 = 2 };     // DOUBLE
+enum { ACC_FIX = 0,       // FIXED, value already carries the wave's factor (fix_wave_scale)
+       ACC_F64 = 2,       // DOUBLE
+       ACC_GLOBAL = 3 };  // not the LDS box at all: float atomics on the gradient volume (oversized adjoints, see B1)
 template <int ACC>
 __device__ __forceinline__ void acc_add(unsigned long long *p, float x, const FixScale &f) {
     if (ACC == ACC_F64) acc_add_f64(p, x);
-    else fix_add_t<ACC == ACC_FIX_WIDE, ACC == ACC_FIX>(p, x, f);
+    else fix_add_scaled(p, x, f);
 }
+// straight to the gradient volume in global memory (float atomics, as the baseline kernels and the reference do): the
+// few samples whose adjoints exceed the fixed-point clamp (normalisation of a nearly vanishing gradient)
 template <int ACC>
-__device__ __forceinline__ void scatter8(unsigned long long *dbox, int base, const float (&w)[8], const FixScale &f) {
-    acc_add<ACC>(dbox + base, w[0], f);
-    acc_add<ACC>(dbox + base + BOX_SX, w[1], f);
-    acc_add<ACC>(dbox + base + BOX_SY, w[2], f);
-    acc_add<ACC>(dbox + base + BOX_SX + BOX_SY, w[3], f);
-    acc_add<ACC>(dbox + base + 1, w[4], f);
-    acc_add<ACC>(dbox + base + BOX_SX + 1, w[5], f);
-    acc_add<ACC>(dbox + base + BOX_SY + 1, w[6], f);
-    acc_add<ACC>(dbox + base + BOX_SX + BOX_SY + 1, w[7], f);
+__device__ __forceinline__ void acc_add(float *p, float x, const FixScale &) { unsafeAtomicAdd(p, x); }
+// SX, SY: element strides of the destination along x and y (z is contiguous in the LDS box; SZ for the global volume)
+template <int ACC, typename PT, typename ST>
+__device__ __forceinline__ void scatter8(PT *dst, ST SX, ST SY, ST SZ, const float (&w)[8], const FixScale &f) {
+    acc_add<ACC>(dst, w[0], f);
+    acc_add<ACC>(dst + SX, w[1], f);
+    acc_add<ACC>(dst + SY, w[2], f);
+    acc_add<ACC>(dst + SX + SY, w[3], f);
+    acc_add<ACC>(dst + SZ, w[4], f);
+    acc_add<ACC>(dst + SX + SZ, w[5], f);
+    acc_add<ACC>(dst + SY + SZ, w[6], f);
+    acc_add<ACC>(dst + SX + SY + SZ, w[7], f);
 }
-// the four voxels base + {0, SA, SB, SA+SB} receive c * w[0..3]
-template <int ACC, int SA, int SB>
-__device__ __forceinline__ void scatter4(unsigned long long *dbox, int base, float c, const float (&w)[4], const FixScale &f) {
-    acc_add<ACC>(dbox + base, c * w[0], f);
-    acc_add<ACC>(dbox + base + SA, c * w[1], f);
-    acc_add<ACC>(dbox + base + SB, c * w[2], f);
-    acc_add<ACC>(dbox + base + SA + SB, c * w[3], f);
+// the four voxels dst + {0, SA, SB, SA+SB} receive c * w[0..3]
+template <int ACC, typename PT, typename ST>
+__device__ __forceinline__ void scatter4(PT *dst, ST SA, ST SB, float c, const float (&w)[4], const FixScale &f) {
+    acc_add<ACC>(dst, c * w[0], f);
+    acc_add<ACC>(dst + SA, c * w[1], f);
+    acc_add<ACC>(dst + SB, c * w[2], f);
+    acc_add<ACC>(dst + SA + SB, c * w[3], f);
 }
 // Adjoint of the two central-difference taps of one axis, reduced to coefficients along that axis over the box
 // planes l0-1 .. l0+2 (l0 = centre cell). The +delta tap sits in cell l0 or l0+1, the -delta tap in l0-1 or l0
@@ -512,12 +528,12 @@ __device__ __forceinline__ void tap_line(int l0, int lp, int lm, float fp, float
 // lands there is summed into the centre's 8 corners first (8 LDS adds); what remains per axis is one outside
 // plane of 4 voxels (l0+2 or l0-1; both only when delta >= 0.5 voxel, i.e. dim > 1000: rare uniform branch).
 // 8 + 3*4 = 20 LDS adds per sample instead of 8 per tap.
-template <int ACC>
-__device__ __forceinline__ void scatter_sample(unsigned long long *dbox, const TapCoords &t, bool valid, int cbase_i,
+template <int ACC, typename PT, typename ST>
+__device__ __forceinline__ void scatter_sample(PT *dst, ST SX, ST SY, ST SZ, const TapCoords &t, bool valid,
                                                float I_bar, const float (&gq)[3], const FixScale &fs) {
     const float X[2] = {1.0f - t.fx, t.fx}, Y[2] = {1.0f - t.fy, t.fy}, Z[2] = {1.0f - t.fz, t.fz};
-    const float YZ[4] = {Y[0] * Z[0], Y[1] * Z[0], Y[0] * Z[1], Y[1] * Z[1]};  // offsets {0, SY, 1, SY+1}
-    const float XZ[4] = {X[0] * Z[0], X[1] * Z[0], X[0] * Z[1], X[1] * Z[1]};  // offsets {0, SX, 1, SX+1}
+    const float YZ[4] = {Y[0] * Z[0], Y[1] * Z[0], Y[0] * Z[1], Y[1] * Z[1]};  // offsets {0, SY, SZ, SY+SZ}
+    const float XZ[4] = {X[0] * Z[0], X[1] * Z[0], X[0] * Z[1], X[1] * Z[1]};  // offsets {0, SX, SZ, SX+SZ}
     const float XY[4] = {X[0] * Y[0], X[1] * Y[0], X[0] * Y[1], X[1] * Y[1]};  // offsets {0, SX, SY, SX+SY}
     float cx[4], cy[4], cz[4];
     tap_line(t.lx, t.lxp, t.lxm, t.fxp, t.fxm, gq[0], cx);
@@ -532,22 +548,28 @@ __device__ __forceinline__ void scatter_sample(unsigned long long *dbox, const T
     }
     {   // x: outside plane l0+2 (coefficient cx[3]) or l0-1 (cx[0])
         const bool hi = cx[3] != 0.0f, lo = cx[0] != 0.0f;
-        if (valid && (hi || lo)) scatter4<ACC, BOX_SY, 1>(dbox, cbase_i + (hi ? 2 * BOX_SX : -BOX_SX), hi ? cx[3] : cx[0], YZ, fs);
-        if (__any(valid && hi && lo)) { if (valid && hi && lo) scatter4<ACC, BOX_SY, 1>(dbox, cbase_i - BOX_SX, cx[0], YZ, fs); }
+        if (valid && (hi || lo)) scatter4<ACC>(dst + (hi ? 2 * SX : -SX), SY, SZ, hi ? cx[3] : cx[0], YZ, fs);
+        if (__any(valid && hi && lo)) { if (valid && hi && lo) scatter4<ACC>(dst - SX, SY, SZ, cx[0], YZ, fs); }
     }
     {   // y
         const bool hi = cy[3] != 0.0f, lo = cy[0] != 0.0f;
-        if (valid && (hi || lo)) scatter4<ACC, BOX_SX, 1>(dbox, cbase_i + (hi ? 2 * BOX_SY : -BOX_SY), hi ? cy[3] : cy[0], XZ, fs);
-        if (__any(valid && hi && lo)) { if (valid && hi && lo) scatter4<ACC, BOX_SX, 1>(dbox, cbase_i - BOX_SY, cy[0], XZ, fs); }
+        if (valid && (hi || lo)) scatter4<ACC>(dst + (hi ? 2 * SY : -SY), SX, SZ, hi ? cy[3] : cy[0], XZ, fs);
+        if (__any(valid && hi && lo)) { if (valid && hi && lo) scatter4<ACC>(dst - SY, SX, SZ, cy[0], XZ, fs); }
     }
     {   // z
         const bool hi = cz[3] != 0.0f, lo = cz[0] != 0.0f;
-        if (valid && (hi || lo)) scatter4<ACC, BOX_SX, BOX_SY>(dbox, cbase_i + (hi ? 2 : -1), hi ? cz[3] : cz[0], XY, fs);
-        if (__any(valid && hi && lo)) { if (valid && hi && lo) scatter4<ACC, BOX_SX, BOX_SY>(dbox, cbase_i - 1, cz[0], XY, fs); }
+        if (valid && (hi || lo)) scatter4<ACC>(dst + (hi ? 2 * SZ : -SZ), SX, SY, hi ? cz[3] : cz[0], XY, fs);
+        if (__any(valid && hi && lo)) { if (valid && hi && lo) scatter4<ACC>(dst - SZ, SX, SY, cz[0], XY, fs); }
     }
     // (Consecutive lanes are consecutive samples of a ray, ~3.5 per cell: these eight adds collide in the LDS, ~7 cycles
     // per duplicate address. Summing the runs across lanes first was tried twice: +1.0 ms of VALU for 0.4 ms of LDS.)
-    if (valid) scatter8<ACC>(dbox, cbase_i, acc, fs);
+    if (valid) scatter8<ACC>(dst, SX, SY, SZ, acc, fs);
+}
+// the common destination: the brick's LDS gradient box, centre cell at element cbase_i
+template <int ACC>
+__device__ __forceinline__ void scatter_sample(unsigned long long *dbox, const TapCoords &t, bool valid, int cbase_i,
+                                               float I_bar, const float (&gq)[3], const FixScale &fs) {
+    scatter_sample<ACC>(dbox + cbase_i, (int)BOX_SX, (int)BOX_SY, 1, t, valid, I_bar, gq, fs);
 }
 
 // Backward: the largest and the smallest non-zero |grad_out| (per pixel: its largest component) over the brick's
@@ -976,12 +998,32 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                             gq[0] = acc_sanitise(gq[0]); gq[1] = acc_sanitise(gq[1]); gq[2] = acc_sanitise(gq[2]);
                         }
                         scatter_sample<ACC_F64>(L.dbox, t, valid, cbase_i, I_bar, gq, fs);
-                    } else if (__any(!fix_fits(bound, fs))) {
-                        const float gc[3] = {fix_clamp(gq[0], fs), fix_clamp(gq[1], fs), fix_clamp(gq[2], fs)};
-                        scatter_sample<ACC_FIX_WIDE>(L.dbox, t, valid, cbase_i, fix_clamp(I_bar, fs), gc, fs);
-                    } else {  // common case: scale the four adjoints once instead of the twenty addends
-                        const float gs[3] = {gq[0] * fs.lo, gq[1] * fs.lo, gq[2] * fs.lo};
-                        scatter_sample<ACC_FIX>(L.dbox, t, valid, cbase_i, I_bar * fs.lo, gs, fs);
+                    } else {
+                        // Beyond the range of the fixed-point box (2^12 x the brick's largest upstream gradient: the
+                        // normalisation of a nearly vanishing volume gradient amplifies by 1/|grad|, 1e7 and more where
+                        // only rounding noise is left of it) a sample goes straight to the gradient volume with float
+                        // atomics, exactly as in the baseline kernels and in the reference; NaN / absurd values are
+                        // dropped or clamped.
+                        bool in_box = valid;
+                        float bnd = valid ? bound : 0.0f;
+                        if (__any(valid && !(bound <= fs.lim))) {
+                            const bool over = valid && bound > fs.lim && bound <= ACC_LIM;
+                            if (__any(over)) {
+                                const GradView dv = P.dvol;
+                                float *gdst = dv.p + ((long long)view * P.dvol_vs + (long long)(c.ox + t.lx) * dv.sx +
+                                                      (long long)(c.oy + t.ly) * dv.sy + (long long)(c.oz + t.lz) * dv.sz);
+                                scatter_sample<ACC_GLOBAL>(gdst, (long long)dv.sx, (long long)dv.sy, (long long)dv.sz, t, over, I_bar, gq, fs);
+                            }
+                            in_box = valid && !over;
+                            I_bar = fix_clamp(I_bar, fs);
+                            gq[0] = fix_clamp(gq[0], fs); gq[1] = fix_clamp(gq[1], fs); gq[2] = fix_clamp(gq[2], fs);
+                            bnd = in_box ? fabsf(I_bar) + (fabsf(gq[0]) + fabsf(gq[1]) + fabsf(gq[2])) : 0.0f;
+                        }
+                        // block floating point: the pass's addends share the exponent of its largest adjoint
+                        FixScale fw = fs;
+                        const float mul = fix_wave_scale(wave_max_nonneg(bnd), fw);
+                        const float gs[3] = {gq[0] * mul, gq[1] * mul, gq[2] * mul};
+                        scatter_sample<ACC_FIX>(L.dbox, t, in_box, cbase_i, I_bar * mul, gs, fw);
                     }
                 }
             }

@@ -9,11 +9,56 @@
 #include <stdlib.h>
 #include <stddef.h>
 
+/* Opacity correction 1 - (1 - a)^(1/sr) (VR.py:285): `ti.pow` is CUDA's approximate __powf in the reference (Taichi's
+ * fast_math default), i.e. not a pinned function, and at small a the result is ill-conditioned in f32: one ulp of the
+ * power is a relative 1e-4 of the opacity at sr = 16, and whether a ray crosses alpha 0.99 at sample s or s + 1 can hinge
+ * on it. Oracle and kernels therefore share one SPECIFIED single-precision power, reproducible bit for bit on any IEEE
+ * platform (differender_amd/csrc/dr_device.h: pow_inv_sr, pow_spec -- written independently from this description):
+ *   1/sr = 2^-k (sampling rates 2, 4, 8, 16): k correctly rounded square roots;
+ *   otherwise exp2(y * log2(x)) in double precision from +, -, *, / only, rounded once to float:
+ *     x = m * 2^e with m in [1/sqrt2, sqrt2];  z = (m-1)/(m+1);  ln m = z * (2 + 2/3 z^2 + ... + 2/13 z^12)  (Horner);
+ *     t = y * (e + ln m * log2(e));  n = rint(t);  r = (t - n) * ln 2;  exp r = 1 + r + ... + r^11/11!  (Horner);
+ *     result = (float)(exp r * 2^n).
+ * Both are within 1 ulp of x^y (tests/test_oracle_kat.py checks that against the double-precision pow). */
+static float dro_pow_spec_f32(float x, float y) {
+    union { double d; int64_t i; } u;
+    if (!(x > 0.0f)) return (x == 0.0f) ? 0.0f : NAN;
+    u.d = (double)x;
+    int e = (int)((u.i >> 52) & 0x7ff) - 1023;
+    u.i = (u.i & INT64_C(0x000fffffffffffff)) | INT64_C(0x3ff0000000000000);
+    double m = u.d;
+    if (m > 1.4142135623730951) { m *= 0.5; e += 1; }
+    const double z = (m - 1.0) / (m + 1.0), z2 = z * z;
+    double p = 2.0 / 13.0;
+    p = p * z2 + 2.0 / 11.0; p = p * z2 + 2.0 / 9.0; p = p * z2 + 2.0 / 7.0; p = p * z2 + 2.0 / 5.0;
+    p = p * z2 + 2.0 / 3.0; p = p * z2 + 2.0;
+    const double t = (double)y * ((double)e + (p * z) * 1.4426950408889634);
+    if (!(t > -160.0)) return 0.0f;
+    if (!(t < 128.0)) return INFINITY;
+    const double n = rint(t), r = (t - n) * 0.6931471805599453;
+    double q = 1.0 / 39916800.0;
+    q = q * r + 1.0 / 3628800.0; q = q * r + 1.0 / 362880.0; q = q * r + 1.0 / 40320.0; q = q * r + 1.0 / 5040.0;
+    q = q * r + 1.0 / 720.0; q = q * r + 1.0 / 120.0; q = q * r + 1.0 / 24.0; q = q * r + 1.0 / 6.0;
+    q = q * r + 0.5; q = q * r + 1.0; q = q * r + 1.0;
+    u.i = (int64_t)((int)n + 1023) << 52;
+    return (float)(q * u.d);
+}
+static float dro_pow_inv_sr_f32(float base, float inv_sr) {
+    if (inv_sr == 1.0f) return base;
+    if (inv_sr == 0.5f) return sqrtf(base);
+    if (inv_sr == 0.25f) return sqrtf(sqrtf(base));
+    if (inv_sr == 0.125f) return sqrtf(sqrtf(sqrtf(base)));
+    if (inv_sr == 0.0625f) return sqrtf(sqrtf(sqrtf(sqrtf(base))));
+    return dro_pow_spec_f32(base, inv_sr);
+}
+float dro_pow_inv_sr(float base, float inv_sr) { return dro_pow_inv_sr_f32(base, inv_sr); }  /* exported for the KAT */
+
 #define REAL float
 #define SUF(x) x##_f32
 #define R_SQRT sqrtf
 #define R_FLOOR floorf
 #define R_POW powf
+#define R_POW_INV_SR dro_pow_inv_sr_f32
 #define R_FMAX fmaxf
 #define R_FMIN fminf
 #define R_FMA fmaf
@@ -23,6 +68,7 @@
 #undef R_SQRT
 #undef R_FLOOR
 #undef R_POW
+#undef R_POW_INV_SR
 #undef R_FMAX
 #undef R_FMIN
 #undef R_FMA
@@ -32,6 +78,7 @@
 #define R_SQRT sqrt
 #define R_FLOOR floor
 #define R_POW pow
+#define R_POW_INV_SR pow
 #define R_FMAX fmax
 #define R_FMIN fmin
 #define R_FMA fma

@@ -231,3 +231,37 @@ def test_epilogue_loss_and_momentum_step(oracle):
     np.testing.assert_allclose(mom2, m_ref, rtol=1e-6, atol=1e-9)
     np.testing.assert_allclose(tf2, np.maximum(tf - m_ref, 0), rtol=1e-6, atol=1e-8)
     assert (tf2 >= 0).all() and (tf2 == 0).any()      # the clamp at zero is exercised
+
+
+def test_specified_power_is_within_one_ulp(oracle):
+    """(1 - a)^(1/sr), the one function oracle and kernels share bit for bit (oracle/dr_oracle.c, dr_device.h): against the
+    double-precision power it must stay within 1 ulp at the square-root rates and be the correctly rounded float elsewhere."""
+    import ctypes
+    f = oracle.lib().dro_pow_inv_sr
+    f.restype = ctypes.c_float; f.argtypes = [ctypes.c_float, ctypes.c_float]
+    rng = np.random.default_rng(5)
+    xs = np.concatenate([rng.random(4000, dtype=np.float32), 1 - rng.random(4000, dtype=np.float32) * np.float32(0.01),
+                         rng.random(500, dtype=np.float32) * np.float32(1e-6), np.array([1.0, 0.5, 0.25, 1e-30, 1e-38], np.float32)])
+    for sr in (2.0, 4.0, 8.0, 16.0, 0.3, 0.6, 1.5, 3.0, 5.0, 12.0):
+        y = np.float32(1.0) / np.float32(sr)
+        got = np.array([f(float(x), float(y)) for x in xs], np.float32)
+        ref = np.power(xs.astype(np.float64), np.float64(y))
+        ulp = np.spacing(ref.astype(np.float32)).astype(np.float64)
+        err = np.abs(got.astype(np.float64) - ref) / ulp
+        if sr in (2.0, 4.0, 8.0, 16.0):
+            assert err.max() < 1.0, (sr, err.max())
+        else:
+            assert err.max() <= 0.5 + 1e-6, (sr, err.max())          # correctly rounded on this sample
+            assert np.array_equal(got, ref.astype(np.float32))
+    assert f(0.0, 0.3) == 0.0 and f(1.0, 0.3) == 1.0 and math.isnan(f(-0.1, 0.3))
+    assert f(0.7, 1.0) == np.float32(0.7)
+
+
+def test_ray_parallel_to_a_slab_it_misses_has_no_samples(oracle):
+    """Both slab distances are the same infinity, the reference's hit test passes and ray_len = inf - inf: the sample count is
+    NaN cast to int -- 0 on a GPU (CUDA cvt.rzi, AMD v_cvt_i32_f32), undefined in C. The oracle defines it as the GPUs do."""
+    cam = np.array([3.5491052, -17.622072, 35.73327], np.float32)   # the fuzzer's find (seed 1116, view 1)
+    e, x, r, n = oracle.ray_setup(cam, 47, 93, (3, 3, 95), sr=8.0)
+    assert n.min() >= 0
+    bad = ~np.isfinite(x - e)
+    assert bad.any() and (n[bad] == 0).all()

@@ -1,0 +1,184 @@
+"""Randomised parity fuzzer (GPU box): HIP fast path against the CPU oracle on the same ray buffers, far wider than
+tests/test_gpu_parity.py::test_random_configurations -- ragged and anisotropic volumes (2..96 per axis), images up to 96 px,
+1..3 views sharing a volume, TF sizes 1..300 with empty / opaque / spiky alpha, sampling rates 0.3..16, clipped
+max_samples, fp16 and strided volumes, jitter, cameras anywhere (inside the volume, on a face, far away, axis aligned).
+
+    python tools/fuzz_parity.py [seconds=300] [first_seed=0]
+
+Prints one line per failing configuration (with the seed that reproduces it) and a summary; exit code 1 on any failure.
+Tolerances are those of the parity tests: ray setup and steps bit-exact, RGBA 1e-5, gradients 1e-4 of the tensor's largest
+magnitude -- or, where the order of the float atomics alone moves the f32 result by that much (gauged by the baseline
+kernels, which share the oracle's arithmetic), 3 x the baseline's distance from the oracle + 1e-4.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from differender_amd import functional as Fn  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+dev = torch.device("cuda:0")
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def make_case(seed):
+    rng = np.random.default_rng(770000 + seed)
+    big = rng.random() < 0.25
+    hi = 97 if big else 40
+    vshape = tuple(int(v) for v in rng.integers(2, hi, 3))
+    if rng.random() < 0.15:   # strongly anisotropic
+        vshape = tuple(int(v) for v in (rng.integers(2, 9), rng.integers(30, hi), rng.integers(2, hi)))
+        vshape = tuple(np.array(vshape)[rng.permutation(3)].tolist())
+    WH = (int(rng.integers(1, 97 if big else 49)), int(rng.integers(1, 97 if big else 49)))
+    R = int(rng.choice([1, 2, 3, 7, 16, 64, 128, 256, 300]))
+    sr = float(rng.choice([0.3, 0.6, 1.0, 1.0, 1.0, 1.5, 2.0, 3.0, 4.0, 8.0, 16.0]))
+    mode = int(rng.random() < 0.35)
+    n_views = int(rng.choice([1, 1, 2, 3]))
+    S = int(rng.choice([5000, 5000, 5000, 1, 2, 7, 33, 150]))
+    vol = rng.random(vshape, dtype=np.float32)
+    kind = rng.integers(0, 4)
+    if kind >= 1:   # smooth (normals are not pure noise)
+        for ax in range(3):
+            vol = (vol + np.roll(vol, 1, ax) + np.roll(vol, -1, ax)) / 3.0
+    if kind == 2:   # flat regions: zero gradient -> ambient-only samples (D1)
+        vol = np.round(vol * 3.0) / 3.0
+    if kind == 3:   # sparse: mostly empty space
+        vol = np.clip((vol - 0.5) * 8.0, 0.0, 1.0)
+    vol = np.ascontiguousarray(vol.astype(np.float32))
+    f16 = rng.random() < 0.25
+    if f16:
+        vol = vol.astype(np.float16).astype(np.float32)
+    tf = rng.random((R, 4), dtype=np.float32)
+    ak = rng.integers(0, 6)
+    tf[:, 3] *= [0.004, 0.02, 0.2, 0.9, 1.0, 0.05][ak]
+    if ak == 4:     # alpha reaches exactly 1 somewhere: opacity 1, transmittance 0
+        tf[rng.integers(0, R), 3] = 1.0
+    if ak == 5 and R > 4:   # empty ranges (alpha exactly 0) + a spike
+        tf[: R // 2, 3] = 0.0
+        tf[rng.integers(R // 2, R), 3] = 0.95
+    cams = []
+    for _ in range(n_views):
+        d = rng.standard_normal(3); d /= np.linalg.norm(d)
+        ck = rng.integers(0, 8)
+        if ck == 0:
+            d = np.eye(3)[rng.integers(0, 3)] * rng.choice([-1.0, 1.0])   # axis aligned
+        if abs(d[1]) > 0.97:    # (anti)parallel to the up vector is degenerate in VR.py:143
+            d = np.array([0.6, 0.3, 0.74]); d /= np.linalg.norm(d)
+        dist = float(rng.choice([0.05, 0.5, 0.9, 1.0, 1.2, 1.75, 2.5, 6.0, 40.0]))
+        cams.append((d * dist).astype(np.float32))
+    cam = np.stack(cams)
+    jitter = int(rng.integers(0, 2)) * int(rng.integers(1, 1 << 30))
+    strided = (not f16) and rng.random() < 0.2
+    g = rng.standard_normal((n_views, *WH, 4)).astype(np.float32)
+    if rng.random() < 0.2:
+        g *= np.exp(rng.uniform(-9, 9, size=(n_views, *WH, 1))).astype(np.float32)   # wide dynamic range of the upstream gradient
+    want = [(True, True), (True, True), (True, False), (False, True)][int(rng.integers(0, 4))]
+    return dict(vshape=vshape, WH=WH, R=R, sr=sr, mode=mode, n_views=n_views, S=S, vol=vol, f16=f16, tf=tf, cam=cam,
+                jitter=jitter, strided=strided, g=g, want=want, vol_kind=int(kind), alpha_kind=int(ak))
+
+
+def describe(c):
+    return {k: c[k] for k in ("vshape", "WH", "R", "sr", "mode", "n_views", "S", "f16", "jitter", "strided", "want", "vol_kind", "alpha_kind")} | {"cam": c["cam"].tolist()}
+
+
+def run_case(c):
+    """Returns a list of failure strings (empty = pass)."""
+    fails = []
+    vol_h, tf_h, cam_h = c["vol"], c["tf"], c["cam"]
+    WH, vshape, sr, S, mode = c["WH"], c["vshape"], c["sr"], c["S"], c["mode"]
+    if c["f16"]:
+        vol = T(vol_h.astype(np.float16))
+    elif c["strided"]:
+        big = torch.zeros(tuple(v + 3 for v in vshape), device=dev)
+        vol = big[1:1 + vshape[0], 2:2 + vshape[1], 0:vshape[2]]
+        vol.copy_(T(vol_h))
+    else:
+        vol = T(vol_h)
+    tf, cam = T(tf_h), T(cam_h)
+    e, x, r, n = Fn.ray_setup(cam, WH, vshape, sr, jitter_seed=c["jitter"])
+    ws = Fn.alloc_workspace(c["n_views"], WH, vshape, c["R"], dev)
+    out, steps = Fn.march_fwd(vol, tf, cam, e, x, r, n, S, sr, mode, workspace=ws)
+    eh, xh, rh, nh = (t.cpu().numpy() for t in (e, x, r, n))
+    out_h, steps_h = out.cpu().numpy(), steps.cpu().numpy()
+    if not np.isfinite(out_h).all():
+        fails.append("non-finite forward output")
+    g = c["g"].copy()
+    for v in range(c["n_views"]):
+        eo, xo, ro, no = O.ray_setup(cam_h[v], *WH, vshape, sr=sr, jitter_seed=c["jitter"], view=v)
+        same = all(np.array_equal(a, b, equal_nan=True) for a, b in ((eo, eh[v]), (xo, xh[v]), (ro, rh[v]))) and np.array_equal(no, nh[v])
+        if not same:
+            fails.append(f"ray setup differs (view {v})")
+        ref, sref = O.march_fwd(vol_h, tf_h, cam_h[v], eh[v], xh[v], rh[v], nh[v], S, sr, mode)
+        diff = steps_h[v] != sref     # (1 - a)^(1/sr) is one specified function in oracle and kernels: no excuse at any rate
+        if diff.any():
+            fails.append(f"steps differ (view {v}): {int(diff.sum())} pixels")
+            g[v][diff] = 0.0
+        ok = ~diff
+        err = float(np.abs(out_h[v] - ref)[ok].max()) if ok.any() else 0.0
+        if not err <= 1e-5:
+            fails.append(f"forward error {err:.3e} (view {v})")
+    if mode == 0:
+        dv_ref = np.zeros(vshape, np.float32); dt_ref = np.zeros_like(tf_h)
+        for v in range(c["n_views"]):
+            a, b = O.march_bwd(vol_h, tf_h, cam_h[v], eh[v], xh[v], rh[v], nh[v], S, sr, g[v])
+            dv_ref += a; dt_ref += b
+        wv, wt = c["want"]
+        base = None
+        dv, dt = Fn.march_bwd(vol, tf, cam, e, x, r, n, S, sr, T(g), out, wv, wt, workspace=ws)
+        for name, got, ref in (("d_vol", dv, dv_ref), ("d_tf", dt, dt_ref)):
+            if got is None:
+                continue
+            got = got.float().cpu().numpy()
+            if not np.isfinite(got).all():
+                fails.append(f"{name} non-finite"); continue
+            if not np.isfinite(ref).all():
+                # alpha == 1 at a sampling rate != 1: d/da (1 - a)^(1/sr) is infinite there, in the reference as well
+                # (its NaN / inf are what RaycastFunction.backward's nan_to_num is for): nothing to compare against
+                c["_undefined"] = True; continue
+            scale = max(float(np.abs(ref).max()), 1e-12)
+            err = float(np.abs(got - ref).max()) / scale
+            if not err <= 1e-4:
+                # Ill-conditioned case? Normalising a nearly vanishing gradient amplifies by 1/|grad|, and the f32 result then
+                # depends on the order of the float atomics at this level. The baseline kernels -- the oracle's arithmetic,
+                # float atomics in another order -- gauge that noise: the fast path may be 3 x as far from the oracle + 1e-4.
+                if base is None:
+                    bv, bt = Fn.march_bwd(vol, tf, cam, e, x, r, n, S, sr, T(g), out, True, True, variant=1)
+                    base = {"d_vol": bv.float().cpu().numpy(), "d_tf": bt.cpu().numpy()}
+                e_base = float(np.abs(base[name] - ref).max()) / scale
+                if not err <= 3.0 * e_base + 1e-4:
+                    fails.append(f"{name} error {err:.3e} of max {scale:.3e} (baseline kernels: {e_base:.3e})")
+                else:
+                    c["_illcond"] = True
+    return fails
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    t0 = time.time(); n_run = 0; n_bad = 0; last = t0; n_undef = 0; n_ill = 0
+    while time.time() - t0 < budget:
+        c = make_case(seed)
+        try:
+            fails = run_case(c)
+        except Exception as exc:   # an error return of the library is a finding too
+            fails = [f"exception {type(exc).__name__}: {exc}"]
+        if fails:
+            n_bad += 1
+            print("FAIL seed", seed, fails, describe(c), flush=True)
+        n_run += 1; seed += 1; n_undef += bool(c.get("_undefined")); n_ill += bool(c.get("_illcond"))
+        if time.time() - last > 30:
+            last = time.time(); print(f"... {n_run} cases, {n_bad} failing, next seed {seed}", flush=True)
+    print(f"fuzz done: {n_run} cases in {time.time() - t0:.0f} s, {n_bad} failing, seeds up to {seed - 1}; "
+          f"{n_undef} cases with an infinite reference gradient, {n_ill} ill-conditioned cases judged against the baseline kernels' noise")
+    sys.exit(1 if n_bad else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -12,7 +12,7 @@ ws = F.alloc_workspace(1, (IMG, IMG), (Nv,) * 3, R, dev)
 cam = torch.tensor([in_circles(0.3)], dtype=torch.float32, device=dev)
 for tfname in ("bench", "tf1"):
     tf = bench_tf_torch(R, 1e-3, dev) if tfname == "bench" else get_tf("tf1", R).t().contiguous().to(dev)
-    for mode, sr in ((0, 1.0), (1, 2.0), (1, 4.0), (1, 8.0)):
+    for mode, sr in ((0, 1.0), (0, 1.5), (1, 2.0), (1, 3.0), (1, 4.0), (1, 8.0)):
         e, x, r, n = F.ray_setup(cam, (IMG, IMG), (Nv,) * 3, sr)
         for it in range(6):
             if it == 2:
