@@ -262,6 +262,12 @@ __device__ __forceinline__ void shade_from_grad(float dx, float dy, float dz, f3
     sm.Lraw = fmaf(0.8f, sm.ndl, sm.spec) + 0.4f;
     sm.L = clampL ? fminf(1.0f, sm.Lraw) : sm.Lraw;
 }
+// The adjoint of the lighting term is discontinuous where the forward has a kink: Lraw = 1 (min(1, .), VR.py:298),
+// n.l = 0 and r.v = 0 (max(., 0), VR.py:291,294). The FAST normalisations move n.l by ~3e-7, r.v by ~1e-6 and Lraw by up
+// to ~1e-5 (r.v^32); inside these bands the fast backward re-shades the sample exactly (shade_from_grad<false>).
+__device__ __forceinline__ bool near_lighting_kink(const Sample &sm) {
+    return !sm.flat && (fabsf(sm.Lraw - 1.0f) < 6e-5f || fabsf(sm.m) < 4e-6f || fabsf(sm.q) < 8e-6f);
+}
 template <typename VT>
 __device__ __forceinline__ void shade(const VolView<VT> &v, f3 light_pos, f3 vd, bool clampL, Sample &sm) {
     const float delta = 1e-3f;

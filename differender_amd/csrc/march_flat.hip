@@ -840,8 +840,14 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                     if (lit) {
                         sample_normal_taps_lds(L.box, t, dx, dy, dz);
                         shade_from_grad<true>(dx, dy, dz, light, vd, MODE == DR_MODE_DIFF, sm);
-                        el.c0 = sm.L * sm.r * sm.op; el.c1 = sm.L * sm.g * sm.op; el.c2 = sm.L * sm.b * sm.op; el.a = sm.op;
                     }
+                    // Kinks of the lighting model: the adjoint switches on 1 < Lraw (the clamp of VR.py:298),
+                    // 0 < n.l and 0 < r.v (the max(., 0) of :291,:294). A sample within rounding distance of one of them is
+                    // shaded again with the oracle's exact normalisations, so that the switch falls as it does there.
+                    if (BWD && __any(lit && near_lighting_kink(sm))) {
+                        if (lit && near_lighting_kink(sm)) shade_from_grad<false>(dx, dy, dz, light, vd, MODE == DR_MODE_DIFF, sm);
+                    }
+                    if (lit) { el.c0 = sm.L * sm.r * sm.op; el.c1 = sm.L * sm.g * sm.op; el.c2 = sm.L * sm.b * sm.op; el.a = sm.op; }
                 }
                 vm_fwd[0] = BWD ? 0ull : __ballot(valid);
             } else {

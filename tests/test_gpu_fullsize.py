@@ -97,7 +97,7 @@ def test_backward_linearity_and_stability(scene):
     assert float((dt3 - (2.0 * dt1 - 0.5 * dt2)).abs().max()) <= 2e-5 * st
     dv1b, dt1b = bwd(g1)  # float atomics across bricks may reorder: equal up to rounding
     assert float((dv1b - dv1).abs().max()) <= 1e-6 * float(dv1.abs().max())
-    assert float((dt1b - dt1).abs().max()) <= 1e-6 * float(dt1.abs().max())
+    assert float((dt1b - dt1).abs().max()) <= 3e-6 * float(dt1.abs().max())   # (80 000 bricks flush into 1 024 floats)
     assert torch.isfinite(dv1).all() and torch.isfinite(dt1).all()
 
 

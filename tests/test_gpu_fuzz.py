@@ -7,6 +7,7 @@ What the listed seeds pinned down ("What the fuzzer found"):
   28, 113, 1246        sampling rates 8 and 16: (1 - a)^(1/sr) must be the same function in oracle and kernels
   759, 1310, 2430      sampling rates 0.3 and 3: likewise for exponents that are not 2^-k
   826, 177             contributions far below the brick's largest upstream gradient (block-floating-point addends)
+  20228, 23671, 26708  a sample on a kink of the lighting model (Lraw within 1e-5 of the clamp at 1): D7
   1108, 1116, 2440     a ray parallel to a slab it lies outside of: NaN sample count, defined as 0
   56, 90, 3255         alpha == 1 at a sampling rate != 1: infinite reference gradient, kernels stay finite
 """
@@ -19,7 +20,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REGRESSION_SEEDS = [1, 28, 56, 90, 113, 177, 603, 759, 826, 1108, 1116, 1246, 1310, 2430, 2440, 2552, 2571, 3255]
+REGRESSION_SEEDS = [1, 28, 56, 90, 113, 177, 603, 759, 826, 1108, 1116, 1246, 1310, 2430, 2440, 2552, 2571, 3255,
+                    20228, 21150, 23557, 23646, 23671, 26708]
 
 
 @pytest.fixture(scope="module")

@@ -62,7 +62,9 @@ for seed in map(int, sys.argv[1:]):
         d = np.abs(res["flat"][2] - res["o32"][2]); idx = np.unravel_index(np.argmax(d), d.shape)
         print("  worst d_vol voxel", idx, {k: float(res[k][2][idx]) for k in res}, "max|o64|", float(np.abs(o64[2]).max()),
               "nan in o32/o64:", bool(np.isnan(res['o32'][2]).any()), bool(np.isnan(o64[2]).any()))
-        print("  sorted top |o64| d_vol:", np.sort(np.abs(o64[2]).ravel())[-5:])
+        order = np.argsort(d.ravel())[::-1][:12]
+        print("  top differing voxels (flat - o32):", [(tuple(int(q) for q in np.unravel_index(o, d.shape)), float((res['flat'][2] - res['o32'][2]).ravel()[o])) for o in order])
+        print("  g range", float(np.abs(c['g']).min()), float(np.abs(c['g']).max()), "sum of differences", float((res['flat'][2] - res['o32'][2]).sum()), "sum |o32|", float(np.abs(res['o32'][2]).sum()))
     bad = np.argwhere(res["flat"][1] != res["o32"][1])
     for b in bad[:4]:
         b = tuple(b)

@@ -80,12 +80,13 @@ def make_case(seed):
     if rng.random() < 0.2:
         g *= np.exp(rng.uniform(-9, 9, size=(n_views, *WH, 1))).astype(np.float32)   # wide dynamic range of the upstream gradient
     want = [(True, True), (True, True), (True, False), (False, True)][int(rng.integers(0, 4))]
+    variant = 1 if seed % 6 == 5 else 0     # every sixth case runs the baseline kernels (DR_VARIANT_BASELINE) instead
     return dict(vshape=vshape, WH=WH, R=R, sr=sr, mode=mode, n_views=n_views, S=S, vol=vol, f16=f16, tf=tf, cam=cam,
-                jitter=jitter, strided=strided, g=g, want=want, vol_kind=int(kind), alpha_kind=int(ak))
+                jitter=jitter, strided=strided, g=g, want=want, vol_kind=int(kind), alpha_kind=int(ak), variant=variant, seed=seed)
 
 
 def describe(c):
-    return {k: c[k] for k in ("vshape", "WH", "R", "sr", "mode", "n_views", "S", "f16", "jitter", "strided", "want", "vol_kind", "alpha_kind")} | {"cam": c["cam"].tolist()}
+    return {k: c[k] for k in ("vshape", "WH", "R", "sr", "mode", "n_views", "S", "f16", "jitter", "strided", "want", "vol_kind", "alpha_kind", "variant", "seed")} | {"cam": c["cam"].tolist()}
 
 
 def run_case(c):
@@ -102,9 +103,21 @@ def run_case(c):
     else:
         vol = T(vol_h)
     tf, cam = T(tf_h), T(cam_h)
-    e, x, r, n = Fn.ray_setup(cam, WH, vshape, sr, jitter_seed=c["jitter"])
-    ws = Fn.alloc_workspace(c["n_views"], WH, vshape, c["R"], dev)
-    out, steps = Fn.march_fwd(vol, tf, cam, e, x, r, n, S, sr, mode, workspace=ws)
+    variant = c["variant"]
+    # the image as one piece, or (every seventh case) as two bands of rows the way a strong-scaling run splits one view
+    # across GPUs (dr_*_rows): the bands' ray buffers, images and step counts are concatenated, their gradients summed
+    W = WH[0]
+    cut = (1 + c["seed"] % (W - 1)) if (c["seed"] % 7 == 3 and W >= 2) else 0
+    bands = [(0, W)] if cut == 0 else [(0, cut), (cut, W - cut)]
+    c["bands"] = len(bands)
+    pieces = []
+    for row0, nr in bands:
+        rows = None if cut == 0 else (row0, W)
+        eb, xb, rb, nb = Fn.ray_setup(cam, (nr, WH[1]), vshape, sr, jitter_seed=c["jitter"], rows=rows)
+        wsb = Fn.alloc_workspace(c["n_views"], (nr, WH[1]), vshape, c["R"], dev) if variant == 0 else None
+        ob, sb = Fn.march_fwd(vol, tf, cam, eb, xb, rb, nb, S, sr, mode, variant=variant, workspace=wsb, rows=rows)
+        pieces.append((rows, row0, nr, eb, xb, rb, nb, wsb, ob, sb))
+    e, x, r, n, out, steps = (torch.cat([p[k] for p in pieces], dim=1) for k in (3, 4, 5, 6, 8, 9))
     eh, xh, rh, nh = (t.cpu().numpy() for t in (e, x, r, n))
     out_h, steps_h = out.cpu().numpy(), steps.cpu().numpy()
     if not np.isfinite(out_h).all():
@@ -131,19 +144,35 @@ def run_case(c):
             dv_ref += a; dt_ref += b
         wv, wt = c["want"]
         base = None
-        dv, dt = Fn.march_bwd(vol, tf, cam, e, x, r, n, S, sr, T(g), out, wv, wt, workspace=ws)
+        dv = dt = None
+        gt = T(g)
+        for rows, row0, nr, eb, xb, rb, nb, wsb, ob, sb in pieces:
+            dvb, dtb = Fn.march_bwd(vol, tf, cam, eb, xb, rb, nb, S, sr, gt[:, row0:row0 + nr].contiguous(), ob, wv, wt,
+                                    variant=variant, workspace=wsb, rows=rows)
+            dv = dvb if dv is None or dvb is None else dv + dvb
+            dt = dtb if dt is None or dtb is None else dt + dtb
         for name, got, ref in (("d_vol", dv, dv_ref), ("d_tf", dt, dt_ref)):
             if got is None:
                 continue
             got = got.float().cpu().numpy()
-            if not np.isfinite(got).all():
-                fails.append(f"{name} non-finite"); continue
             if not np.isfinite(ref).all():
                 # alpha == 1 at a sampling rate != 1: d/da (1 - a)^(1/sr) is infinite there, in the reference as well
-                # (its NaN / inf are what RaycastFunction.backward's nan_to_num is for): nothing to compare against
-                c["_undefined"] = True; continue
+                # (its NaN / inf are what RaycastFunction.backward's nan_to_num is for): nothing to compare against.
+                # The fast path still has to return finite values; the baseline kernels return what the oracle does.
+                c["_undefined"] = True
+                if variant == 0 and not np.isfinite(got).all():
+                    fails.append(f"{name} non-finite")
+                continue
+            if not np.isfinite(got).all():
+                fails.append(f"{name} non-finite"); continue
             scale = max(float(np.abs(ref).max()), 1e-12)
             err = float(np.abs(got - ref).max()) / scale
+            if variant == 1:
+                # the baseline kernels add every contribution with a float atomic (as the reference does): thousands land on
+                # a few texels of d_tf, in arbitrary order
+                if not err <= 1e-3:
+                    fails.append(f"{name} error {err:.3e} of max {scale:.3e} (baseline kernels)")
+                continue
             if not err <= 1e-4:
                 # Ill-conditioned case? Normalising a nearly vanishing gradient amplifies by 1/|grad|, and the f32 result then
                 # depends on the order of the float atomics at this level. The baseline kernels -- the oracle's arithmetic,
