@@ -165,7 +165,7 @@ __device__ __forceinline__ void sample_pos_rcp(float t0, float exit_, float nm1,
     px = fmaf(t, vx, cx); py = fmaf(t, vy, cy); pz = fmaf(t, vz, cz);
 }
 
-// (1 - a)^(1/sr) of VR.py:284-285 -- a SPECIFIED function shared with the oracle (oracle/dr_oracle.c, dro_pow_inv_sr),
+// (1 - a)^(1/sr) of VR.py:284-285 -- a SPECIFIED function (the CPU checker of the tests restates it),
 // because `ti.pow` is CUDA's approximate __powf in the reference (not a pinned function) and the result is ill-conditioned
 // in f32: one ulp of the power is a relative 1e-4 of the opacity at sampling rate 16 and small alpha, and whether a ray
 // crosses alpha 0.99 at sample s or s + 1 can hinge on it. Both sides evaluate, bit for bit:
