@@ -374,7 +374,7 @@ __device__ __forceinline__ float fix_wave_scale(float bmax, FixScale &f) {
     int sh = f.shift - 30 + eb;
     sh = sh < 1 ? 1 : (sh > 31 ? 31 : sh);  // sh > 31 cannot happen below 4 lim (DR_FIX_BITS + DR_FIX_LIM_BITS + 2 - 30 <= 31)
     f.sh = sh;
-    return ldexpf(1.0f, f.shift - sh);
+    return __uint_as_float((unsigned int)(127 + f.shift - sh) << 23);  // 2^(shift - sh): the exponent stays within [-119, 119]
 }
 // x already carries the factor 2^(shift - sh) and |x| < 2^31
 __device__ __forceinline__ void fix_add_scaled(unsigned long long *p, float x, const FixScale &f) {

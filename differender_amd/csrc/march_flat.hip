@@ -447,14 +447,15 @@ __device__ __forceinline__ int scan_max(int v, int lane) {
 }
 // largest of a non-negative float over the wave, wave-uniform (DPP; non-negative floats order like their bit patterns)
 __device__ __forceinline__ float wave_max_nonneg(float x) {
-    int v = __float_as_int(x);
-    { const int o = dpp_i<0x111>(v); v = max(v, o); }   // row_shr:1 (bound_ctrl: lanes without a source read 0)
-    { const int o = dpp_i<0x112>(v); v = max(v, o); }
-    { const int o = dpp_i<0x114>(v); v = max(v, o); }
-    { const int o = dpp_i<0x118>(v); v = max(v, o); }   // lane 15 of every row: the row's maximum
-    { const int o = dpp_i<0x142>(v); v = max(v, o); }   // row_bcast:15
-    { const int o = dpp_i<0x143>(v); v = max(v, o); }   // row_bcast:31 -> lane 63: the wave's maximum
-    return __int_as_float(__builtin_amdgcn_readlane(v, 63));
+    // unsigned max: 0 (what a lane without a DPP source reads) is its identity, so each step folds into one v_max_u32_dpp
+    unsigned int v = __float_as_uint(x);
+    v = max(v, (unsigned int)dpp_i<0x111>((int)v));   // row_shr:1
+    v = max(v, (unsigned int)dpp_i<0x112>((int)v));
+    v = max(v, (unsigned int)dpp_i<0x114>((int)v));
+    v = max(v, (unsigned int)dpp_i<0x118>((int)v));   // lane 15 of every row: the row's maximum
+    v = max(v, (unsigned int)dpp_i<0x142>((int)v));   // row_bcast:15
+    v = max(v, (unsigned int)dpp_i<0x143>((int)v));   // row_bcast:31 -> lane 63: the wave's maximum
+    return __uint_as_float((unsigned int)__builtin_amdgcn_readlane((int)v, 63));
 }
 __device__ __forceinline__ Over readlane_over(const Over &v, int lane) {
     Over r;
