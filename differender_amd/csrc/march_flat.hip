@@ -410,6 +410,30 @@ __device__ __forceinline__ Over seg_scan_over(Over v, int lane, int sl) {
 #undef DR_OVER_STEP
     return v;
 }
+// The backward needs the composites only through gC . C and A (the tape-free identity's suffix term): it scans the PAIR
+// (w, a), w = gC . c with the lane's own upstream colour gradient (constant over a segment = one ray), under the same
+// "over" -- half the scan of the forward's four channels.
+struct Over2 { float w, a; };
+__device__ __forceinline__ Over2 over2(const Over2 &front, const Over2 &back) {
+    const float T = 1.0f - front.a;
+    Over2 r;
+    r.w = fmaf(T, back.w, front.w); r.a = fmaf(T, back.a, front.a);
+    return r;
+}
+__device__ __forceinline__ Over2 seg_scan_over2(Over2 v, int lane, int sl) {
+#define DR_OVER2_STEP(CTRL, K)                                                    \
+    {                                                                             \
+        const float ow = dpp0_f<CTRL>(v.w), oa = dpp0_f<CTRL>(v.a);               \
+        if (scan_src_ok<K>(lane, sl)) {                                           \
+            const float T = 1.0f - oa;                                            \
+            fma_into(v.w, T, ow); fma_into(v.a, T, oa);                           \
+        }                                                                         \
+    }
+    DR_OVER2_STEP(0x111, 0) DR_OVER2_STEP(0x112, 1) DR_OVER2_STEP(0x114, 2) DR_OVER2_STEP(0x118, 3)
+    DR_OVER2_STEP(0x142, 4) DR_OVER2_STEP(0x143, 5)
+#undef DR_OVER2_STEP
+    return v;
+}
 // segmented inclusive SUM of NV values (same segment convention)
 template <int NV>
 __device__ __forceinline__ void seg_scan_sum(float (&v)[NV], int lane, int sl) {
@@ -744,6 +768,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
         if (cbase == 0) tk2 = clock64();
 #endif
         Over carry = {0.f, 0.f, 0.f, 0.f};
+        Over2 carry2 = {0.f, 0.f};  // the backward's pair (gC . C, A)
         int carry_e = -1;  // entry whose composite so far is in `carry` (continues into the next chunk)
         int e_cur = ea;
         for (int f0 = fa, ks = 1; f0 < fb; f0 += 64 * ks) {
@@ -822,6 +847,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
             bool valid = false;
             float dx = 0.f, dy = 0.f, dz = 0.f;
             Over el = {0.f, 0.f, 0.f, 0.f};
+            Over2 el2 = {0.f, 0.f};  // backward
             unsigned long long vm_fwd[KS];  // forward: which lanes hold an in-brick sample, per sub-sample
             // Lighting only matters where the sample has opacity: c = L*rgb*op is exactly 0 for op == 0 whatever L
             // is (the nondiff path skips alpha <= 1e-3 by definition, VR.py:334). Lanes are consecutive samples of a
@@ -848,7 +874,10 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                     if (BWD && __any(lit && near_lighting_kink(sm))) {
                         if (lit && near_lighting_kink(sm)) shade_from_grad<false>(dx, dy, dz, light, vd, MODE == DR_MODE_DIFF, sm);
                     }
-                    if (lit) { el.c0 = sm.L * sm.r * sm.op; el.c1 = sm.L * sm.g * sm.op; el.c2 = sm.L * sm.b * sm.op; el.a = sm.op; }
+                    if (lit) {
+                        if (BWD) { el2.w = (sm.L * sm.op) * (pf_go.x * sm.r + pf_go.y * sm.g + pf_go.z * sm.b); el2.a = sm.op; }
+                        else { el.c0 = sm.L * sm.r * sm.op; el.c1 = sm.L * sm.g * sm.op; el.c2 = sm.L * sm.b * sm.op; el.a = sm.op; }
+                    }
                 }
                 vm_fwd[0] = BWD ? 0ull : __ballot(valid);
             } else {
@@ -889,21 +918,27 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                 }
             }
             // segmented inclusive scan of "over" across the wave (segments = entries)
-            Over inc = seg_scan_over(el, lane, sl);
             // the first segment may continue an entry begun in an earlier chunk of this wave
             const int e_first = __builtin_amdgcn_readfirstlane(e);
             const bool cont = (carry_e == e_first);
-            Over exc = {0.f, 0.f, 0.f, 0.f};                  // composite before this sample, within the chunk
-            if (BWD) exc = shfl_up1_over(inc);
-            if (lane == sl) { exc.c0 = exc.c1 = exc.c2 = exc.a = 0.f; }
-            if (cont && e == e_first) { inc = over(carry, inc); exc = over(carry, exc); }
-            // carry out: composite of the last lane's entry if it continues past this chunk
-            {
-                const int e_last = __builtin_amdgcn_readlane(e, 63);
-                const Over last = readlane_over(inc, 63);
-                const bool more = (f0 + 64 * ks < fb) && (offs[e_last + 1] > f0 + 64 * ks);
-                carry = last; carry_e = more ? e_last : -1;
+            const int e_last = __builtin_amdgcn_readlane(e, 63);
+            const bool more = (f0 + 64 * ks < fb) && (offs[e_last + 1] > f0 + 64 * ks);
+            Over inc = {0.f, 0.f, 0.f, 0.f};
+            Over2 inc2 = {0.f, 0.f}, exc2 = {0.f, 0.f};   // backward: composite up to and including / before this sample, within the chunk
+            if (!BWD) {
+                inc = seg_scan_over(el, lane, sl);
+                if (cont && e == e_first) inc = over(carry, inc);
+                // carry out: composite of the last lane's entry if it continues past this chunk
+                carry = readlane_over(inc, 63);
+            } else {
+                inc2 = seg_scan_over2(el2, lane, sl);
+                exc2.w = wave_up1(inc2.w, 0.f); exc2.a = wave_up1(inc2.a, 0.f);
+                if (lane == sl) { exc2.w = 0.f; exc2.a = 0.f; }
+                if (cont && e == e_first) { inc2 = over2(carry2, inc2); exc2 = over2(carry2, exc2); }
+                carry2.w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inc2.w), 63));
+                carry2.a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inc2.a), 63));
             }
+            carry_e = more ? e_last : -1;
             const bool seg_end = act && (f + ks >= offs[e + 1]);
             if (!BWD) {
                 // count the in-brick samples of each segment piece, store finished segments
@@ -927,12 +962,13 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                 if (valid) {
                     const float4 pre = pf_pre, of = pf_of;  // lanes of a chunk share a few rays: broadcast-like cached loads
                     go = pf_go;
-                    const Over preo = {pre.x, pre.y, pre.z, pre.w};
-                    const Over absi = over(preo, inc);                       // composite up to and including s
-                    const float T = (1.0f - pre.w) * (1.0f - exc.a);         // transmittance before s
+                    // composite up to and including s, as (gC . C, A): the segment's stored prefix, then the chunk's scan
+                    const float Tpre = 1.0f - pre.w;
+                    const float absw = fmaf(Tpre, inc2.w, go.x * pre.x + go.y * pre.y + go.z * pre.z);
+                    const float absa = fmaf(Tpre, inc2.a, pre.w);
+                    const float T = Tpre * (1.0f - exc2.a);                  // transmittance before s
                     const bool last = (s == L.live[e] - 1);
-                    const float suffix = (go.x * (of.x - absi.c0) + go.y * (of.y - absi.c1) + go.z * (of.z - absi.c2)) +
-                                         go.w * (of.w - absi.a);
+                    const float suffix = ((go.x * of.x + go.y * of.y + go.z * of.z) - absw) + go.w * (of.w - absa);
                     sample_adjoint<true>(sm, vd, T, suffix, last, go, P.inv_sr, ad);
                 }
 #ifdef DR_ABL_NOSCATTER
