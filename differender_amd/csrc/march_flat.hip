@@ -1082,7 +1082,10 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                 const_cast<BrickCtxRec *>(P.ctx)[(size_t)view * nbricks + brick].live = 1;
         }
     }
-#if DR_PHASE_TIMING
+#if DR_PHASE_TIMING == 2
+    if (BWD && lane == 0)  // sample-loop time of each of the workgroup's waves (slot = wave)
+        atomicAdd(reinterpret_cast<unsigned long long *>(P.stats + ST_TIMING) + (wave & 7), (unsigned long long)(clock64() - tk2));
+#elif DR_PHASE_TIMING
     if (!ALPHA && threadIdx.x == 0) {  // per-phase clocks of this workgroup, summed over the grid (tools/phase_times.py)
         const long long tk3 = clock64();
         unsigned long long *tt = reinterpret_cast<unsigned long long *>(P.stats + ST_TIMING) + (BWD ? 3 : 0);
@@ -1092,7 +1095,14 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
     }
 #endif
     if (!BWD) return;
+#if DR_PHASE_TIMING == 1
+    const long long tk4 = clock64();
+#endif
     if (!__syncthreads_or(any)) return;  // uniform; also: every wave's LDS adds are done before the flush
+#if DR_PHASE_TIMING == 1
+    if (threadIdx.x == 0)  // wave 0 waiting for the slowest wave of the workgroup
+        atomicAdd(reinterpret_cast<unsigned long long *>(P.stats + ST_TIMING) + 7, (unsigned long long)(clock64() - tk4));
+#endif
     // flush: one pass of global float atomics per brick, walking the gradient's fastest axis
     if (WANT_VOL) {
         GradView dv = P.dvol;
@@ -1117,7 +1127,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
             if (raw != 0ull) unsafeAtomicAdd(dtf + k, acc_f64_to_float(raw));
         }
     }
-#if DR_PHASE_TIMING
+#if DR_PHASE_TIMING == 1
     __syncthreads();
     if (threadIdx.x == 0)  // whole lifetime of a backward workgroup, gradient flush included
         atomicAdd(reinterpret_cast<unsigned long long *>(P.stats + ST_TIMING) + 6, (unsigned long long)(clock64() - tk0));

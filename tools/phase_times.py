@@ -19,5 +19,7 @@ t = ws[:256].view(torch.int64).cpu().numpy().astype(float)
 nb = (N - 1 + 11) // 12
 nb = nb ** 3
 print("clock ticks per workgroup (sum over the grid / bricks)")
-print("fwd: staging+listing %.0f  wave split %.0f  sample loop %.0f" % tuple(t[26:29] / nb))
-print("bwd: staging+listing %.0f  wave split %.0f  sample loop %.0f  | whole workgroup incl. flush %.0f" % (t[29] / nb, t[30] / nb, t[31] / nb, t[25] / nb))
+B = 8   # stats word ST_TIMING = 16 -> 64-bit slot 8
+print("fwd: staging+listing %.0f  wave split %.0f  sample loop %.0f" % tuple(t[B:B + 3] / nb))
+print("bwd: wave 0 waits for the slowest wave %.0f" % (t[B + 7] / nb))
+print("bwd: staging+listing %.0f  wave split %.0f  sample loop %.0f  | whole workgroup incl. flush %.0f" % (t[B + 3] / nb, t[B + 4] / nb, t[B + 5] / nb, t[B + 6] / nb))
