@@ -1,0 +1,23 @@
+import sys, os, torch
+sys.path.insert(0, os.getcwd())
+from differender_amd import functional as F
+from differender_amd.utils import get_tf
+from bench import synth_volume_torch, bench_tf_torch, in_circles
+dev = torch.device("cuda:0")
+N, IMG, R = 512, 512, 256
+vol = synth_volume_torch(N, dev)
+for tfname in ("bench", "tf1"):
+    tf = bench_tf_torch(R, 1e-3, dev) if tfname == "bench" else get_tf("tf1", R).t().contiguous().to(dev)
+    for ci in (0.3, 1.7):
+        cam = torch.tensor([in_circles(ci)], dtype=torch.float32, device=dev)
+        ws = F.alloc_workspace(1, (IMG, IMG), (N,) * 3, R, dev)
+        e, x, r, n = F.ray_setup(cam, (IMG, IMG), (N,) * 3, 1.0)
+        out, steps = F.march_fwd(vol, tf, cam, e, x, r, n, 1 << 20, 1.0, workspace=ws)
+        ob, sb = F.march_fwd(vol, tf, cam, e, x, r, n, 1 << 20, 1.0, variant=1)
+        g = torch.randn(out.shape, generator=torch.Generator().manual_seed(5)).to(dev)
+        dv, dt = F.march_bwd(vol, tf, cam, e, x, r, n, 1 << 20, 1.0, g, out, workspace=ws)
+        db, dtb = F.march_bwd(vol, tf, cam, e, x, r, n, 1 << 20, 1.0, g, ob, variant=1)
+        d = (dv - db).abs()
+        print(tfname, ci, "steps equal", bool(torch.equal(steps, sb)), "fwd max diff %.2e" % float((out - ob).abs().max()),
+              "d_vol max diff / max %.3e" % (float(d.max()) / float(db.abs().max())), "voxels beyond 1e-4 of max:", int((d > 1e-4 * db.abs().max()).sum()),
+              "beyond 3e-5:", int((d > 3e-5 * db.abs().max()).sum()), "d_tf %.3e" % (float((dt - dtb).abs().max()) / float(dtb.abs().max())), flush=True)

@@ -3,7 +3,7 @@ tests/test_gpu_parity.py::test_random_configurations -- ragged and anisotropic v
 1..3 views sharing a volume, TF sizes 1..300 with empty / opaque / spiky alpha, sampling rates 0.3..16, clipped
 max_samples, fp16 and strided volumes, jitter, cameras anywhere (inside the volume, on a face, far away, axis aligned).
 
-    python tools/fuzz_parity.py [seconds=300] [first_seed=0]
+    python tools/fuzz_parity.py [seconds=300] [first_seed=0]          (FUZZ_SCALE=3: volumes and images three times the size)
 
 Prints one line per failing configuration (with the seed that reproduces it) and a summary; exit code 1 on any failure.
 Tolerances are those of the parity tests: ray setup and steps bit-exact, RGBA 1e-5, gradients 1e-4 of the tensor's largest
@@ -28,15 +28,19 @@ def T(a):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
 
+SCALE = int(os.environ.get("FUZZ_SCALE", "1"))   # 3: volumes up to 288 per axis, images up to 288 px (a case takes seconds)
+
+
 def make_case(seed):
     rng = np.random.default_rng(770000 + seed)
     big = rng.random() < 0.25
-    hi = 97 if big else 40
+    hi = (97 if big else 40) * SCALE - (SCALE - 1)
     vshape = tuple(int(v) for v in rng.integers(2, hi, 3))
     if rng.random() < 0.15:   # strongly anisotropic
-        vshape = tuple(int(v) for v in (rng.integers(2, 9), rng.integers(30, hi), rng.integers(2, hi)))
+        vshape = tuple(int(v) for v in (rng.integers(2, 9), rng.integers(min(30, hi - 1), hi), rng.integers(2, hi)))
         vshape = tuple(np.array(vshape)[rng.permutation(3)].tolist())
-    WH = (int(rng.integers(1, 97 if big else 49)), int(rng.integers(1, 97 if big else 49)))
+    wh_hi = (97 if big else 49) * SCALE - (SCALE - 1)
+    WH = (int(rng.integers(1, wh_hi)), int(rng.integers(1, wh_hi)))
     R = int(rng.choice([1, 2, 3, 7, 16, 64, 128, 256, 300]))
     sr = float(rng.choice([0.3, 0.6, 1.0, 1.0, 1.0, 1.5, 2.0, 3.0, 4.0, 8.0, 16.0]))
     mode = int(rng.random() < 0.35)
