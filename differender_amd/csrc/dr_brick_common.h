@@ -9,7 +9,7 @@
 namespace dr {
 
 // Overflow work item: candidates [c0, c1) of one brick of one view (march_flat.hip, brick_flat_items_kernel).
-struct BrickItem { int view, brick, c0, c1; };
+struct BrickItem { int view, brick, c0, c1; };   // brick: its DISPATCH SLOT (the index of its record, see near_first_brick)
 constexpr int ITEM_CAP = 1 << 18;     // items the workspace holds, 4 MB (a 512^2 view from inside a 512^3 volume makes ~160 000;
                                       // items beyond the cap are dropped: their rays fail the count check and are marched whole)
 constexpr int CTX_MAIN_CAND = 1024;   // candidates of a brick the main launch takes (= MAIN_CAND of march_flat.hip)
@@ -159,6 +159,28 @@ __device__ __forceinline__ void brick_setup(const BrickParams<VT> &P, int b, f3 
     c.j0 = max(0, (int)ceilf(pymin - DR_RECT_SLACK)); c.j1 = min(P.H - 1, (int)floorf(pymax + DR_RECT_SLACK));
 }
 
+// Dispatch order: workgroup i of a view takes the i-th brick counted from the corner of the volume NEAREST the camera
+// (perspective puts the most rays, hence the most samples, into the bricks close to the eye: with the plain index order
+// an orbit camera on the +x side had its heaviest bricks dispatched last, and the launch ended on a few long workgroups).
+#ifndef DR_NEAR_FIRST
+#define DR_NEAR_FIRST 1
+#endif
+template <typename VT>
+__device__ __forceinline__ int near_first_brick(const BrickParams<VT> &P, int i, int view) {
+#if DR_NEAR_FIRST
+    const int NBx = P.g.NBx, NBy = P.g.NBy, NBz = P.g.NBz;
+    int iz = i % NBz, iy = (i / NBz) % NBy, ix = i / (NBz * NBy);
+    if (P.cam[3 * view] > 0.0f) ix = NBx - 1 - ix;
+    if (P.cam[3 * view + 1] > 0.0f) iy = NBy - 1 - iy;
+    if (P.cam[3 * view + 2] > 0.0f) iz = NBz - 1 - iz;
+    return (ix * NBy + iy) * NBz + iz;
+#else
+    return i;
+#endif
+}
+
+// The records are STORED in that order (record i of a view = the brick dispatched i-th), so that a workgroup's first load
+// does not wait for the camera position; a work item names its brick by the same dispatch slot.
 // One thread per (brick, view): brick_setup once, for all passes of a forward/backward pair. The forward launches it
 // with forward = 1 (live flags cleared, DR_CTX_MARK left in stats[ST_MARK]: "records and live flags are the flat
 // forward's"); the backward recomputes the geometry (it may follow a forward of another kernel variant) and keeps
@@ -205,8 +227,9 @@ static __global__ __launch_bounds__(256) void brick_ctx_kernel(BrickParams<VT> P
     r.bx = c.bx; r.by = c.by; r.bz = c.bz; r.layer = c.layer;
     for (int k = 0; k < 3; ++k) { r.lo[k] = c.lo[k]; r.hi[k] = c.hi[k]; }
     r.i0 = c.i0; r.i1 = c.i1; r.j0 = c.j0; r.j1 = c.j1; r.pad1 = 0;
-    r.live = forward ? 0 : out[(size_t)view * nbricks + b].live;
-    out[(size_t)view * nbricks + b] = r;
+    const int slot_b = near_first_brick(P, b, view);  // (an involution: slot -> brick and brick -> slot are the same flips)
+    r.live = forward ? 0 : out[(size_t)view * nbricks + slot_b].live;
+    out[(size_t)view * nbricks + slot_b] = r;
     if (forward && c.i0 <= c.i1 && c.j0 <= c.j1) {
         // a brick with more candidate pixels than the main launch takes: cut the rest into work items
         // (item size: 1024 to 4096 candidates, a full-image brick makes at most 64 items up to 512^2 pixels; most candidates of
@@ -215,7 +238,7 @@ static __global__ __launch_bounds__(256) void brick_ctx_kernel(BrickParams<VT> P
         const int item_cand = min(max(1024, ((P.W * P.H / 64) + 255) & ~255), CTX_ITEM_MAX_CAND);
         for (int c0 = CTX_MAIN_CAND; c0 < ncand; c0 += item_cand) {
             const unsigned int slot = atomicAdd(P.n_items, 1u);
-            if (slot < (unsigned int)ITEM_CAP) P.items[slot] = BrickItem{view, b, c0, min(c0 + item_cand, ncand)};
+            if (slot < (unsigned int)ITEM_CAP) P.items[slot] = BrickItem{view, slot_b, c0, min(c0 + item_cand, ncand)};
         }
     }
 }

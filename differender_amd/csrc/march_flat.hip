@@ -654,7 +654,7 @@ __device__ __forceinline__ float wave_min_f(float v) {
 // candidates by brick_ctx_kernel, which a second, small launch works off (brick_flat_items_kernel). Without that, the few
 // bricks next to the camera would each be one workgroup's job: 61 ms instead of 6 for a 512^2 view from inside a 512^3 volume.
 template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, bool ALPHA, int KF, bool HEAVY>
-__device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsigned char *smem, const int brick, const int view,
+__device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsigned char *smem, const int slot, const int view,
                                                 const int c_lo, const int c_hi) {
     if (ALPHA && P.vflags[view] == 0u) return;  // uniform: no ray of this view can terminate early
     constexpr int EC = BWD ? FEC_BWD : FEC_FWD;
@@ -663,9 +663,13 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
     constexpr int FNW = FNT / 64;
     constexpr int KS = BWD ? 1 : KF;  // consecutive samples per lane (forward and alpha pre-pass)
     const int nbricks = P.g.NBx * P.g.NBy * P.g.NBz;
+#if DR_PHASE_TIMING == 3
+    const long long tq0 = clock64();
+#endif
     const f3 cam = make_f3(P.cam[3 * view], P.cam[3 * view + 1], P.cam[3 * view + 2]);
     BrickCtx c;
-    brick_ctx_load(P.ctx + (size_t)view * nbricks + brick, c);  // uniform address: scalar loads
+    // the records are stored in dispatch order (near-first, brick_ctx_kernel): the address does not wait for the camera
+    brick_ctx_load(P.ctx + (size_t)view * nbricks + slot, c);  // uniform address: scalar loads
     if (c.i0 > c.i1 || c.j0 > c.j1) return;  // uniform: the brick projects outside the image
     if (ALPHA) {  // uniform: is this brick part of this phase of the pre-pass? (camera inside the volume: one phase, all bricks)
         if (P.vflags[P.n_views + view] ? !P.pp_first : (c.layer < P.pp_l0 || c.layer >= P.pp_l1)) return;
@@ -723,6 +727,9 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
         r_lo = 0; r_hi = *nhit;
         if (r_hi == 0) return;  // uniform
     }
+#if DR_PHASE_TIMING == 3
+    const long long tq1 = clock64();   // (the brick record has arrived: c.i0 .. were compared above)
+#endif
     CandData cd;
     cand_load<VT, MODE, BWD, ALPHA>(P, c, view, r_lo, r_hi, hits, c_lo, ncand_all, cd);  // ray buffers of the first round's candidates
     BoxStage<FNT> stage;
@@ -750,8 +757,23 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
         }
         flat_build_entries<VT, MODE, BWD, FNT, ALPHA, KS>(P, c, cam, view, cd, L, nE0, M0);  // ... while the segments are listed
     }
+#if DR_PHASE_TIMING == 3
+    const long long tq2 = clock64();   // candidates loaded and listed
+#endif
     box_commit<VT, FNT>(P, vol, c, P.tf + view * P.tf_vs, stage, L);
+#if DR_PHASE_TIMING == 3
+    const long long tq3 = clock64();   // box arrived and stored
+#endif
     __syncthreads();
+#if DR_PHASE_TIMING == 3
+    if (!BWD && !ALPHA && threadIdx.x == 0) {  // forward prologue, thread 0 (tools/phase_times.py)
+        unsigned long long *tt = reinterpret_cast<unsigned long long *>(P.stats + ST_TIMING);
+        atomicAdd(tt + 0, (unsigned long long)(tq1 - tq0));
+        atomicAdd(tt + 1, (unsigned long long)(tq2 - tq1));
+        atomicAdd(tt + 2, (unsigned long long)(tq3 - tq2));
+        atomicAdd(tt + 3, (unsigned long long)(clock64() - tq3));
+    }
+#endif
     bool acc64 = false;  // brick-uniform: d_volume accumulates in double
     if (BWD && WANT_VOL) {
         // this brick's fixed-point scale, or doubles if its candidates' |grad_out| span more than 2^DR_MIXED_BITS
@@ -1099,13 +1121,13 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                 if (v > 0) { P.seg_cnt[seg_view + L.segi[e]] = (uint16_t)min(v, 65535); some = true; }
             }
             if (!ALPHA && __any(some) && lane == 0)  // tell the backward that this brick holds live samples of the view
-                const_cast<BrickCtxRec *>(P.ctx)[(size_t)view * nbricks + brick].live = 1;
+                const_cast<BrickCtxRec *>(P.ctx)[(size_t)view * nbricks + slot].live = 1;
         }
     }
 #if DR_PHASE_TIMING == 2
     if (BWD && lane == 0)  // sample-loop time of each of the workgroup's waves (slot = wave)
         atomicAdd(reinterpret_cast<unsigned long long *>(P.stats + ST_TIMING) + (wave & 7), (unsigned long long)(clock64() - tk2));
-#elif DR_PHASE_TIMING
+#elif DR_PHASE_TIMING == 1
     if (!ALPHA && threadIdx.x == 0) {  // per-phase clocks of this workgroup, summed over the grid (tools/phase_times.py)
         const long long tk3 = clock64();
         unsigned long long *tt = reinterpret_cast<unsigned long long *>(P.stats + ST_TIMING) + (BWD ? 3 : 0);
@@ -1156,26 +1178,6 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
 
 constexpr int ITEM_GRID = 1024;  // workgroups of the overflow launch (they loop over the items)
 
-// Dispatch order: workgroup i of a view takes the i-th brick counted from the corner of the volume NEAREST the camera
-// (perspective puts the most rays, hence the most samples, into the bricks close to the eye: with the plain index order
-// an orbit camera on the +x side had its heaviest bricks dispatched last, and the launch ended on a few long workgroups).
-#ifndef DR_NEAR_FIRST
-#define DR_NEAR_FIRST 1
-#endif
-template <typename VT>
-__device__ __forceinline__ int near_first_brick(const BrickParams<VT> &P, int i, int view) {
-#if DR_NEAR_FIRST
-    const int NBx = P.g.NBx, NBy = P.g.NBy, NBz = P.g.NBz;
-    int iz = i % NBz, iy = (i / NBz) % NBy, ix = i / (NBz * NBy);
-    if (P.cam[3 * view] > 0.0f) ix = NBx - 1 - ix;
-    if (P.cam[3 * view + 1] > 0.0f) iy = NBy - 1 - iy;
-    if (P.cam[3 * view + 2] > 0.0f) iz = NBz - 1 - iz;
-    return (ix * NBy + iy) * NBz + iz;
-#else
-    return i;
-#endif
-}
-
 template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, bool ALPHA = false, int KF = 1>
 __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FWD_WAVES) void brick_flat_kernel(BrickParams<VT> P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1185,7 +1187,7 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
     const int nv = P.n_views;
     brick_flat_body<VT, MODE, BWD, WANT_VOL, WANT_TF, ALPHA, KF, false>(P, smem, blockIdx.x / nv, blockIdx.x % nv, 0, MAIN_CAND);
 #else
-    brick_flat_body<VT, MODE, BWD, WANT_VOL, WANT_TF, ALPHA, KF, false>(P, smem, near_first_brick(P, blockIdx.x, blockIdx.y), blockIdx.y,
+    brick_flat_body<VT, MODE, BWD, WANT_VOL, WANT_TF, ALPHA, KF, false>(P, smem, blockIdx.x, blockIdx.y,
                                                                        0, MAIN_CAND);
 #endif
 }

@@ -23,3 +23,4 @@ B = 8   # stats word ST_TIMING = 16 -> 64-bit slot 8
 print("fwd: staging+listing %.0f  wave split %.0f  sample loop %.0f" % tuple(t[B:B + 3] / nb))
 print("bwd: wave 0 waits for the slowest wave %.0f" % (t[B + 7] / nb))
 print("bwd: staging+listing %.0f  wave split %.0f  sample loop %.0f  | whole workgroup incl. flush %.0f" % (t[B + 3] / nb, t[B + 4] / nb, t[B + 5] / nb, t[B + 6] / nb))
+print("(library built with -DDR_PHASE_TIMING=3 instead: forward prologue of thread 0 = brick record %.0f, candidates loaded + listed %.0f, box arrived + stored %.0f, barrier %.0f)" % tuple(t[B:B + 4] / nb))
