@@ -174,7 +174,8 @@ __device__ __forceinline__ void sample_pos_rcp(float t0, float exit_, float nm1,
 //     of the ~100 of powf, which at sampling rate 8 was most of the arithmetic of the alpha pre-pass.
 //   * any other exponent: exp2(y * log2(x)) in DOUBLE precision from IEEE +, -, *, / only (an atanh series for the
 //     logarithm, a Taylor polynomial for the exponential; relative error < 1e-11), rounded once to float: the
-//     correctly rounded power but for ~1e-4 of the arguments, and the same float on any IEEE platform always.
+//     correctly rounded power on every one of 4e5 sampled arguments (CPU test of the same formula), and the same float on
+//     any IEEE platform always. Every translation unit is built with -ffp-contract=off: p * z2 + c is a multiply and an add.
 __device__ __forceinline__ float pow_spec(float x, float y) {
     if (!(x > 0.0f)) return (x == 0.0f) ? 0.0f : __builtin_nanf("");
     const long long bits = __double_as_longlong((double)x);
