@@ -132,7 +132,9 @@ def self_launch(args):
         except subprocess.TimeoutExpired:
             p.kill()
             rcs.append(-9)
-    sys.stdout.write(out.decode())
+    for ln in out.decode().splitlines():      # rank 0's JSON line (its stdout carries nothing else: claim_stdout)
+        if ln.startswith("{"):
+            sys.stdout.write(ln + "\n")
     sys.stdout.flush()
     return max(abs(rc) for rc in rcs)
 
@@ -204,7 +206,9 @@ def init_dist(args):
     torch.cuda.set_device(local_rank % ndev)  # (% ndev only matters for the shared-card rehearsal)
     dev = torch.device("cuda", local_rank % ndev)
     dist, backend = None, None
-    if world > 1:
+    # DR_BENCH_FORCE_DIST=1 (with DR_ALLREDUCE_SINGLE_RANK=1): the whole N > 1 control flow -- RCCL communicator, overlapped
+    # gradient all-reduce, barriers, max over ranks -- with the ONE rank a one-GPU box allows (a rehearsal, not a scaling number)
+    if world > 1 or os.environ.get("DR_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -216,10 +220,31 @@ def init_dist(args):
     return world, rank, dev, dist, backend
 
 
+_JSON_OUT = None
+
+
+def claim_stdout():
+    """The contract is ONE JSON line on stdout. RCCL prints a banner there when a communicator is created (C-level stdio),
+    and any other library might: from here on file descriptor 1 is stderr, and the line goes to the descriptor kept here."""
+    global _JSON_OUT
+    if _JSON_OUT is None:
+        sys.stdout.flush()
+        _JSON_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+    return _JSON_OUT
+
+
+def emit(line):
+    out = claim_stdout()
+    out.write(json.dumps(line) + "\n")
+    out.flush()
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
+    claim_stdout()
     if args.workload == "opt":
         return main_opt(args)
     args.vol = args.vol or 512
@@ -294,7 +319,7 @@ def main():
             b1.record()
             if timed:
                 ev["bwd"].append((b0, b1))
-            if world > 1:
+            if dist is not None:
                 # RCCL sum of the shared gradients on its own stream: it overlaps the next step's forward; the
                 # previous step's reduction is awaited first so at most one is in flight (and all before timing ends)
                 reducer.submit([dv, dt])
@@ -421,7 +446,7 @@ def main():
         "rays_repaired": (int(stats[0]) if stats is not None else None),
         "cpu_baseline": cpu_baseline,
     }
-    print(json.dumps(line))
+    emit(line)
 
 
 # ------------------------------------------------------------------------------------------------ the demo loop
@@ -531,7 +556,7 @@ def main_opt(args):
         "ms_host_overhead": round(it_ms - gpu_ms, 4),   # wall time per iteration not covered by the GPU phases above
         "loss_first_last": [round(float(losses[0]), 6), round(float(losses[-1]), 6)] if losses else None,
     }
-    print(json.dumps(line))
+    emit(line)
 
 
 def run_cpu_baseline(vol, tf, args, sr, want_vol, want_tf):

@@ -35,9 +35,12 @@ def all_reduce_gradients(grads, group=None, async_op=False):
     """Sum-all-reduce the shared gradients in place (d_volume: one large message, so the ring is
     bandwidth-bound on the xGMI links; d_tf: a few KiB, latency-bound). Large tensors go as they are --
     they are already one contiguous bucket each; small ones are coalesced into a single message."""
+    import os
     import torch.distributed as dist
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_available() or not dist.is_initialized():
         return []
+    if dist.get_world_size(group) == 1 and os.environ.get("DR_ALLREDUCE_SINGLE_RANK") != "1":
+        return []   # (the variable makes a one-rank group go through RCCL all the same: the only way to test this path on one GPU)
     handles = []
     small = [g for g in grads if g is not None and g.numel() * g.element_size() < (1 << 20)]
     large = [g for g in grads if g is not None and g.numel() * g.element_size() >= (1 << 20)]

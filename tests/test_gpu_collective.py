@@ -42,3 +42,42 @@ def test_calls_run_on_the_device_of_their_buffers(hiplib, oracle):
     ref, _, _ = oracle.render(vol.cpu().numpy(), tf.cpu().numpy(), oracle.in_circles(0.2), (16, 16), S=4096)
     assert np.abs(out[0].cpu().numpy() - ref).max() <= 1e-5
     assert torch.cuda.current_device() == 0
+
+
+_NCCL_ONE_RANK = r"""
+import os, sys, socket
+sys.path.insert(0, os.environ["DR_ROOT"])
+import torch, torch.distributed as dist
+s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DR_ALLREDUCE_SINGLE_RANK="1")
+dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)      # "nccl" IS RCCL on ROCm
+from differender_amd.distributed import GradientReducer, all_reduce_gradients
+big = torch.arange(96 * 64 * 80, dtype=torch.float32, device=dev).reshape(96, 64, 80).permute(2, 0, 1)   # dense, not contiguous, > 1 MiB
+small = torch.linspace(0, 1, 64, device=dev).reshape(16, 4)
+ref_b, ref_s = big.clone(), small.clone()
+all_reduce_gradients([big, small, None])
+torch.cuda.synchronize()
+assert torch.equal(big, ref_b) and torch.equal(small, ref_s)             # a sum over one rank is the identity
+red = GradientReducer()
+for step in range(3):                                                    # bench.py's pattern: at most one reduction in flight
+    g = (big * float(step + 1)).contiguous().permute(1, 2, 0)
+    want = g.clone()
+    done = red.submit([g, small.clone()])
+    last = (g, want)
+out = red.wait(); torch.cuda.synchronize()
+assert torch.equal(out[0], last[1])
+dist.barrier(); dist.destroy_process_group()
+print("NCCL_ONE_RANK_OK")
+"""
+
+
+def test_torch_rccl_backend_one_rank_gradient_reduction():
+    """torch.distributed's "nccl" backend (= RCCL) on this box, the code path of bench.py --gpus N and of
+    differender_amd.distributed -- with the one rank a one-GPU box allows: communicator set-up, the sum all-reduce of a dense
+    non-contiguous gradient through its flat storage view, the coalesced small message, the overlapped reducer."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DR_ROOT=root, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _NCCL_ONE_RANK], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "NCCL_ONE_RANK_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
