@@ -51,6 +51,8 @@ enum {
     ST_REPAIR = 0,         // rays whose segments failed the sample-count check and were marched whole (expected 0)
     ST_BASELINE_RAYS = 2,  // rays the per-ray fallback marched in the last forward (irregular rays + repaired ones)
     ST_MARK = 3,           // DR_CTX_MARK once the flat forward has written brick records and live flags
+    ST_TICKET = 6,         // work-item launches: next item to hand out / workgroups done (the last one resets both to 0)
+    ST_DONE = 7,
     ST_NITEMS = 5,         // diagnostic copy of the number of overflow work items of the last forward (heavy bricks: BrickItem)
     ST_F64_BRICKS = 4,     // backward: (view, brick) pairs whose d_volume box accumulated in double (wide local range of |grad_out|)
     ST_TIMING = 16,        // DR_PHASE_TIMING: u64 x3 forward phases, u64 x3 backward phases, u64 backward lifetime
@@ -215,7 +217,7 @@ static __global__ __launch_bounds__(256) void brick_ctx_kernel(BrickParams<VT> P
                 const float lim = 1.0f + 1e-3f;
                 P.vflags[view] = flag;
                 P.vflags[P.n_views + view] = (fabsf(cx) <= lim && fabsf(cy) <= lim && fabsf(cz) <= lim) ? 1u : 0u;
-                if (view == 0) { P.stats[ST_REPAIR] = 0u; P.stats[ST_BASELINE_RAYS] = 0u; P.stats[ST_F64_BRICKS] = 0u; P.stats[ST_MARK] = DR_CTX_MARK; }
+                if (view == 0) { P.stats[ST_REPAIR] = 0u; P.stats[ST_BASELINE_RAYS] = 0u; P.stats[ST_F64_BRICKS] = 0u; P.stats[ST_TICKET] = 0u; P.stats[ST_DONE] = 0u; P.stats[ST_MARK] = DR_CTX_MARK; }
             }
         }
     }
@@ -236,10 +238,12 @@ static __global__ __launch_bounds__(256) void brick_ctx_kernel(BrickParams<VT> P
         // such bricks fail the item's geometric pre-test and cost nothing further)
         const int ncand = (c.i1 - c.i0 + 1) * (c.j1 - c.j0 + 1);
         const int item_cand = min(max(1024, ((P.W * P.H / 64) + 255) & ~255), CTX_ITEM_MAX_CAND);
-        for (int c0 = CTX_MAIN_CAND; c0 < ncand; c0 += item_cand) {
-            const unsigned int slot = atomicAdd(P.n_items, 1u);
+        // (one reservation per brick: its items are consecutive, so that a workgroup taking a run of items keeps the brick's
+        // voxel box staged across them)
+        const int n_it = ncand > CTX_MAIN_CAND ? (ncand - CTX_MAIN_CAND + item_cand - 1) / item_cand : 0;
+        unsigned int slot = n_it ? atomicAdd(P.n_items, (unsigned int)n_it) : 0u;
+        for (int c0 = CTX_MAIN_CAND; c0 < ncand; c0 += item_cand, ++slot)
             if (slot < (unsigned int)ITEM_CAP) P.items[slot] = BrickItem{view, slot_b, c0, min(c0 + item_cand, ncand)};
-        }
     }
 }
 

@@ -655,7 +655,7 @@ __device__ __forceinline__ float wave_min_f(float v) {
 // bricks next to the camera would each be one workgroup's job: 61 ms instead of 6 for a 512^2 view from inside a 512^3 volume.
 template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, bool ALPHA, int KF, bool HEAVY>
 __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsigned char *smem, const int slot, const int view,
-                                                const int c_lo, const int c_hi) {
+                                                const int c_lo, const int c_hi, bool &box_valid) {
     if (ALPHA && P.vflags[view] == 0u) return;  // uniform: no ray of this view can terminate early
     constexpr int EC = BWD ? FEC_BWD : FEC_FWD;
     constexpr int ROUND = (BWD && DR_BWD_UNEVEN) ? 4 * (8 * DR_BWD_UNEVEN + 4 * (8 - DR_BWD_UNEVEN)) : EC;  // candidates consumed per round (cand_load)
@@ -730,6 +730,9 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
 #if DR_PHASE_TIMING == 3
     const long long tq1 = clock64();   // (the brick record has arrived: c.i0 .. were compared above)
 #endif
+    // A work item that follows another item of the same brick in its workgroup finds the voxel box (and the TF) in LDS already.
+    // (Forward and pre-pass only: the backward's gradient box is flushed per item.)
+    const bool reuse_box = HEAVY && !BWD && box_valid;  // uniform
     CandData cd;
     cand_load<VT, MODE, BWD, ALPHA>(P, c, view, r_lo, r_hi, hits, c_lo, ncand_all, cd);  // ray buffers of the first round's candidates
     BoxStage<FNT> stage;
@@ -742,11 +745,11 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
     if (lazy) {
         flat_build_entries<VT, MODE, BWD, FNT, ALPHA, KS>(P, c, cam, view, cd, L, nE0, M0);
         if (!__syncthreads_or(nE0 > 0) && r_hi - r_lo <= ROUND) return;  // uniform: no wave found a segment
-        box_issue<VT, FNT>(P, vol, c, P.tf + view * P.tf_vs, stage);
+        if (!reuse_box) box_issue<VT, FNT>(P, vol, c, P.tf + view * P.tf_vs, stage);
     } else {
         float gm = 0.0f, gn = 3.0e38f;
         if (BWD && WANT_VOL) cand_grad_range<VT, FNT>(P, c, view, r_lo, r_hi, hits, c_lo, ncand_all, gm, gn);  // upstream gradients of the candidates,
-        box_issue<VT, FNT>(P, vol, c, P.tf + view * P.tf_vs, stage);      // voxel box + TF: in flight ...
+        if (!reuse_box) box_issue<VT, FNT>(P, vol, c, P.tf + view * P.tf_vs, stage);      // voxel box + TF: in flight ...
         if (BWD) {
             if (WANT_VOL) for (int k = threadIdx.x; k < BOX_LDS; k += FNT) L.dbox[k] = 0ull;
             if (WANT_TF) for (int k = threadIdx.x; k < 4 * P.R; k += FNT) L.dtf[k] = 0ull;
@@ -760,7 +763,8 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
 #if DR_PHASE_TIMING == 3
     const long long tq2 = clock64();   // candidates loaded and listed
 #endif
-    box_commit<VT, FNT>(P, vol, c, P.tf + view * P.tf_vs, stage, L);
+    if (!reuse_box) box_commit<VT, FNT>(P, vol, c, P.tf + view * P.tf_vs, stage, L);
+    box_valid = true;
 #if DR_PHASE_TIMING == 3
     const long long tq3 = clock64();   // box arrived and stored
 #endif
@@ -1177,6 +1181,10 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
 }
 
 constexpr int ITEM_GRID = 1024;  // workgroups of the overflow launch (they loop over the items)
+#ifndef DR_ITEM_RUN
+#define DR_ITEM_RUN 2   // camera inside a 512^3 volume, fwd / bwd ms: static striding 11.3 / 19.8; runs of 1: 10.0 / 17.9, 2: 9.2 / 16.2, 3: 9.3 / 16.5, 4: 9.9 / 17.4, 8: 13.2 / 22.6
+#endif
+constexpr int ITEM_RUN = DR_ITEM_RUN;   // consecutive items a workgroup takes at a time
 
 template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, bool ALPHA = false, int KF = 1>
 __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FWD_WAVES) void brick_flat_kernel(BrickParams<VT> P) {
@@ -1185,10 +1193,12 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
     // (tried: consecutive workgroups = the same brick of consecutive views, so that the box comes from L2 after its first
     // read -- 2 % slower with 8 views, 13 % on the demo loop)
     const int nv = P.n_views;
-    brick_flat_body<VT, MODE, BWD, WANT_VOL, WANT_TF, ALPHA, KF, false>(P, smem, blockIdx.x / nv, blockIdx.x % nv, 0, MAIN_CAND);
+    bool bv = false;
+    brick_flat_body<VT, MODE, BWD, WANT_VOL, WANT_TF, ALPHA, KF, false>(P, smem, blockIdx.x / nv, blockIdx.x % nv, 0, MAIN_CAND, bv);
 #else
+    bool bv = false;
     brick_flat_body<VT, MODE, BWD, WANT_VOL, WANT_TF, ALPHA, KF, false>(P, smem, blockIdx.x, blockIdx.y,
-                                                                       0, MAIN_CAND);
+                                                                       0, MAIN_CAND, bv);
 #endif
 }
 // the overflow items of heavy bricks (all views), worked off by a fixed, small grid
@@ -1197,10 +1207,32 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int n_items = min((int)*P.n_items, ITEM_CAP);
     if (blockIdx.x == 0 && threadIdx.x == 0) P.stats[ST_NITEMS] = *P.n_items;
-    for (int it = blockIdx.x; it < n_items; it += gridDim.x) {  // uniform
-        const BrickItem item = P.items[it];
-        brick_flat_body<VT, MODE, BWD, WANT_VOL, WANT_TF, ALPHA, KF, true>(P, smem, item.brick, item.view, item.c0, item.c1);
-        __syncthreads();  // the next item reuses the LDS
+    // Runs of ITEM_RUN consecutive items (consecutive items belong to one brick, brick_ctx_kernel) are handed out through a
+    // ticket: the items differ widely in work, and within a run the brick's box stays staged.
+    if (n_items == 0) return;  // uniform over the grid: nobody touches the ticket
+    __shared__ int s_first;
+    for (int round = 0;; ++round) {  // uniform
+        // first run: by workgroup index; further runs: from the ticket (1024 returning atomics on one address take ~30 us)
+        int first = blockIdx.x * ITEM_RUN;
+        if (round > 0) {
+            if (threadIdx.x == 0) s_first = (int)gridDim.x * ITEM_RUN + (int)atomicAdd(&P.stats[ST_TICKET], (unsigned int)ITEM_RUN);
+            __syncthreads();
+            first = s_first;
+            __syncthreads();
+        }
+        if (first >= n_items) break;
+        bool box_valid = false;
+        int pv = -1, ps = -1;
+        for (int it = first; it < min(first + ITEM_RUN, n_items); ++it) {
+            const BrickItem item = P.items[it];
+            if (item.view != pv || item.brick != ps) { box_valid = false; pv = item.view; ps = item.brick; }
+            brick_flat_body<VT, MODE, BWD, WANT_VOL, WANT_TF, ALPHA, KF, true>(P, smem, item.brick, item.view, item.c0, item.c1, box_valid);
+            __syncthreads();  // the next item reuses the LDS
+        }
+    }
+    // the last workgroup to leave resets the ticket for the next launch
+    if (threadIdx.x == 0 && atomicAdd(&P.stats[ST_DONE], 1u) == gridDim.x - 1) {
+        P.stats[ST_TICKET] = 0u; P.stats[ST_DONE] = 0u;
     }
 }
 
