@@ -1180,7 +1180,15 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
 #endif
 }
 
-constexpr int ITEM_GRID = 1024;  // workgroups of the overflow launch (they loop over the items)
+#ifndef DR_ITEM_GRID_FWD
+#define DR_ITEM_GRID_FWD 1280
+#endif
+#ifndef DR_ITEM_GRID_BWD
+#define DR_ITEM_GRID_BWD 512
+#endif
+// workgroups of the overflow launch (they loop over the items): what is resident at once on 256 CUs -- a workgroup that starts
+// only after another has left would work off its first, statically assigned run of items at the very end
+constexpr int ITEM_GRID_FWD = DR_ITEM_GRID_FWD, ITEM_GRID_BWD = DR_ITEM_GRID_BWD;
 #ifndef DR_ITEM_RUN
 #define DR_ITEM_RUN 2   // camera inside a 512^3 volume, fwd / bwd ms: static striding 11.3 / 19.8; runs of 1: 10.0 / 17.9, 2: 9.2 / 16.2, 3: 9.3 / 16.5, 4: 9.9 / 17.4, 8: 13.2 / 22.6
 #endif
@@ -1263,7 +1271,7 @@ bool brick_path_supported(int VX, int VY, int VZ, int R) {
         if ((e = allow_lds(brick_flat_kernel<VT, MODE_, BWD_, VOL_, TF_, ALPHA_, K_>, lds)) != hipSuccess) return (int)e;             \
         if ((e = allow_lds(brick_flat_items_kernel<VT, MODE_, BWD_, VOL_, TF_, ALPHA_, K_>, align16(lds) + ITEM_EXTRA_LDS)) != hipSuccess) return (int)e; \
         hipLaunchKernelGGL((brick_flat_kernel<VT, MODE_, BWD_, VOL_, TF_, ALPHA_, K_>), DR_GRID1, dim3(NT_), lds, stream, P);         \
-        hipLaunchKernelGGL((brick_flat_items_kernel<VT, MODE_, BWD_, VOL_, TF_, ALPHA_, K_>), dim3(ITEM_GRID), dim3(NT_), align16(lds) + ITEM_EXTRA_LDS, stream, P); \
+        hipLaunchKernelGGL((brick_flat_items_kernel<VT, MODE_, BWD_, VOL_, TF_, ALPHA_, K_>), dim3(BWD_ ? ITEM_GRID_BWD : ITEM_GRID_FWD), dim3(NT_), align16(lds) + ITEM_EXTRA_LDS, stream, P); \
     }
 
 template <typename VT>
