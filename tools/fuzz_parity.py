@@ -29,6 +29,8 @@ def T(a):
 
 
 SCALE = int(os.environ.get("FUZZ_SCALE", "1"))   # 3: volumes up to 288 per axis, images up to 288 px (a case takes seconds)
+PROFILE = os.environ.get("FUZZ_PROFILE", "")     # "inside": every camera inside or next to the volume (work items of heavy
+                                                 # bricks); "ert": opaque TFs at high sampling rates (termination decisions)
 
 
 def make_case(seed):
@@ -61,6 +63,8 @@ def make_case(seed):
         vol = vol.astype(np.float16).astype(np.float32)
     tf = rng.random((R, 4), dtype=np.float32)
     ak = rng.integers(0, 6)
+    if PROFILE == "ert":
+        ak = [2, 3, 4, 3][seed % 4]; sr = [2.0, 4.0, 8.0, 16.0, 3.0, 1.0][seed % 6]
     tf[:, 3] *= [0.004, 0.02, 0.2, 0.9, 1.0, 0.05][ak]
     if ak == 4:     # alpha reaches exactly 1 somewhere: opacity 1, transmittance 0
         tf[rng.integers(0, R), 3] = 1.0
@@ -76,6 +80,8 @@ def make_case(seed):
         if abs(d[1]) > 0.97:    # (anti)parallel to the up vector is degenerate in VR.py:143
             d = np.array([0.6, 0.3, 0.74]); d /= np.linalg.norm(d)
         dist = float(rng.choice([0.05, 0.5, 0.9, 1.0, 1.2, 1.75, 2.5, 6.0, 40.0]))
+        if PROFILE == "inside":
+            dist = [0.05, 0.3, 0.5, 0.9, 1.0, 1.1][seed % 6]
         cams.append((d * dist).astype(np.float32))
     cam = np.stack(cams)
     jitter = int(rng.integers(0, 2)) * int(rng.integers(1, 1 << 30))
