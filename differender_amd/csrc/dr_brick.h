@@ -93,21 +93,6 @@ __device__ __forceinline__ int camera_layer(int bx, int by, int bz, f3 cam, floa
 
 // trilinear tap from the LDS box; identical arithmetic to tri_sample (x -> y -> z lerps)
 __device__ __forceinline__ float tri_lds(const float *box, int base, float fx, float fy, float fz) {
-#ifdef DR_EXP_B64
-    // TIMING EXPERIMENT ONLY (wrong values for odd z): the (z, z+1) pair of every corner column as one 8-byte read
-    const float2 *b2 = reinterpret_cast<const float2 *>(box);
-    const int h = base >> 1;
-    const float2 p00 = b2[h], p10 = b2[h + (BOX_SX >> 1)], p01 = b2[h + (BOX_SY >> 1)], p11 = b2[h + ((BOX_SX + BOX_SY) >> 1)];
-    {
-        float a = mixf(p00.x, p10.x, fx);
-        float b = mixf(p01.x, p11.x, fx);
-        float zl = mixf(a, b, fy);
-        a = mixf(p00.y, p10.y, fx);
-        b = mixf(p01.y, p11.y, fx);
-        float zh = mixf(a, b, fy);
-        return mixf(zl, zh, fz);
-    }
-#endif
     float a = mixf(box[base], box[base + BOX_SX], fx);
     float b = mixf(box[base + BOX_SY], box[base + BOX_SX + BOX_SY], fx);
     float zl = mixf(a, b, fy);
