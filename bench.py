@@ -35,7 +35,15 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-B_FWD, B_BWD_VOL, B_BWD_TF = 32.0, 96.0, 32.0  # algorithmic bytes per voxel-step
+
+
+def algorithmic_bytes(vol_dtype):
+    """Algorithmic bytes per voxel-step, from the volume's STORAGE type: the forward
+    gathers the 8 corners of the centre cell (8 x sizeof(voxel)); the backward w.r.t. the TF re-marches (the same);
+    the backward w.r.t. the volume adds the read-modify-write of the centre cell's 8 f32 gradients (8 x 4 B x 2).
+    f32: 32 / 32 / 96; f16: 16 / 16 / 80."""
+    b_fwd = 8.0 * {"f32": 4, "f16": 2}[vol_dtype]
+    return b_fwd, b_fwd + 64.0, b_fwd   # forward, backward w.r.t. volume (+TF), backward w.r.t. TF only
 
 
 def synth_volume_torch(N, device, seed=1234):
@@ -96,7 +104,8 @@ def parse_args(argv=None):
                     help="N > 1: 'views' = one view per rank per step (weak scaling, the default); 'rows' = ONE view per "
                          "step split into N bands of image rows (strong scaling, SURVEY 8(e))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-img", type=int, default=224, help="image edge of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-img", type=int, default=None,
+                    help="image edge of the CPU-baseline sample (default: the whole view, capped at 512: ~20 s on 16 cores)")
     ap.add_argument("--pmc", default="auto", choices=["auto", "live", "off"],
                     help="roofline.traffic: 'live' collects FETCH_SIZE / WRITE_SIZE with rocprofv3 around short child runs of "
                          "this very command; 'auto' = live for the default single-GPU headline, else off")
@@ -119,27 +128,60 @@ def self_launch(args):
     if ndev < n and "DR_BENCH_BACKEND" not in env:
         env["DR_BENCH_BACKEND"] = "gloo"  # rehearsal: ranks share the card(s)
         print(f"[bench] {ndev} GPU(s) for {n} ranks: rehearsing over gloo on shared devices", file=sys.stderr)
-    procs = []
+    procs, logs = [], []
     for r in range(n):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r), OMP_NUM_THREADS=env.get("OMP_NUM_THREADS", "4"))
+        # rank 0's stdout carries the JSON line (a pipe would have to be drained while polling: a temporary file instead)
+        logs.append(tempfile.TemporaryFile() if r == 0 else None)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode]
-    for p in procs[1:]:
-        try:
-            rcs.append(p.wait(timeout=600))
-        except subprocess.TimeoutExpired:
-            p.kill()
-            rcs.append(-9)
-    for ln in out.decode().splitlines():      # rank 0's JSON line (its stdout carries nothing else: claim_stdout)
-        if ln.startswith("{"):
-            sys.stdout.write(ln + "\n")
-    sys.stdout.flush()
+                                      stdout=logs[r] if r == 0 else subprocess.DEVNULL))
+    # Poll ALL ranks: when one dies (RCCL init failure, a fault) the others sit in a collective for ever -- end them at
+    # once instead of waiting for each in turn.
+    rcs = [None] * n
+    failed = None
+    while any(rc is None for rc in rcs):
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+                if rcs[r] not in (None, 0) and failed is None:
+                    failed = r
+        if failed is not None:
+            print(f"[bench] rank {failed} exited with code {rcs[failed]}: stopping the other ranks", file=sys.stderr)
+            for r, p in enumerate(procs):
+                if rcs[r] is None:
+                    p.terminate()
+            deadline = time.time() + 10.0
+            for r, p in enumerate(procs):
+                if rcs[r] is None:
+                    try:
+                        rcs[r] = p.wait(timeout=max(deadline - time.time(), 0.1))
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        rcs[r] = p.wait()
+            break
+        time.sleep(0.05)
+    logs[0].seek(0)
+    out = logs[0].read()
+    if failed is None:
+        for ln in out.decode().splitlines():      # rank 0's JSON line (its stdout carries nothing else: claim_stdout)
+            if ln.startswith("{"):
+                sys.stdout.write(ln + "\n")
+        sys.stdout.flush()
     return max(abs(rc) for rc in rcs)
 
 
 # ------------------------------------------------------------------------------------------------ live HBM counters
+PROFILER_ENV_PREFIXES = ("ROCP_", "ROCPROF", "ROCPROFILER_", "HSA_TOOLS_", "ROCTRACER_")
+
+
+def under_profiler(env=None):
+    """True if this process was started under rocprofv3 / rocprof (their preload or tool variables are set)."""
+    env = os.environ if env is None else env
+    if "rocprof" in env.get("LD_PRELOAD", "").lower():
+        return True
+    return any(k.startswith(PROFILER_ENV_PREFIXES) for k in env)
+
+
 def measure_traffic_live(argv_workload):
     """roofline.traffic, measured in THIS job: rocprofv3 --pmc around short child runs of the same command, FETCH_SIZE
     and WRITE_SIZE in separate passes (the TCC block has 4 slots: 3 + 2 do not fit, MI355X guide "rocprofv3 PMC slots"),
@@ -147,11 +189,19 @@ def measure_traffic_live(argv_workload):
     exe = shutil.which("rocprofv3")
     if exe is None:
         return None, "rocprofv3 not found"
+    # Never nest profilers: under `rocprofv3 -- python3 bench.py` this process carries the profiler's preload, a child
+    # rocprofv3 (a python script that exec's its target) would inherit it, and the preloaded tool initialises the GPU
+    # before that exec -- the exec of a GPU-initialised process that takes a box down.
+    if under_profiler():
+        return None, "already running under a profiler: live counters skipped"
     res = {}
     work = tempfile.mkdtemp(prefix="dr_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
-        env.pop(k, None)
+    for k in list(env):
+        if k in ("RANK", "LOCAL_RANK", "WORLD_SIZE") or k.startswith(PROFILER_ENV_PREFIXES):
+            env.pop(k, None)
+    if "rocprof" in env.get("LD_PRELOAD", "").lower():
+        env.pop("LD_PRELOAD", None)
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(work, counter)
@@ -389,8 +439,9 @@ def main():
                 "note": "achieved/frac price the ALGORITHMIC bytes (model); hbm_gbs_measured = traffic / avg_launch is what "
                         "the memory-side counters saw"}
 
-    roof_fwd = roof("march_fwd", fwd_ms, B_FWD)
-    roof_bwd = roof("march_bwd", bwd_ms, B_BWD_VOL if want_vol else B_BWD_TF) if want_bwd else None
+    b_fwd, b_bwd_vol, b_bwd_tf = algorithmic_bytes(args.vol_dtype)
+    roof_fwd = roof("march_fwd", fwd_ms, b_fwd)
+    roof_bwd = roof("march_bwd", bwd_ms, b_bwd_vol if want_vol else b_bwd_tf) if want_bwd else None
 
     # roofline.traffic: HBM-side bytes per launch of the dominant kernels
     pm, traffic_source = None, None
@@ -421,7 +472,7 @@ def main():
                 "vol": "fwd+bwd w.r.t. volume", "none": "forward only"}[args.grads]
     cams = "orbit cameras in_circles(0.1*v)" if args.cam == "orbit" else "cameras INSIDE the volume (radius 0.45)"
     line = {
-        "metric": "Mvoxel-steps/s fwd+bwd, 512^3 vol @ 512^2 img",
+        "metric": f"Mvoxel-steps/s {'fwd+bwd' if want_bwd else 'fwd'}, {N}^3 vol @ {IMG}^2 img",
         "value": round(vsteps / elapsed / 1e6, 3),
         "unit": "Mvoxel-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -559,22 +610,42 @@ def main_opt(args):
     emit(line)
 
 
+def host_cores():
+    """Threads the CPU baseline uses: the cores this process may run on (scheduler affinity), cut to the cgroup's CPU
+    quota when there is one (a container's share of a bigger host) -- what the box really gives, no cap by fiat."""
+    try:
+        n_aff = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n_aff = os.cpu_count() or 1
+    quota = None
+    try:   # cgroup v2: "max 100000" or "<quota> <period>"
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:   # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    n = n_aff if quota is None else max(1, min(n_aff, int(math.ceil(quota))))
+    note = f"{n_aff} cores in the affinity mask" + ("" if quota is None else f", cgroup CPU quota {quota:.1f}")
+    return n, note
+
+
 def run_cpu_baseline(vol, tf, args, sr, want_vol, want_tf):
     """Oracle (kind 'port': this repo's C restatement, not Taichi) timed on the host cores on a bounded
     sample of the same workload: same volume/TF/camera, smaller image."""
     from oracle import oracle as O
     O.build()
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        pass
-    cores = min(cores, 16)  # a 1-GPU box's CPU share (the host exposes all its cores to every box)
+    cores, cores_note = host_cores()
     os.environ["OMP_NUM_THREADS"] = str(cores)
     vol_h = vol.float().cpu().numpy()
     tf_h = tf.cpu().numpy()
     cam = np.array(in_circles(0.0), np.float32)
-    W = args.cpu_img
+    W = args.cpu_img or min(args.img, 512)
     N = args.vol
     # untimed warm-up on a 16x16 image: the first parallel region pays for the OpenMP thread pool and first touches
     ew, xw, rw, nw = O.ray_setup(cam, 16, 16, (N, N, N), sr)
@@ -589,15 +660,17 @@ def run_cpu_baseline(vol, tf, args, sr, want_vol, want_tf):
         O.march_bwd(vol_h, tf_h, cam, e, x, r, n, 1 << 20, sr, g.astype(np.float32), want_vol, want_tf)
     dt = time.perf_counter() - t0
     nst = int(steps.sum())
+    whole = "the WHOLE view" if W == args.img else f"a {W}x{W} rendering of the {args.img}x{args.img} view"
     res = {"value": round(nst / dt / 1e6, 4), "unit": "Mvoxel-steps/s", "cores": cores, "kind": "port",
-           "sample": f"same {N}^3 volume/TF, camera in_circles(0), {W}x{W} image "
+           "cores_note": cores_note,
+           "sample": f"same {N}^3 volume/TF, camera in_circles(0), {W}x{W} image = {whole} "
                      f"({nst} voxel-steps, fwd{'+bwd' if (want_tf or want_vol) else ''}), C oracle with OpenMP, {dt:.1f} s"}
     # single-thread figure on a 16x smaller sample (SURVEY 8(d) asks for both)
     try:
         import ctypes
         gomp = ctypes.CDLL("libgomp.so.1")
         gomp.omp_set_num_threads(1)
-        W1 = max(W // 4, 8)
+        W1 = max(W // 8, 8)
         e, x, r, n = O.ray_setup(cam, W1, W1, (N, N, N), sr)
         t0 = time.perf_counter()
         out, steps = O.march_fwd(vol_h, tf_h, cam, e, x, r, n, 1 << 20, sr, 0)

@@ -31,7 +31,7 @@ SIGNATURES = {
                                _I, _I, _I, _I, _F, _D, _D, _I, _I, _P, _P, _P, _Z, _I, _I, _P]),
     "dr_march_bwd_rows": (_I, [_P, _I, _I, _I, _I, _L, _L, _L, _L, _P, _I, _L, _P, _P, _P, _P, _P,
                                _I, _I, _I, _I, _F, _D, _D, _I, _P, _P, _P, _L, _L, _L, _L, _P, _L, _P, _Z, _I, _I, _P]),
-    "dr_march_bwd_variant": (_I, [_I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _I, _I, _I]),
+    "dr_march_bwd_variant": (_I, [_I, _I, _I, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _I, _I, _I]),
     "dr_comm_unique_id": (_I, [_P]),
     "dr_comm_init_rank": (_I, [_c.POINTER(_P), _I, _P, _I]),
     "dr_comm_init_all": (_I, [_c.POINTER(_P), _I, _c.POINTER(_I)]),
@@ -58,7 +58,7 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.dr_abi_version() != 6:
+        if handle.dr_abi_version() != 7:
             raise ImportError("libdifferender_hip.so ABI version mismatch; rebuild it")
         _lib = handle
     return _lib

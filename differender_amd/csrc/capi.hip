@@ -128,6 +128,11 @@ int dr_march_fwd_rows(const void *vol, int vol_dtype, int VX, int VY, int VZ, in
         if (workspace_bytes < brick_workspace_bytes(n_views, W, H, VX, VY, VZ)) return DR_EINVAL;
         if (flat_strides_ok(sx, sy, sz)) return launch_march_fwd_flat(a, (hipStream_t)stream);
     }
+    // served by the plain kernels: whatever coarse tape the workspace still holds is not this call's
+    if (workspace) {
+        const hipError_t e = flat_invalidate_workspace(workspace, workspace_bytes, (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+    }
     return launch_march_fwd_baseline(a, (hipStream_t)stream);
 }
 
@@ -141,10 +146,11 @@ int dr_march_fwd(const void *vol, int vol_dtype, int VX, int VY, int VZ, int64_t
                              variant, out_rgba, steps, workspace, workspace_bytes, W, 0, stream);
 }
 
-int dr_march_bwd_variant(int VX, int VY, int VZ, int R, int64_t sx, int64_t sy, int64_t sz, int64_t dsx, int64_t dsy,
-                         int64_t dsz, int has_dvol, int variant, int has_workspace) {
-    const bool fast = variant != DR_VARIANT_BASELINE && has_workspace && VX >= 2 && VY >= 2 && VZ >= 2 && R >= 1 &&
-                      brick_path_supported(VX, VY, VZ, R) && flat_strides_ok(sx, sy, sz) &&
+int dr_march_bwd_variant(int n_views, int W, int H, int VX, int VY, int VZ, int R, int64_t sx, int64_t sy, int64_t sz,
+                         int64_t dsx, int64_t dsy, int64_t dsz, int has_dvol, int variant, int has_workspace) {
+    const bool fast = variant != DR_VARIANT_BASELINE && has_workspace && n_views > 0 && W > 0 && H > 0 && VX >= 2 &&
+                      VY >= 2 && VZ >= 2 && R >= 1 && brick_path_supported(VX, VY, VZ, R) &&
+                      brick_image_supported(W, H, VX, VY, VZ) && flat_strides_ok(sx, sy, sz) &&
                       (!has_dvol || flat_strides_ok(dsx, dsy, dsz));
     return fast ? DR_VARIANT_AUTO : DR_VARIANT_BASELINE;
 }
@@ -173,8 +179,8 @@ int dr_march_bwd_rows(const void *vol, int vol_dtype, int VX, int VY, int VZ, in
     a.d_vol = d_vol; a.dsx = dsx; a.dsy = dsy; a.dsz = dsz; a.dvol_vs = dvol_view_stride;
     a.d_tf = d_tf; a.dtf_vs = dtf_view_stride;
     a.fov_rad = fov_rad; a.near_plane = near_plane; a.workspace = workspace; a.workspace_bytes = workspace_bytes;
-    if (dr_march_bwd_variant(VX, VY, VZ, R, sx, sy, sz, dsx, dsy, dsz, d_vol != nullptr, variant, workspace != nullptr) ==
-            DR_VARIANT_AUTO && brick_image_supported(W, H, VX, VY, VZ)) {
+    if (dr_march_bwd_variant(n_views, W, H, VX, VY, VZ, R, sx, sy, sz, dsx, dsy, dsz, d_vol != nullptr, variant,
+                             workspace != nullptr) == DR_VARIANT_AUTO) {
         if (workspace_bytes < brick_workspace_bytes(n_views, W, H, VX, VY, VZ)) return DR_EINVAL;
         return launch_march_bwd_flat(a, (hipStream_t)stream);
     }

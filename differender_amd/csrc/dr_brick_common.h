@@ -5,6 +5,7 @@
 #include "dr_brick.h"
 #include "dr_kernels.h"
 #include "../../include/differender_hip.h"
+#include <string.h>
 
 namespace dr {
 
@@ -35,6 +36,8 @@ struct BrickParams {
                           // [n_views + view] 1 if the camera sits inside (or on) the volume: rays start behind the eye, the
                           // camera-based brick layers are not monotone along them and the pre-pass runs as ONE phase
     int n_views;
+    unsigned int mark;   // fingerprint of this forward/backward pair (ws_fingerprint): the forward leaves it in stats[ST_MARK],
+                         // the backward trusts records, live flags, ray flags and work items only if it finds it there
     int use_live;        // forward: ws_steps holds each ray's exact live sample count (from the alpha pre-pass)
     int pp_l0, pp_l1, pp_first;  // alpha pre-pass phase: brick layers [pp_l0, pp_l1); later phases skip terminated rays
     const struct BrickCtxRec *ctx;  // [view][brick]: brick geometry + pixel rectangle, filled once per forward call
@@ -50,7 +53,7 @@ struct BrickParams {
 enum {
     ST_REPAIR = 0,         // rays whose segments failed the sample-count check and were marched whole (expected 0)
     ST_BASELINE_RAYS = 2,  // rays the per-ray fallback marched in the last forward (irregular rays + repaired ones)
-    ST_MARK = 3,           // DR_CTX_MARK once the flat forward has written brick records and live flags
+    ST_MARK = 3,           // fingerprint of the flat forward that wrote the brick records, flags, items and coarse tape
     ST_TICKET = 6,         // work-item launches: next item to hand out / workgroups done (the last one resets both to 0)
     ST_DONE = 7,
     ST_NITEMS = 5,         // diagnostic copy of the number of overflow work items of the last forward (heavy bricks: BrickItem)
@@ -183,11 +186,28 @@ __device__ __forceinline__ int near_first_brick(const BrickParams<VT> &P, int i,
 
 // The records are STORED in that order (record i of a view = the brick dispatched i-th), so that a workgroup's first load
 // does not wait for the camera position; a work item names its brick by the same dispatch slot.
-// One thread per (brick, view): brick_setup once, for all passes of a forward/backward pair. The forward launches it
-// with forward = 1 (live flags cleared, DR_CTX_MARK left in stats[ST_MARK]: "records and live flags are the flat
-// forward's"); the backward recomputes the geometry (it may follow a forward of another kernel variant) and keeps
-// the live flags, which its kernels only trust when the mark is there.
-constexpr unsigned int DR_CTX_MARK = 0x600DF1A7u;
+// One thread per (brick, view): brick_setup once, for all passes of a forward/backward pair. The forward leaves a
+// FINGERPRINT of its call in stats[ST_MARK] (ws_fingerprint: sizes, sampling rate, the addresses of the ray buffers and of
+// the volume); the backward does not re-derive anything -- records, live flags, ray flags, work items and the coarse tape
+// are the forward's -- and therefore only touches them when it finds the fingerprint of ITS OWN arguments there. A
+// workspace that holds something else (never filled, filled by another call, forward served by the baseline kernels, which
+// clear the mark) makes B1 return at once and B2 march every ray: slow, correct, and no index read from garbage.
+static_assert(ST_MARK == WS_MARK_WORD, "capi.hip clears this word through flat_invalidate_workspace");
+static inline unsigned int ws_fingerprint(const MarchArgs &a) {
+    unsigned long long h = 0xcbf29ce484222325ull;
+    auto mix = [&h](unsigned long long v) { for (int k = 0; k < 8; ++k) { h ^= (v >> (8 * k)) & 0xffu; h *= 0x100000001b3ull; } };
+    mix((unsigned long long)a.n_views); mix((unsigned long long)a.W); mix((unsigned long long)a.H);
+    mix((unsigned long long)(a.img_W > 0 ? a.img_W : a.W)); mix((unsigned long long)(a.img_W > 0 ? a.row0 : 0));
+    mix((unsigned long long)a.VX); mix((unsigned long long)a.VY); mix((unsigned long long)a.VZ);
+    mix((unsigned long long)a.R); mix((unsigned long long)a.S);
+    unsigned int srb; memcpy(&srb, &a.sr, 4); mix(srb);
+    mix((unsigned long long)a.vol_dtype); mix((unsigned long long)a.sx); mix((unsigned long long)a.sy); mix((unsigned long long)a.sz);
+    mix((unsigned long long)a.vol_vs);
+    mix((unsigned long long)(uintptr_t)a.vol); mix((unsigned long long)(uintptr_t)a.entry); mix((unsigned long long)(uintptr_t)a.exit_);
+    mix((unsigned long long)(uintptr_t)a.rays); mix((unsigned long long)(uintptr_t)a.nsamp); mix((unsigned long long)(uintptr_t)a.cam);
+    const unsigned int f = (unsigned int)(h ^ (h >> 32));
+    return f ? f : 1u;   // 0 = "nobody's" (what flat_invalidate_workspace writes)
+}
 // Can any ray of a view terminate early? Upper bound from the largest TF alpha: after n_max samples of opacity
 // op_max the accumulated alpha is 1 - (1 - op_max)^n_max. Evaluated by one wave.
 __device__ __forceinline__ unsigned int may_terminate(const float4 *t, int R, float inv_sr, float n_max) {
@@ -217,7 +237,7 @@ static __global__ __launch_bounds__(256) void brick_ctx_kernel(BrickParams<VT> P
                 const float lim = 1.0f + 1e-3f;
                 P.vflags[view] = flag;
                 P.vflags[P.n_views + view] = (fabsf(cx) <= lim && fabsf(cy) <= lim && fabsf(cz) <= lim) ? 1u : 0u;
-                if (view == 0) { P.stats[ST_REPAIR] = 0u; P.stats[ST_BASELINE_RAYS] = 0u; P.stats[ST_F64_BRICKS] = 0u; P.stats[ST_TICKET] = 0u; P.stats[ST_DONE] = 0u; P.stats[ST_MARK] = DR_CTX_MARK; }
+                if (view == 0) { P.stats[ST_REPAIR] = 0u; P.stats[ST_BASELINE_RAYS] = 0u; P.stats[ST_F64_BRICKS] = 0u; P.stats[ST_TICKET] = 0u; P.stats[ST_DONE] = 0u; P.stats[ST_MARK] = P.mark; }
             }
         }
     }
@@ -483,6 +503,7 @@ static inline BrickParams<VT> make_brick_params(const MarchArgs &a, const Worksp
     P.g = make_brick_grid(a.VX, a.VY, a.VZ);
     P.seg_rgba = w.seg_rgba; P.seg_cnt = w.seg_cnt; P.rayflag = w.rayflag; P.stats = w.stats; P.vflags = w.vflags; P.n_views = a.n_views; P.ws_steps = w.ws_steps;
     P.use_live = a.use_live; P.ctx = w.ctx; P.items = w.items; P.n_items = w.n_items;
+    P.mark = ws_fingerprint(a);
     P.pp_l0 = a.pp_l0; P.pp_l1 = a.pp_l1; P.pp_first = a.pp_first;
     P.out = a.out; P.steps = a.steps;
     P.grad_out = a.grad_out; P.out_fwd = a.out_fwd;

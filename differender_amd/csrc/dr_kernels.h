@@ -21,6 +21,8 @@ struct MarchArgs {
     double fov_rad, near_plane;
     void *workspace; size_t workspace_bytes;
     const uint8_t *only_flagged;  // baseline backward: restrict to rays with a non-zero flag (may be null)
+    const unsigned int *ws_mark;  // ... unless *ws_mark != ws_mark_expect (the workspace is not this call's forward's: the
+    unsigned int ws_mark_expect;  //     flags are garbage, every ray is marched); may be null
     int use_live;                 // forward: per-ray live sample counts are available (alpha pre-pass)
     int pp_l0, pp_l1, pp_first;   // alpha pre-pass phase: brick layers [pp_l0, pp_l1); pp_first: no earlier phase
 };
@@ -41,6 +43,10 @@ int launch_ray_compose(const MarchArgs &a, hipStream_t stream);      // F2
 int launch_ray_alpha(const MarchArgs &a, hipStream_t stream);        // alpha pre-pass: per-ray composition of one phase
 int launch_ray_cross(const MarchArgs &a, hipStream_t stream);        // alpha pre-pass: exact termination sample of crossing rays
 bool flat_strides_ok(int64_t sx, int64_t sy, int64_t sz);  // 32-bit in-box offsets
+// Word of the workspace header that says whose coarse tape the workspace holds (a fingerprint of the forward call that
+// filled it, see ws_fingerprint); a forward served by the baseline kernels clears it (flat_invalidate_workspace).
+constexpr int WS_MARK_WORD = 3;
+hipError_t flat_invalidate_workspace(void *workspace, size_t workspace_bytes, hipStream_t stream);
 int launch_march_fwd_flat(const MarchArgs &a, hipStream_t stream);   // one lane per sample
 int launch_march_bwd_flat(const MarchArgs &a, hipStream_t stream);
 

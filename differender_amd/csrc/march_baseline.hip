@@ -25,6 +25,7 @@ struct MarchParams {
     GradView dvol; int64_t dvol_vs;
     float *d_tf; int64_t dtf_vs;
     const uint8_t *only_flagged;
+    const unsigned int *ws_mark; unsigned int ws_mark_expect;  // see MarchArgs
 };
 
 __device__ __forceinline__ bool tile_pixel(int W, int H, int &i, int &j) {
@@ -98,7 +99,10 @@ __global__ __launch_bounds__(256) void march_bwd_baseline_kernel(MarchParams<VT>
 
     int i, j;
     bool active = tile_pixel(P.W, P.H, i, j);
-    if (active && P.only_flagged) active = P.only_flagged[((size_t)view * P.W + i) * P.H + j] != 0;
+    // second pass of the brick-centric backward: only the rays the forward flagged -- unless the workspace is not that
+    // forward's (uniform): then the flags mean nothing, B1 has done nothing, and every ray is marched here
+    const bool stale_ws = P.ws_mark != nullptr && *P.ws_mark != P.ws_mark_expect;
+    if (active && P.only_flagged && !stale_ws) active = P.only_flagged[((size_t)view * P.W + i) * P.H + j] != 0;
     if (active) {
         const size_t p = ((size_t)view * P.W + i) * P.H + j;
         VolView<VT> vol = P.vol;
@@ -197,6 +201,7 @@ static MarchParams<VT> make_params(const MarchArgs &a) {
     P.dvol.p = a.d_vol; P.dvol.sx = a.dsx; P.dvol.sy = a.dsy; P.dvol.sz = a.dsz; P.dvol_vs = a.dvol_vs;
     P.d_tf = a.d_tf; P.dtf_vs = a.dtf_vs / 4;
     P.only_flagged = a.only_flagged;
+    P.ws_mark = a.ws_mark; P.ws_mark_expect = a.ws_mark_expect;
     return P;
 }
 

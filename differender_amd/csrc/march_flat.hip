@@ -143,9 +143,9 @@ __device__ __forceinline__ BoxWalk make_box_walk(long long sx, long long sy, lon
     return w;
 }
 // row r (0 .. BOX*BOX-1) -> (b, d): r / BOX == (r * (65536 / BOX + 1)) >> 16 for r < 4000 (checked exhaustively for
-// BOX = 15, 19, 23)
+// BOX = 9, 11, 13, 15, 19, 23)
 __device__ __forceinline__ void box_row(int r, int &b, int &d) {
-    static_assert(BOX == 15 || BOX == 19 || BOX == 23, "magic divisor checked for these box edges only");
+    static_assert(BOX == 9 || BOX == 11 || BOX == 13 || BOX == 15 || BOX == 19 || BOX == 23, "magic divisor checked for these box edges only");
     d = (r * (65536 / BOX + 1)) >> 16; b = r - d * BOX;
 }
 
@@ -666,6 +666,8 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
 #if DR_PHASE_TIMING == 3
     const long long tq0 = clock64();
 #endif
+    // backward: records, flags, items and coarse tape are only touched if THIS call's forward wrote them (ws_fingerprint)
+    if (BWD && P.stats[ST_MARK] != P.mark) return;  // uniform; B2 then marches every ray
     const f3 cam = make_f3(P.cam[3 * view], P.cam[3 * view + 1], P.cam[3 * view + 2]);
     BrickCtx c;
     // the records are stored in dispatch order (near-first, brick_ctx_kernel): the address does not wait for the camera
@@ -675,7 +677,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
         if (P.vflags[P.n_views + view] ? !P.pp_first : (c.layer < P.pp_l0 || c.layer >= P.pp_l1)) return;
     }
     // backward after a flat forward: bricks in which the forward marched nothing (rays terminated before them) have no work
-    if (BWD && !DR_PHASE_TIMING && c.live == 0 && P.stats[ST_MARK] == DR_CTX_MARK) return;  // uniform
+    if (BWD && !DR_PHASE_TIMING && c.live == 0) return;  // uniform
 
 #if DR_SETPRIO
     __builtin_amdgcn_s_setprio(3);  // the staging / listing prologue is short and latency-bound: let it overtake sample loops
@@ -1144,7 +1146,13 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
 #if DR_PHASE_TIMING == 1
     const long long tk4 = clock64();
 #endif
+#ifdef DR_ABL_NOBARRIER
+    return;  // what-if (wrong results): every wave leaves after its own samples -- no wait for the slowest wave, no flush
+#endif
     if (!__syncthreads_or(any)) return;  // uniform; also: every wave's LDS adds are done before the flush
+#ifdef DR_ABL_NOFLUSH
+    return;  // what-if (wrong results): the wait for the slowest wave stays, the flush goes
+#endif
 #if DR_PHASE_TIMING == 1
     if (threadIdx.x == 0)  // wave 0 waiting for the slowest wave of the workgroup
         atomicAdd(reinterpret_cast<unsigned long long *>(P.stats + ST_TIMING) + 7, (unsigned long long)(clock64() - tk4));
@@ -1213,6 +1221,7 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
 template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, bool ALPHA = false, int KF = 1>
 __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FWD_WAVES) void brick_flat_items_kernel(BrickParams<VT> P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (BWD && P.stats[ST_MARK] != P.mark) return;  // uniform over the grid: not this call's workspace, the item list is garbage
     const int n_items = min((int)*P.n_items, ITEM_CAP);
     if (blockIdx.x == 0 && threadIdx.x == 0) P.stats[ST_NITEMS] = *P.n_items;
     // Runs of ITEM_RUN consecutive items (consecutive items belong to one brick, brick_ctx_kernel) are handed out through a
@@ -1347,6 +1356,11 @@ static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     return launch_ray_compose(b, stream);
 }
 
+hipError_t flat_invalidate_workspace(void *workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (!workspace || workspace_bytes < (size_t)ST_WORDS * 4) return hipSuccess;
+    return hipMemsetAsync(static_cast<unsigned int *>(workspace) + ST_MARK, 0, 4, stream);
+}
+
 int launch_march_fwd_flat(const MarchArgs &a, hipStream_t stream) {
     return a.vol_dtype == DR_F16 ? flat_fwd_dispatch<__half>(a, stream) : flat_fwd_dispatch<float>(a, stream);
 }
@@ -1360,7 +1374,10 @@ static int flat_bwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     if (!a.workspace || a.workspace_bytes < need) return DR_EINVAL;
     BrickParams<VT> P = make_brick_params<VT>(a, w);
     const bool wv = a.d_vol != nullptr, wt = a.d_tf != nullptr;
-    const size_t lds = flat_lds_bytes<true>(a.R, wv, wt);
+#ifndef DR_ABL_EXTRA_LDS_BWD
+#define DR_ABL_EXTRA_LDS_BWD 0   // what-if: bytes of unused LDS per backward workgroup (fewer workgroups per CU)
+#endif
+    const size_t lds = flat_lds_bytes<true>(a.R, wv, wt) + DR_ABL_EXTRA_LDS_BWD;
     const dim3 grid1(g.NBx * g.NBy * g.NBz, a.n_views);
     hipError_t e = hipSuccess;
     // (the brick records, live flags and work items are the forward's: same inputs, same workspace)
@@ -1369,7 +1386,8 @@ static int flat_bwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     else DR_LAUNCH_BOTH(DR_MODE_DIFF, true, false, true, false, 1, FNT_BWD)
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
     MarchArgs b = a;
-    b.only_flagged = w.rayflag;  // B2: irregular rays through the baseline backward
+    b.only_flagged = w.rayflag;  // B2: irregular rays through the baseline backward (every ray, if the workspace is not this call's)
+    b.ws_mark = w.stats + ST_MARK; b.ws_mark_expect = P.mark;
     return launch_march_bwd_baseline(b, stream);
 }
 

@@ -44,6 +44,16 @@ def all_reduce_gradients(grads, group=None, async_op=False):
     handles = []
     small = [g for g in grads if g is not None and g.numel() * g.element_size() < (1 << 20)]
     large = [g for g in grads if g is not None and g.numel() * g.element_size() >= (1 << 20)]
+    # The small bucket goes FIRST: it is reduced synchronously (a few KiB: latency-bound, not worth deferring), and the
+    # collectives of a process group run in order on RCCL's stream -- issued behind the large asynchronous reduction, its
+    # implicit wait would hold the caller's stream until that one had finished too, and nothing would overlap.
+    if small:
+        flat = torch.cat([g.reshape(-1) for g in small])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        off = 0
+        for g in small:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
     for g in large:
         t = g if g.is_contiguous() or _dense(g) else None
         if t is None:
@@ -54,13 +64,6 @@ def all_reduce_gradients(grads, group=None, async_op=False):
             h = dist.all_reduce(_flat_view(t), op=dist.ReduceOp.SUM, group=group, async_op=async_op)
             if async_op:
                 handles.append(h)
-    if small:
-        flat = torch.cat([g.reshape(-1) for g in small])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)  # a few KiB: latency-bound, not worth deferring
-        off = 0
-        for g in small:
-            g.copy_(flat[off:off + g.numel()].view_as(g))
-            off += g.numel()
     return handles  # async_op: call .wait() on each before reading the large tensors
 
 

@@ -30,17 +30,19 @@ def as_volume(vol):
     return vol if vol.dtype in (torch.float32, torch.float16) else vol.float()
 
 
-def bwd_is_sanitised(vol, tf, d_vol, workspace):
-    """True if march_bwd(vol, tf, ..., workspace=workspace) is served by the fast kernels, whose gradients are
-    finite by construction (dr_march_bwd_variant); False for the plain kernels, which propagate NaN like the
-    reference and want the reference's nan_to_num."""
+def bwd_is_sanitised(vol, tf, d_vol, workspace, n):
+    """True if march_bwd(vol, tf, ..., n, ..., workspace=workspace) is served by the fast kernels, which sanitise their
+    gradients themselves (dr_march_bwd_variant -- the function dr_march_bwd_rows itself asks; residual overflow case: see
+    include/differender_hip.h); False for the plain kernels, which propagate NaN like the reference and want the
+    reference's nan_to_num. n: the (views, W, H) sample-count buffer of the call."""
     if workspace is None:
         return False
     if workspace.numel() == 0:
         return False
     sv = vol.stride()[-3:]
     sd = d_vol.stride()[-3:] if d_vol is not None else (0, 0, 0)
-    return N.lib().dr_march_bwd_variant(*(int(v) for v in vol.shape[-3:]), int(tf.shape[-2]), *sv, *sd,
+    V, W, H = (int(v) for v in n.shape)
+    return N.lib().dr_march_bwd_variant(V, W, H, *(int(v) for v in vol.shape[-3:]), int(tf.shape[-2]), *sv, *sd,
                                         int(d_vol is not None), N.DR_VARIANT_AUTO, 1) == N.DR_VARIANT_AUTO
 
 

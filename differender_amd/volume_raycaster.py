@@ -260,7 +260,7 @@ class RaycastFunction(torch.autograd.Function):
         # VR.py:463-464,474-475: nan_to_num. The fast kernels drop NaN adjoints and clamp infinite ones themselves
         # ("non-finite upstream gradients"), so the two full passes over d_volume are only run when the
         # plain kernels served the call.
-        if not F.bwd_is_sanitised(volume, tf, dv, ctx.workspace):
+        if not F.bwd_is_sanitised(volume, tf, dv, ctx.workspace, n):
             if dv is not None:
                 dv = torch.nan_to_num(dv)
             if dt is not None:

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DR_ABI_VERSION 6
+#define DR_ABI_VERSION 7
 
 enum { DR_F32 = 0, DR_F16 = 1 };
 enum { DR_MODE_DIFF = 0, DR_MODE_NONDIFF = 1 };
@@ -115,11 +115,15 @@ int dr_march_bwd(const void *vol, int vol_dtype, int VX, int VY, int VZ,
 
 /* Which kernels dr_march_bwd[_rows] would run for these arguments, without running anything (no GPU needed):
  * DR_VARIANT_AUTO = the brick-centric kernels, DR_VARIANT_BASELINE = the plain ones (requested, no workspace, a
- * TF too large for LDS, a volume edge > 2000, or strides beyond 32-bit in-box offsets).
- * The brick-centric backward returns FINITE gradients by construction: a NaN adjoint (NaN pixel of grad_out, NaN
- * voxel) contributes nothing and +-inf is clamped, so its caller may skip the torch.nan_to_num of VR.py:463-475; the
- * plain kernels propagate NaN exactly like the reference and rely on it. (dsx,dsy,dsz) are ignored if !has_dvol. */
-int dr_march_bwd_variant(int VX, int VY, int VZ, int R, int64_t sx, int64_t sy, int64_t sz,
+ * TF too large for LDS, a volume edge > 2000, strides beyond 32-bit in-box offsets, or more [layer][pixel] slots than
+ * 32-bit indices hold: n_views, W, H as in the march call). The ONE function that decides: dr_march_bwd_rows asks it.
+ * The brick-centric backward sanitises its gradients itself: a NaN adjoint (NaN pixel of grad_out, NaN voxel)
+ * contributes nothing, +-inf and magnitudes beyond 1e30 are clamped per sample, a brick's flush to +-3e38 -- so its
+ * caller may skip the torch.nan_to_num of VR.py:463-475. Residual case: the float atomics that combine bricks, views and
+ * the few samples that bypass the LDS box can still overflow to +-inf when clamped contributions of ~1e38 meet (upstream
+ * gradients beyond ~1e30); the reference's nan_to_num would turn that into +-3.4e38. The plain kernels propagate NaN
+ * exactly like the reference and rely on nan_to_num. (dsx,dsy,dsz) are ignored if !has_dvol. */
+int dr_march_bwd_variant(int n_views, int W, int H, int VX, int VY, int VZ, int R, int64_t sx, int64_t sy, int64_t sz,
                          int64_t dsx, int64_t dsy, int64_t dsz, int has_dvol, int variant, int has_workspace);
 
 /* Image bands: the same three calls for rows [row0, row0 + W) of an image that is img_W rows wide (SURVEY 8(e):

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(hiplib):
     for s in _declared_symbols():
         assert hasattr(raw, s), f"{s} declared in include/differender_hip.h but not exported"
         assert s in N.SIGNATURES, f"{s} has no ctypes signature in differender_amd/_native.py"
-    assert hiplib.dr_abi_version() == 6
+    assert hiplib.dr_abi_version() == 7
     assert b"invalid" in hiplib.dr_error_string(-1)
 
 

@@ -197,7 +197,12 @@ def test_backward_skips_nan_to_num_only_on_the_fast_path(hiplib):
     from differender_amd import functional as F
     vol = torch.zeros((16, 16, 16), device=dev()); tf = torch.zeros((8, 4), device=dev())
     ws = torch.empty(16, dtype=torch.uint8, device=dev())
-    assert F.bwd_is_sanitised(vol, tf, torch.zeros_like(vol), ws)
-    assert not F.bwd_is_sanitised(vol, tf, torch.zeros_like(vol), None)
+    n = torch.zeros((1, 8, 8), dtype=torch.int32, device=dev())
+    assert F.bwd_is_sanitised(vol, tf, torch.zeros_like(vol), ws, n)
+    assert not F.bwd_is_sanitised(vol, tf, torch.zeros_like(vol), None, n)
     big = torch.zeros((20000, 4), device=dev())                       # TF too large for LDS -> plain kernels
-    assert not F.bwd_is_sanitised(vol, big, torch.zeros_like(vol), ws)
+    assert not F.bwd_is_sanitised(vol, big, torch.zeros_like(vol), ws, n)
+    # more [layer][pixel] slots than 32-bit indices hold -> plain kernels (the same function dr_march_bwd_rows asks)
+    from differender_amd import _native as N
+    assert N.lib().dr_march_bwd_variant(1, 8, 8, 16, 16, 16, 8, 256, 16, 1, 256, 16, 1, 1, 0, 1) == N.DR_VARIANT_AUTO
+    assert N.lib().dr_march_bwd_variant(1, 40000, 40000, 16, 16, 16, 8, 256, 16, 1, 256, 16, 1, 1, 0, 1) == N.DR_VARIANT_BASELINE

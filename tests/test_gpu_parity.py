@@ -508,9 +508,63 @@ def test_stale_workspace_and_mixed_variants(oracle, hiplib):
         assert ok, (vb, err)
 
 
+def test_backward_does_not_trust_a_workspace_it_did_not_fill(oracle, hiplib):
+    """The fast backward takes brick records, live flags, ray flags and work items from the workspace as the forward left
+    them. A workspace that does NOT hold this call's forward -- garbage bytes under a forward served by the plain kernels,
+    or the coarse tape of another call -- must never be indexed: the fingerprint in the header does not match, B1 does
+    nothing and B2 marches every ray (slow, and the oracle's result)."""
+    from differender_amd import functional as Fn
+    import differender_amd._native as N
+    vol_h, tf_h, cam_h = scene(oracle, N=40, R=32, tf="peaks")
+    WH = (48, 40)
+    vol, tf, cam = T(vol_h), T(tf_h), T(np.atleast_2d(cam_h))
+    e, x, r, n = Fn.ray_setup(cam, WH, vol.shape, 1.0)
+    eh, xh, rh, nh = (t[0].cpu().numpy() for t in (e, x, r, n))
+    g_h = np.random.default_rng(5).standard_normal((1, *WH, 4)).astype(np.float32)
+    g = T(g_h)
+    dv_o, dt_o = oracle.march_bwd(vol_h, tf_h, cam_h, eh, xh, rh, nh, 4096, 1.0, g_h[0])
+
+    # (1) garbage workspace, forward by the plain kernels (which clear the mark), backward asks for the fast path
+    ws = Fn.alloc_workspace(1, WH, vol.shape, tf.shape[0], dev())
+    ws.fill_(0x5A)
+    out, _ = Fn.march_fwd(vol, tf, cam, e, x, r, n, 4096, 1.0, variant=N.DR_VARIANT_BASELINE, workspace=ws)
+    assert int(Fn.workspace_stats(ws)[3]) == 0            # the mark word: nobody's
+    dv, dt = Fn.march_bwd(vol, tf, cam, e, x, r, n, 4096, 1.0, g, out, workspace=ws)
+    torch.cuda.synchronize()
+    ok, err = grad_close(dv.cpu().numpy(), dv_o)
+    assert ok, err
+    ok, err = grad_close(dt.cpu().numpy(), dt_o)
+    assert ok, err
+
+    # (2) garbage workspace and no forward at all on it
+    ws.fill_(0xA5)
+    dv, dt = Fn.march_bwd(vol, tf, cam, e, x, r, n, 4096, 1.0, g, out, workspace=ws)
+    torch.cuda.synchronize()
+    ok, err = grad_close(dv.cpu().numpy(), dv_o)
+    assert ok, err
+
+    # (3) the workspace holds ANOTHER call's forward (other camera, other ray buffers): same sizes, wrong tape
+    cam2 = T(np.atleast_2d(oracle.in_circles(2.1)))
+    e2, x2, r2, n2 = Fn.ray_setup(cam2, WH, vol.shape, 1.0)
+    Fn.march_fwd(vol, tf, cam2, e2, x2, r2, n2, 4096, 1.0, workspace=ws)
+    dv, dt = Fn.march_bwd(vol, tf, cam, e, x, r, n, 4096, 1.0, g, out, workspace=ws)
+    torch.cuda.synchronize()
+    ok, err = grad_close(dv.cpu().numpy(), dv_o)
+    assert ok, err
+    ok, err = grad_close(dt.cpu().numpy(), dt_o)
+    assert ok, err
+
+    # (4) and the matching pair still takes the fast path: B2 marches nothing but irregular rays
+    out4, _ = Fn.march_fwd(vol, tf, cam, e, x, r, n, 4096, 1.0, workspace=ws)
+    dv, dt = Fn.march_bwd(vol, tf, cam, e, x, r, n, 4096, 1.0, g, out4, workspace=ws)
+    ok, err = grad_close(dv.cpu().numpy(), dv_o)
+    assert ok, err
+
+
 def test_many_views_without_prepass(oracle, hiplib):
-    """More than 48 views in one call: the per-view termination flags do not fit the workspace header, the alpha
-    pre-pass is skipped and F2 resolves early termination itself. Results must still match the oracle."""
+    """More than 48 views in one call (the per-view termination flags once lived in the 2 KiB workspace header and the
+    alpha pre-pass was skipped beyond 48 views; they now have their own array behind the header and the pre-pass runs
+    for any number of views). Results must match the oracle view by view."""
     from differender_amd import functional as Fn
     vol_h = oracle.synth_volume(24)
     tf_h = oracle.peaks_tf(32)

@@ -2,7 +2,7 @@
 # usage: tools/pmc2.sh <outdir> "<bench args>" <counters...>
 out=$1; bargs=$2; shift 2
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d gpurun_out/$out -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline $bargs > gpurun_out/$out.log 2>&1
+rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d gpurun_out/$out -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --pmc off $bargs > gpurun_out/$out.log 2>&1
 f=$(find gpurun_out/$out -name "*counter_collection.csv" | head -1)
 python - <<PY
 import csv, collections

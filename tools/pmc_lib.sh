@@ -3,7 +3,7 @@
 out=$1; lib=$2; shift 2
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export DIFFERENDER_HIP_LIB=$PWD/$lib
-rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d gpurun_out/$out -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/$out.log 2>&1
+rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d gpurun_out/$out -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --pmc off > gpurun_out/$out.log 2>&1
 f=$(find gpurun_out/$out -name "*counter_collection.csv" | head -1)
 python - <<PY
 import csv, collections
