@@ -103,6 +103,10 @@ def parse_args(argv=None):
     ap.add_argument("--split", default="views", choices=["views", "rows"],
                     help="N > 1: 'views' = one view per rank per step (weak scaling, the default); 'rows' = ONE view per "
                          "step split into N bands of image rows (strong scaling, SURVEY 8(e))")
+    ap.add_argument("--rccl-channels", type=int, default=None,
+                    help="N > 1: cap RCCL at this many channels (NCCL_MAX_NCHANNELS / NCCL_MIN_NCHANNELS, set before the "
+                         "communicator is created). Each channel is a workgroup on a CU: fewer channels leave more CUs to "
+                         "the forward march the gradient all-reduce overlaps with, at a lower all-reduce bandwidth")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-img", type=int, default=None,
                     help="image edge of the CPU-baseline sample (default: the whole view, capped at 512: ~20 s on 16 cores)")
@@ -245,6 +249,18 @@ def traffic_bytes(pm, want_bwd_kernel):
     return None
 
 
+def allreduce_model(nbytes, world):
+    """SURVEY section 5 cost model of the gradient all-reduce over xGMI (7 links x ~153 GB/s per GPU, point to point):
+    a single ring is bound by one link, 2 (G-1)/G S / 153 GB/s; with all links in use (direct reduce-scatter + all-gather,
+    S/G per peer and phase) 2 (G-1)/G S / (min(G-1, 7) x 153 GB/s). Reported beside the measured allreduce_ms."""
+    if not nbytes or world < 2:
+        return None
+    link = 153e9
+    vol = 2.0 * (world - 1) / world * nbytes
+    return {"one_link_ring_ms": round(vol / link * 1e3, 3),
+            "all_links_ms": round(vol / (min(world - 1, 7) * link) * 1e3, 3)}
+
+
 # ------------------------------------------------------------------------------------------------ main
 def init_dist(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -263,6 +279,9 @@ def init_dist(args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         backend = os.environ.get("DR_BENCH_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm
+        if getattr(args, "rccl_channels", None):
+            os.environ["NCCL_MAX_NCHANNELS"] = str(args.rccl_channels)
+            os.environ["NCCL_MIN_NCHANNELS"] = str(min(args.rccl_channels, int(os.environ.get("NCCL_MIN_NCHANNELS", "1"))))
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -398,8 +417,10 @@ def main():
 
     # the exchange step on its own (not overlapped): K synchronous all-reduces of the gradient buffers
     allreduce_ms = None
+    allreduce_bytes = None
     if dist is not None and want_bwd:
         grads = [g for g in last if g is not None]
+        allreduce_bytes = int(sum(g.numel() * g.element_size() for g in grads))
         barrier()
         t1 = time.perf_counter()
         for _ in range(max(args.steps, 1)):
@@ -491,6 +512,9 @@ def main():
         "planned_steps_per_step": int(int(planned_steps.item()) / max(args.steps, 1)),  # executed/planned < 1 = early termination
         "ms_per_step_ranks": [round(v, 4) for v in rank_ms],
         "allreduce_ms": None if allreduce_ms is None else round(allreduce_ms, 4),
+        "allreduce_bytes": allreduce_bytes,
+        "allreduce_model_ms": allreduce_model(allreduce_bytes, world),
+        "rccl_channels": getattr(args, "rccl_channels", None),
         "roofline": dominant, "roofline_fwd": roof_fwd, "roofline_bwd": roof_bwd,
         "traffic_source": traffic_source,
         "rays_marched_individually": (int(stats[2]) if stats is not None else None),

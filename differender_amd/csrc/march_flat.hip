@@ -60,11 +60,37 @@ constexpr int FNT_BWD = DR_FNT_BWD;     // (backward: 66 KB of LDS, 128 VGPRs ->
 #ifndef DR_FWD_K_HI
 #define DR_FWD_K_HI 4   // ... and at 1.75 and above
 #endif
+#ifndef DR_BWDTF_K
+#define DR_BWDTF_K 2    // backward w.r.t. the TF only (C3): consecutive samples per lane (no gradient box to feed: the
+#endif                  // per-sample state that must survive the scan is six registers)
 #ifndef DR_BWD_UNEVEN
 #define DR_BWD_UNEVEN 7   // backward: candidates dealt to a later wave for every 8 of an earlier one (0: even); 7: -1.1 %, 6: -0.5 %, 5: +2 %
 #endif
 constexpr int FEC_FWD = DR_FEC_FWD;      // ray segments listed per round (<= threads: one candidate per thread)
 constexpr int FEC_BWD = DR_FEC_BWD;      // (backward: the entry table also holds prefix / gradient / output)
+// The backward w.r.t. the TF only (C3) has no gradient box, 33 KB of LDS instead of 67: FOUR-wave workgroups, four per CU
+// (the same 4 waves per SIMD its 127 VGPRs allow, but from four workgroups in different phases instead of two): 3.22 ms
+// against 3.80 with the 8-wave shape at 512^3 (same device, profiles/r03_ab_experiments.txt); 96 VGPRs for a fifth
+// workgroup spill 132 bytes per lane: 4.08 ms.
+#ifndef DR_FNT_BWDTF
+#define DR_FNT_BWDTF 256
+#endif
+#ifndef DR_FEC_BWDTF
+#define DR_FEC_BWDTF 128
+#endif
+#ifndef DR_BWDTF_WAVES
+#define DR_BWDTF_WAVES 4
+#endif
+// Workgroup configuration of a brick kernel: forward / backward with a gradient box / backward w.r.t. the TF only
+template <bool BWD, bool WANT_VOL>
+struct FlatCfg {
+    static constexpr int FNT = BWD ? (WANT_VOL ? DR_FNT_BWD : DR_FNT_BWDTF) : DR_FNT_FWD;      // threads per workgroup
+    static constexpr int EC = BWD ? (WANT_VOL ? DR_FEC_BWD : DR_FEC_BWDTF) : DR_FEC_FWD;       // segment-table entries (= candidates per round)
+    static constexpr int WAVES = BWD ? (WANT_VOL ? DR_BWD_WAVES : DR_BWDTF_WAVES) : DR_FWD_WAVES;  // waves per SIMD the registers must allow
+    static constexpr int UNEVEN = (BWD && WANT_VOL) ? DR_BWD_UNEVEN : 0;                      // uneven dealing (cand_load)
+    static constexpr int FNW = FNT / 64, CW = EC / FNW;                                       // waves; candidates per wave and round
+    static_assert(CW <= 64 && CW * FNW == EC, "one candidate per lane and round");
+};
 
 struct FlatLds {
     float4 *tf; float *box; unsigned long long *dbox; unsigned long long *dtf;
@@ -74,7 +100,7 @@ struct FlatLds {
     int *s_rel;     // first sample index of the segment minus its flat offset
     int *offs;      // per wave: flat index of each segment's first sample, then the wave's total (index entry + wave)
     int *valid;     // in-brick samples of each segment (forward)
-    int *slen;      // forward: true length of the segment (its flat extent is padded to a multiple of FWD_K)
+    int *slen;      // true length of the segment (its flat extent is padded to a multiple of the samples per lane)
     int *live;      // backward: live sample count of the ray
     float *gmax;    // backward: per wave, the largest |grad_out| among the brick's candidate pixels
 };
@@ -82,13 +108,13 @@ struct FlatLds {
 // tables whose size depends on the run-time TF resolution R.
 template <bool BWD>
 __host__ __device__ constexpr size_t flat_fixed_bytes(bool want_vol) {
-    constexpr int EC = BWD ? FEC_BWD : FEC_FWD;
+    const int EC = want_vol ? FlatCfg<BWD, true>::EC : FlatCfg<BWD, false>::EC;
     size_t s = ((size_t)BOX_LDS * 4 + 15) / 16 * 16;
     if (BWD && want_vol) s += ((size_t)BOX_LDS * 8 + 15) / 16 * 16;
     s += (size_t)EC * 32;
-    s += (size_t)EC * 4 + (((size_t)EC + 8) * 4 + 15) / 16 * 16 + (size_t)EC * 4 + (size_t)EC * 4;  // (live | slen)
+    s += (size_t)EC * 4 + (((size_t)EC + 8) * 4 + 15) / 16 * 16 + (size_t)EC * 4 + (size_t)EC * 4;  // s_rel, offs, valid, slen
     s += (size_t)EC * 4;  // segi
-    if (BWD) s += 64;  // gmax, gmin per wave
+    if (BWD) s += (size_t)EC * 4 + 64;  // live; gmax, gmin per wave
     return s;
 }
 template <bool BWD>
@@ -97,7 +123,7 @@ __host__ __device__ inline size_t flat_lds_bytes(int R, bool want_vol, bool want
 }
 template <bool BWD, bool WANT_VOL, bool WANT_TF>
 __device__ __forceinline__ FlatLds flat_carve(unsigned char *smem, int R) {
-    constexpr int EC = BWD ? FEC_BWD : FEC_FWD;
+    constexpr int EC = FlatCfg<BWD, WANT_VOL>::EC;
     FlatLds L;
     size_t o = 0;
     L.box = reinterpret_cast<float *>(smem + o); o += align16(BOX_LDS * 4);
@@ -109,10 +135,9 @@ __device__ __forceinline__ FlatLds flat_carve(unsigned char *smem, int R) {
     L.segi = reinterpret_cast<int *>(smem + o); o += (size_t)EC * 4;
     L.offs = reinterpret_cast<int *>(smem + o); o += align16((EC + 8) * 4);  // per wave: its entries' offsets + end marker
     L.valid = reinterpret_cast<int *>(smem + o); o += (size_t)EC * 4;
-    L.slen = nullptr;
     L.gmax = nullptr;
+    L.slen = reinterpret_cast<int *>(smem + o); o += (size_t)EC * 4;
     if (BWD) { L.live = reinterpret_cast<int *>(smem + o); o += (size_t)EC * 4; L.gmax = reinterpret_cast<float *>(smem + o); o += 64; }
-    else { L.slen = reinterpret_cast<int *>(smem + o); o += (size_t)EC * 4; }
     L.tf = reinterpret_cast<float4 *>(smem + o); o += (size_t)R * 16;
     if (BWD && WANT_TF) L.dtf = reinterpret_cast<unsigned long long *>(smem + o);
     return L;
@@ -246,11 +271,11 @@ __device__ __forceinline__ bool line_meets_brick(const BrickCtx &c, f3 cam, f3 d
 }
 // `hits` (overflow items of heavy bricks): the item's candidates that passed the geometric pre-test, as offsets from c_lo;
 // the rounds then run over [0, number of hits) instead of over the raw candidate range.
-template <typename VT, int MODE, bool BWD, bool ALPHA>
+template <typename VT, int MODE, bool BWD, bool ALPHA, bool WANT_VOL>
 __device__ __forceinline__ void cand_load(const BrickParams<VT> &P, const BrickCtx &c, int view, int cbase, int ncand,
                                           const unsigned short *hits, int c_lo, int ncand_all, CandData &d) {
-    constexpr int EC = BWD ? FEC_BWD : FEC_FWD;
-    constexpr int FNW = (BWD ? FNT_BWD : FNT_FWD) / 64, CW = EC / FNW;  // candidates per wave and round
+    using Cfg = FlatCfg<BWD, WANT_VOL>;
+    constexpr int FNW = Cfg::FNW, CW = Cfg::CW;  // candidates per wave and round
     const int NP = P.W * P.H;
     const int nj = c.j1 - c.j0 + 1;
     // the candidates are dealt to the waves like cards, back and forth: neighbouring pixels (similar segment lengths)
@@ -259,13 +284,12 @@ __device__ __forceinline__ void cand_load(const BrickParams<VT> &P, const BrickC
     const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
     int cc = cbase + lane_ * FNW + ((lane_ & 1) ? FNW - 1 - wave_ : wave_);  // dealt back and forth: -1.3 %
     d.have = lane_ < CW && cc < ncand;
-#if DR_BWD_UNEVEN
-    if (BWD) {
+    if constexpr (Cfg::UNEVEN != 0) {
         // The SIMDs serve a workgroup's four earlier waves before its four later ones (1.19 x the loop time for the same
         // samples): deal 8 candidates to each earlier wave for every NL (< 8) of a later one. A round = 4 groups of
         // 8 NL + 4 (8 - NL) candidates: NL back-and-forth deals of 8, then 8 - NL deals of 4 to waves 0-3 only.
-        static_assert(!BWD || (FNW == 8 && CW == 32), "uneven dealing is laid out for 8 waves of 32 slots");
-        constexpr int NL = DR_BWD_UNEVEN, SG = 8 * NL + 4 * (8 - NL);
+        static_assert(FNW == 8 && CW == 32, "uneven dealing is laid out for 8 waves of 32 slots");
+        constexpr int NL = Cfg::UNEVEN, SG = 8 * NL + 4 * (8 - NL);
         const bool early = wave_ < 4;
         const int per = early ? 8 : NL;
         const int sg = early ? (lane_ >> 3) : lane_ / NL;
@@ -274,7 +298,6 @@ __device__ __forceinline__ void cand_load(const BrickParams<VT> &P, const BrickC
         cc = cbase + SG * sg + pos;
         d.have = lane_ < 4 * per && cc < ncand;
     }
-#endif
     d.pl = 0; d.p = 0; d.n = 0; d.entry = -1.0f; d.exit_ = 0.f; d.vx = d.vy = d.vz = 0.f;
     d.live = 0; d.rflag = 0;
     if (!d.have) return;
@@ -311,12 +334,10 @@ __device__ __forceinline__ int wave_incl_sum(int v) {
 // marker) and its own flat sample space [0, M). No workgroup barrier, no serial phase: the compaction is a ballot,
 // the offsets a DPP scan. Slots follow the candidate order, so the flat sample order -- and with it every
 // rounding -- is reproducible.
-template <typename VT, int MODE, bool BWD, int FNT, bool ALPHA = false, int KS = 1>
+template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool ALPHA = false, int KS = 1>
 __device__ __forceinline__ void flat_build_entries(const BrickParams<VT> &P, const BrickCtx &c, f3 cam, int view,
                                                    const CandData &d, FlatLds &L, int &nE, int &M) {
-    constexpr int EC = BWD ? FEC_BWD : FEC_FWD;
-    constexpr int FNW = FNT / 64, CW = EC / FNW;
-    static_assert(CW <= 64 && CW * FNW == EC, "one candidate per lane and round");
+    constexpr int CW = FlatCfg<BWD, WANT_VOL>::CW;
     bool has = false;
     int s0 = 0, s1 = 0;
     float t0 = 0.f, nm1 = 0.f;
@@ -357,7 +378,7 @@ __device__ __forceinline__ void flat_build_entries(const BrickParams<VT> &P, con
         L.segi[slot] = ray_layer(c.bx, c.by, c.bz, ebx, eby, ebz) * (P.W * P.H) + pl;
         L.s_rel[slot] = s0 - off;
         L.offs[slot + wave_] = off;
-        if (!BWD) L.slen[slot] = s1 - s0;
+        L.slen[slot] = s1 - s0;
         L.valid[slot] = 0;
         if (BWD) L.live[slot] = live;
     }
@@ -657,11 +678,13 @@ template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, bool ALP
 __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsigned char *smem, const int slot, const int view,
                                                 const int c_lo, const int c_hi, bool &box_valid) {
     if (ALPHA && P.vflags[view] == 0u) return;  // uniform: no ray of this view can terminate early
-    constexpr int EC = BWD ? FEC_BWD : FEC_FWD;
-    constexpr int ROUND = (BWD && DR_BWD_UNEVEN) ? 4 * (8 * DR_BWD_UNEVEN + 4 * (8 - DR_BWD_UNEVEN)) : EC;  // candidates consumed per round (cand_load)
-    constexpr int FNT = BWD ? FNT_BWD : FNT_FWD;
+    using Cfg = FlatCfg<BWD, WANT_VOL>;
+    constexpr int EC = Cfg::EC;
+    constexpr int ROUND = Cfg::UNEVEN ? 4 * (8 * Cfg::UNEVEN + 4 * (8 - Cfg::UNEVEN)) : EC;  // candidates consumed per round (cand_load)
+    constexpr int FNT = Cfg::FNT;
     constexpr int FNW = FNT / 64;
-    constexpr int KS = BWD ? 1 : KF;  // consecutive samples per lane (forward and alpha pre-pass)
+    constexpr bool BWD_TF = BWD && !WANT_VOL;             // backward w.r.t. the TF only
+    constexpr int KS = BWD ? (BWD_TF ? DR_BWDTF_K : 1) : KF;  // consecutive samples per lane
     const int nbricks = P.g.NBx * P.g.NBy * P.g.NBz;
 #if DR_PHASE_TIMING == 3
     const long long tq0 = clock64();
@@ -736,7 +759,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
     // (Forward and pre-pass only: the backward's gradient box is flushed per item.)
     const bool reuse_box = HEAVY && !BWD && box_valid;  // uniform
     CandData cd;
-    cand_load<VT, MODE, BWD, ALPHA>(P, c, view, r_lo, r_hi, hits, c_lo, ncand_all, cd);  // ray buffers of the first round's candidates
+    cand_load<VT, MODE, BWD, ALPHA, WANT_VOL>(P, c, view, r_lo, r_hi, hits, c_lo, ncand_all, cd);  // ray buffers of the first round's candidates
     BoxStage<FNT> stage;
     FixScale fs;
     int nE0, M0;
@@ -745,7 +768,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
     // anything when there are none.
     const bool lazy = (!BWD && !ALPHA && P.use_live && P.vflags[view] != 0u) || (ALPHA && !P.pp_first);  // uniform
     if (lazy) {
-        flat_build_entries<VT, MODE, BWD, FNT, ALPHA, KS>(P, c, cam, view, cd, L, nE0, M0);
+        flat_build_entries<VT, MODE, BWD, WANT_VOL, ALPHA, KS>(P, c, cam, view, cd, L, nE0, M0);
         if (!__syncthreads_or(nE0 > 0) && r_hi - r_lo <= ROUND) return;  // uniform: no wave found a segment
         if (!reuse_box) box_issue<VT, FNT>(P, vol, c, P.tf + view * P.tf_vs, stage);
     } else {
@@ -760,7 +783,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                 if ((threadIdx.x & 63) == 0) { L.gmax[threadIdx.x >> 6] = gm; L.gmax[8 + (threadIdx.x >> 6)] = gn; }
             }
         }
-        flat_build_entries<VT, MODE, BWD, FNT, ALPHA, KS>(P, c, cam, view, cd, L, nE0, M0);  // ... while the segments are listed
+        flat_build_entries<VT, MODE, BWD, WANT_VOL, ALPHA, KS>(P, c, cam, view, cd, L, nE0, M0);  // ... while the segments are listed
     }
 #if DR_PHASE_TIMING == 3
     const long long tq2 = clock64();   // candidates loaded and listed
@@ -804,8 +827,8 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
     for (int cbase = r_lo; cbase < r_hi; cbase += ROUND) {
         int nE = nE0, M = M0;
         if (cbase > r_lo) {
-            cand_load<VT, MODE, BWD, ALPHA>(P, c, view, cbase, r_hi, hits, c_lo, ncand_all, cd);
-            flat_build_entries<VT, MODE, BWD, FNT, ALPHA, KS>(P, c, cam, view, cd, L, nE, M);  // syncs inside
+            cand_load<VT, MODE, BWD, ALPHA, WANT_VOL>(P, c, view, cbase, r_hi, hits, c_lo, ncand_all, cd);
+            flat_build_entries<VT, MODE, BWD, WANT_VOL, ALPHA, KS>(P, c, cam, view, cd, L, nE, M);  // syncs inside
         }
         any = any || nE > 0;
         // this wave's own segment table: entries [ea, eb), flat samples [0, M); offsets live at index entry + wave
@@ -888,6 +911,135 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                     const int before = cntp ? atomicAdd(&L.valid[e], cntp) : L.valid[e];
                     if (seg_end && before + cntp > 0)
                         P.seg_rgba[seg_view + L.segi[e]] = make_float4(0.f, 0.f, 0.f, 1.0f - Tl);
+                }
+                continue;
+            }
+            if constexpr (BWD_TF && KS == 2) {
+                // ---- Backward w.r.t. the TF only (C3): TWO consecutive samples per lane, like the forward. Without a gradient
+                // box to feed, what a sample must carry across the scan is six registers (L, op, gC.rgb, alpha, TF cell and
+                // fraction), so the cross-lane work -- the scan of (gC.C, A), the run sums of d_tf, the three per-ray loads,
+                // the entry walk -- is paid once per 128 samples. d_tf is a continuous function of the lighting term
+                // (min(1, L) enters, not its switch), so the kink re-shading of D7 is not needed here.
+                const int slen = L.slen[e];
+                const int live_e = L.live[e];
+                const float4 go = pf_go;
+                const float gpre = go.x * pf_pre.x + go.y * pf_pre.y + go.z * pf_pre.z, apre = pf_pre.w;  // stored prefix as (gC . C, A)
+                const float gfin = go.x * pf_of.x + go.y * pf_of.y + go.z * pf_of.z, afin = pf_of.w;      // the final composite likewise
+                float kL[KS], kop[KS], krd[KS], kfr[KS], ka[KS];
+                int klo[KS], khi[KS];
+                bool kval[KS];
+                Over2 el2 = {0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < KS; ++j) {
+                    kL[j] = kop[j] = krd[j] = kfr[j] = ka[j] = 0.f; klo[j] = khi[j] = 0; kval[j] = false;
+                    if (j >= ks) continue;  // uniform
+                    Sample sm; TapCoords t;
+                    const bool actj = act && (f + j - eoff) < slen;
+                    bool vj = false;
+                    if (actj) {
+                        sample_pos_rcp(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, cam.x, cam.y, cam.z, s + j, sm.px, sm.py, sm.pz);
+                        vj = sample_coords_at(vol, c, sm, t);
+                    }
+                    Over2 ej = {0.f, 0.f};
+                    if (vj) {
+                        float dx, dy, dz;
+                        sm.I = sample_centre_lds(L.box, t);
+                        classify_from_I(L.tf, P.R, P.tf_len, P.inv_sr, sm);
+                        sample_normal_taps_lds(L.box, t, dx, dy, dz);
+                        shade_from_grad<true>(dx, dy, dz, light, vd, true, sm);
+                        const float rd = go.x * sm.r + go.y * sm.g + go.z * sm.b;
+                        kL[j] = sm.L; kop[j] = sm.op; krd[j] = rd; kfr[j] = sm.fr; ka[j] = sm.a; klo[j] = sm.lo; khi[j] = sm.hi;
+                        kval[j] = true;
+                        ej.w = (sm.L * sm.op) * rd; ej.a = sm.op;
+                    }
+                    el2 = (j == 0) ? ej : over2(el2, ej);  // over2(x, 0) == x exactly
+                }
+                // segmented scan of the lanes' composites; the first segment may continue an entry begun in an earlier chunk
+                const int e_first = __builtin_amdgcn_readfirstlane(e);
+                const bool cont = (carry_e == e_first);
+                const int e_last = __builtin_amdgcn_readlane(e, 63);
+                const bool more = (f0 + 64 * ks < fb) && (offs[e_last + 1] > f0 + 64 * ks);
+                Over2 inc2 = seg_scan_over2(el2, lane, sl), exc2;
+                exc2.w = wave_up1(inc2.w, 0.f); exc2.a = wave_up1(inc2.a, 0.f);
+                if (lane == sl) { exc2.w = 0.f; exc2.a = 0.f; }
+                if (cont && e == e_first) { inc2 = over2(carry2, inc2); exc2 = over2(carry2, exc2); }
+                carry2.w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inc2.w), 63));
+                carry2.a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inc2.a), 63));
+                carry_e = more ? e_last : -1;
+                // adjoints of the lane's samples, front to back (tape-free identity, as sample_adjoint)
+                float tv[KS][4];
+                {
+                    Over2 cur = exc2;  // composite before the sample, within this brick's part of the segment
+                    const float Tpre = 1.0f - apre;
+#pragma unroll
+                    for (int j = 0; j < KS; ++j) {
+                        tv[j][0] = tv[j][1] = tv[j][2] = tv[j][3] = 0.f;
+                        if (kval[j]) {
+                            Over2 ej; ej.w = (kL[j] * kop[j]) * krd[j]; ej.a = kop[j];
+                            const Over2 after = over2(cur, ej);
+                            const float absw = fmaf(Tpre, after.w, gpre), absa = fmaf(Tpre, after.a, apre);
+                            const float T = Tpre * (1.0f - cur.a);  // transmittance before the sample
+                            const bool last = (s + j == live_e - 1);
+                            const float suffix = (gfin - absw) + go.w * (afin - absa);
+                            const float qs = kL[j] * krd[j] + go.w;
+                            const float sfx = suffix * __builtin_amdgcn_rcpf(1.0f - kop[j]);
+                            const float op_bar = T * qs - (last ? 0.0f : sfx);
+                            const float Lop = kL[j] * kop[j] * T;
+                            const float a_bar = op_bar * ((P.inv_sr == 1.0f) ? 1.0f : P.inv_sr * powf(1.0f - ka[j], P.inv_sr - 1.0f));
+                            const float w0 = 1.0f - kfr[j], w1 = kfr[j];
+                            tv[j][0] = w0 * Lop; tv[j][1] = w1 * Lop; tv[j][2] = w0 * a_bar; tv[j][3] = w1 * a_bar;
+                            cur = after;
+                        }
+                    }
+                }
+                // d_tf: runs of consecutive samples between the same two texels are summed across lanes (DPP) and added once.
+                // A lane whose two samples fall into different TF cells ("split") closes the incoming run with its first sample
+                // and opens a new one with its second. Runs stop at segment boundaries (the upstream colour gradient go.xyz is
+                // per ray) and at the ends of the pass.
+                const bool vA = kval[0], vB = kval[1];
+                const bool split = vA && vB && klo[0] != klo[1];
+                const int key_in = vA ? klo[0] : (vB ? klo[1] : -1 - lane);
+                const int key_out = vB ? klo[1] : (vA ? klo[0] : -1 - lane);
+                const int hi_out = vB ? khi[1] : khi[0];
+                const int prev_out = wave_up1(key_out, key_out);
+                const bool contl = lane != 0 && lane != sl && key_in == prev_out;  // continues the run of the lane before
+                const bool start = !contl || split;                                // the lane's outgoing value starts a run
+                float V[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) V[q] = split ? tv[1][q] : tv[0][q] + tv[1][q];
+                const unsigned long long starts = __ballot(start);
+                const unsigned long long upto = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+                const int rs = 63 - __clzll((long long)(starts & upto));  // first lane of this lane's outgoing run (lane 0 starts one)
+                seg_scan_sum<4>(V, lane, rs);
+                const unsigned long long contm = __ballot(contl);
+                const bool run_end = lane == 63 || !((contm >> ((lane + 1) & 63)) & 1ull);
+                auto emit = [&](bool em, const float (&tq)[4], int lo, int hi) {
+                    const float v8[8] = {tq[0] * go.x, tq[0] * go.y, tq[0] * go.z, tq[2], tq[1] * go.x, tq[1] * go.y, tq[1] * go.z, tq[3]};
+                    const float vmax = ((fabsf(v8[0]) + fabsf(v8[1])) + (fabsf(v8[2]) + fabsf(v8[3]))) +
+                                       ((fabsf(v8[4]) + fabsf(v8[5])) + (fabsf(v8[6]) + fabsf(v8[7])));
+                    unsigned long long *d0 = L.dtf + 4 * lo, *d1 = L.dtf + 4 * hi;
+                    if (__any(em && !(vmax <= ACC_LIM))) {  // a NaN or an absurd run total: the sanitising path
+                        if (em) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) { acc_add_f64(d0 + q, acc_sanitise(v8[q])); acc_add_f64(d1 + q, acc_sanitise(v8[4 + q])); }
+                        }
+                    } else if (em) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { acc_add_f64(d0 + q, v8[q]); acc_add_f64(d1 + q, v8[4 + q]); }
+                    }
+                };
+                emit((vA || vB) && run_end, V, key_out, hi_out);
+                if (__any(split)) {  // uniform
+                    // (the DPP moves are pinned in front of the select: the compiler otherwise turns `contl ? dpp : 0` into an
+                    // exec-masked region around the v_mov_dpp, and a DPP move whose SOURCE lane is masked off writes nothing)
+                    float Pv[4], H[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) Pv[q] = wave_up1(V[q], 0.f);   // inclusive sum of the previous lane's outgoing run
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(Pv[q]));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) H[q] = (contl ? Pv[q] : 0.0f) + tv[0][q];
+                    emit(split, H, klo[0], khi[0]);
                 }
                 continue;
             }
@@ -1203,7 +1355,7 @@ constexpr int ITEM_GRID_FWD = DR_ITEM_GRID_FWD, ITEM_GRID_BWD = DR_ITEM_GRID_BWD
 constexpr int ITEM_RUN = DR_ITEM_RUN;   // consecutive items a workgroup takes at a time
 
 template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, bool ALPHA = false, int KF = 1>
-__global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FWD_WAVES) void brick_flat_kernel(BrickParams<VT> P) {
+__global__ __launch_bounds__((FlatCfg<BWD, WANT_VOL>::FNT), (FlatCfg<BWD, WANT_VOL>::WAVES)) void brick_flat_kernel(BrickParams<VT> P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef DR_VIEW_FASTEST
     // (tried: consecutive workgroups = the same brick of consecutive views, so that the box comes from L2 after its first
@@ -1219,7 +1371,7 @@ __global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FW
 }
 // the overflow items of heavy bricks (all views), worked off by a fixed, small grid
 template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, bool ALPHA = false, int KF = 1>
-__global__ __launch_bounds__(BWD ? FNT_BWD : FNT_FWD, BWD ? DR_BWD_WAVES : DR_FWD_WAVES) void brick_flat_items_kernel(BrickParams<VT> P) {
+__global__ __launch_bounds__((FlatCfg<BWD, WANT_VOL>::FNT), (FlatCfg<BWD, WANT_VOL>::WAVES)) void brick_flat_items_kernel(BrickParams<VT> P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (BWD && P.stats[ST_MARK] != P.mark) return;  // uniform over the grid: not this call's workspace, the item list is garbage
     const int n_items = min((int)*P.n_items, ITEM_CAP);
@@ -1280,7 +1432,7 @@ bool brick_path_supported(int VX, int VY, int VZ, int R) {
         if ((e = allow_lds(brick_flat_kernel<VT, MODE_, BWD_, VOL_, TF_, ALPHA_, K_>, lds)) != hipSuccess) return (int)e;             \
         if ((e = allow_lds(brick_flat_items_kernel<VT, MODE_, BWD_, VOL_, TF_, ALPHA_, K_>, align16(lds) + ITEM_EXTRA_LDS)) != hipSuccess) return (int)e; \
         hipLaunchKernelGGL((brick_flat_kernel<VT, MODE_, BWD_, VOL_, TF_, ALPHA_, K_>), DR_GRID1, dim3(NT_), lds, stream, P);         \
-        hipLaunchKernelGGL((brick_flat_items_kernel<VT, MODE_, BWD_, VOL_, TF_, ALPHA_, K_>), dim3(BWD_ ? ITEM_GRID_BWD : ITEM_GRID_FWD), dim3(NT_), align16(lds) + ITEM_EXTRA_LDS, stream, P); \
+        hipLaunchKernelGGL((brick_flat_items_kernel<VT, MODE_, BWD_, VOL_, TF_, ALPHA_, K_>), dim3(BWD_ ? (VOL_ ? ITEM_GRID_BWD : 2 * ITEM_GRID_BWD) : ITEM_GRID_FWD), dim3(NT_), align16(lds) + ITEM_EXTRA_LDS, stream, P); \
     }
 
 template <typename VT>
@@ -1383,7 +1535,7 @@ static int flat_bwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     // (the brick records, live flags and work items are the forward's: same inputs, same workspace)
     if (wv && wt) DR_LAUNCH_BOTH(DR_MODE_DIFF, true, true, true, false, 1, FNT_BWD)
     else if (wv) DR_LAUNCH_BOTH(DR_MODE_DIFF, true, true, false, false, 1, FNT_BWD)
-    else DR_LAUNCH_BOTH(DR_MODE_DIFF, true, false, true, false, 1, FNT_BWD)
+    else DR_LAUNCH_BOTH(DR_MODE_DIFF, true, false, true, false, 1, (FlatCfg<true, false>::FNT))
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
     MarchArgs b = a;
     b.only_flagged = w.rayflag;  // B2: irregular rays through the baseline backward (every ray, if the workspace is not this call's)
