@@ -107,6 +107,9 @@ def parse_args(argv=None):
                     help="N > 1: cap RCCL at this many channels (NCCL_MAX_NCHANNELS / NCCL_MIN_NCHANNELS, set before the "
                          "communicator is created). Each channel is a workgroup on a CU: fewer channels leave more CUs to "
                          "the forward march the gradient all-reduce overlaps with, at a lower all-reduce bandwidth")
+    ap.add_argument("--hints", default="auto", choices=["auto", "off"],
+                    help="caller hints of dr_march_fwd (DR_HINT_*): 'auto' = derived from the TF's largest alpha once it is "
+                         "known (functional._TerminationHints, no host sync); 'off' = never")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-img", type=int, default=None,
                     help="image edge of the CPU-baseline sample (default: the whole view, capped at 512: ~20 s on 16 cores)")
@@ -374,7 +377,8 @@ def main():
         # (warm-up steps run the very same host code, events included: their first use has a one-time host cost)
         a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a0.record()
-        out, steps = F.march_fwd(vol, tf, cam, e, x, r, n, S, sr, variant=args.variant, workspace=ws, rows=rows_arg)
+        out, steps = F.march_fwd(vol, tf, cam, e, x, r, n, S, sr, variant=args.variant, workspace=ws, rows=rows_arg,
+                                 hints=("auto" if args.hints == "auto" else 0))
         a1.record()
         if timed:
             ev["fwd"].append((a0, a1))

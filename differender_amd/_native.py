@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("DIFFERENDER_HIP_LIB") or os.path.join(_HERE, "libdiff
 DR_F32, DR_F16 = 0, 1
 DR_MODE_DIFF, DR_MODE_NONDIFF = 0, 1
 DR_VARIANT_AUTO, DR_VARIANT_BASELINE = 0, 1
+DR_HINT_NO_EARLY_TERMINATION, DR_HINT_EARLY_TERMINATION = 0x100, 0x200   # OR-ed into `variant` of dr_march_fwd[_rows]
 
 _c = ctypes
 _P, _I, _L, _F, _D, _U, _Z = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_double, _c.c_uint32, _c.c_size_t

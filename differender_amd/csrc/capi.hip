@@ -118,10 +118,14 @@ int dr_march_fwd_rows(const void *vol, int vol_dtype, int VX, int VY, int VZ, in
     if (row0 < 0 || img_W < W || row0 > img_W - W) return DR_EINVAL;
     a.img_W = img_W; a.row0 = row0;
     if (mode != DR_MODE_DIFF && mode != DR_MODE_NONDIFF) return DR_EINVAL;
+    const int hints = variant & ~0xff;
+    variant &= 0xff;
     if (variant < DR_VARIANT_AUTO || variant > DR_VARIANT_BASELINE) return DR_EINVAL;
+    if (hints & ~(DR_HINT_NO_EARLY_TERMINATION | DR_HINT_EARLY_TERMINATION)) return DR_EINVAL;
+    if ((hints & DR_HINT_NO_EARLY_TERMINATION) && (hints & DR_HINT_EARLY_TERMINATION)) return DR_EINVAL;
     DeviceOf guard(vol);
     if (guard.err != hipSuccess) return (int)guard.err;
-    a.mode = mode; a.out = out_rgba; a.steps = steps;
+    a.mode = mode; a.out = out_rgba; a.steps = steps; a.hints = hints;
     a.fov_rad = fov_rad; a.near_plane = near_plane; a.workspace = workspace; a.workspace_bytes = workspace_bytes;
     if (variant != DR_VARIANT_BASELINE && workspace && brick_path_supported(VX, VY, VZ, R) &&
         brick_image_supported(W, H, VX, VY, VZ)) {

@@ -38,6 +38,7 @@ struct BrickParams {
     int n_views;
     unsigned int mark;   // fingerprint of this forward/backward pair (ws_fingerprint): the forward leaves it in stats[ST_MARK],
                          // the backward trusts records, live flags, ray flags and work items only if it finds it there
+    int hint_noterm;     // forward: the caller said no ray can terminate early and the pre-pass was not launched; F2 checks
     int use_live;        // forward: ws_steps holds each ray's exact live sample count (from the alpha pre-pass)
     int pp_l0, pp_l1, pp_first;  // alpha pre-pass phase: brick layers [pp_l0, pp_l1); later phases skip terminated rays
     const struct BrickCtxRec *ctx;  // [view][brick]: brick geometry + pixel rectangle, filled once per forward call
@@ -57,6 +58,7 @@ enum {
     ST_TICKET = 6,         // work-item launches: next item to hand out / workgroups done (the last one resets both to 0)
     ST_DONE = 7,
     ST_NITEMS = 5,         // diagnostic copy of the number of overflow work items of the last forward (heavy bricks: BrickItem)
+    ST_HINT_BAD = 8,       // forward: views for which DR_HINT_NO_EARLY_TERMINATION was wrong (their rays were marched one by one)
     ST_F64_BRICKS = 4,     // backward: (view, brick) pairs whose d_volume box accumulated in double (wide local range of |grad_out|)
     ST_TIMING = 16,        // DR_PHASE_TIMING: u64 x3 forward phases, u64 x3 backward phases, u64 backward lifetime
     ST_WORDS = 512         // header size in words (2 KiB)
@@ -237,7 +239,7 @@ static __global__ __launch_bounds__(256) void brick_ctx_kernel(BrickParams<VT> P
                 const float lim = 1.0f + 1e-3f;
                 P.vflags[view] = flag;
                 P.vflags[P.n_views + view] = (fabsf(cx) <= lim && fabsf(cy) <= lim && fabsf(cz) <= lim) ? 1u : 0u;
-                if (view == 0) { P.stats[ST_REPAIR] = 0u; P.stats[ST_BASELINE_RAYS] = 0u; P.stats[ST_F64_BRICKS] = 0u; P.stats[ST_TICKET] = 0u; P.stats[ST_DONE] = 0u; P.stats[ST_MARK] = P.mark; }
+                if (view == 0) { P.stats[ST_REPAIR] = 0u; P.stats[ST_BASELINE_RAYS] = 0u; P.stats[ST_HINT_BAD] = 0u; P.stats[ST_F64_BRICKS] = 0u; P.stats[ST_TICKET] = 0u; P.stats[ST_DONE] = 0u; P.stats[ST_MARK] = P.mark; }
             }
         }
     }
@@ -502,6 +504,7 @@ static inline BrickParams<VT> make_brick_params(const MarchArgs &a, const Worksp
     P.near_ = (float)a.near_plane; P.near_h = (float)near_h; P.near_w = (float)(near_h * ((double)P.imgW / (double)a.H));
     P.g = make_brick_grid(a.VX, a.VY, a.VZ);
     P.seg_rgba = w.seg_rgba; P.seg_cnt = w.seg_cnt; P.rayflag = w.rayflag; P.stats = w.stats; P.vflags = w.vflags; P.n_views = a.n_views; P.ws_steps = w.ws_steps;
+    P.hint_noterm = (a.hints & DR_HINT_NO_EARLY_TERMINATION) ? 1 : 0;
     P.use_live = a.use_live; P.ctx = w.ctx; P.items = w.items; P.n_items = w.n_items;
     P.mark = ws_fingerprint(a);
     P.pp_l0 = a.pp_l0; P.pp_l1 = a.pp_l1; P.pp_first = a.pp_first;

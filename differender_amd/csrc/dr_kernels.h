@@ -23,6 +23,7 @@ struct MarchArgs {
     const uint8_t *only_flagged;  // baseline backward: restrict to rays with a non-zero flag (may be null)
     const unsigned int *ws_mark;  // ... unless *ws_mark != ws_mark_expect (the workspace is not this call's forward's: the
     unsigned int ws_mark_expect;  //     flags are garbage, every ray is marched); may be null
+    int hints;                    // DR_HINT_* bits of the forward call
     int use_live;                 // forward: per-ray live sample counts are available (alpha pre-pass)
     int pp_l0, pp_l1, pp_first;   // alpha pre-pass phase: brick layers [pp_l0, pp_l1); pp_first: no earlier phase
 };

@@ -1455,9 +1455,11 @@ static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     // Alpha pre-pass (early-termination culling): only if the TF can make some ray reach alpha >= 0.99 -- decided on
     // the device from max(alpha) by the first kernel (which also writes the brick records and resets the workspace
     // header); the kernels of the pre-pass return at once otherwise.
-    const bool prepass = true;
+    // DR_HINT_NO_EARLY_TERMINATION: the caller knows the TF cannot make a ray opaque -- the (device-gated) launches of the
+    // pre-pass are not issued at all. The device still evaluates may_terminate(); F2 repairs the view if the hint was wrong.
+    const bool prepass = !(a.hints & DR_HINT_NO_EARLY_TERMINATION);
     double n_max = 0.0;
-    if (prepass) {
+    {
         const double diag = sqrt((double)(a.VX - 1) * (a.VX - 1) + (double)(a.VY - 1) * (a.VY - 1) + (double)(a.VZ - 1) * (a.VZ - 1));
         n_max = floor((double)a.sr * 2.0 * sqrt(3.0) * diag) + 1.0;  // longest chord of the box (VR.py:251-253)
         if (a.mode == DR_MODE_DIFF && n_max > a.S) n_max = a.S;
@@ -1465,13 +1467,18 @@ static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     }
     hipLaunchKernelGGL(brick_ctx_kernel<VT>, dim3((nbricks + 255) / 256, a.n_views), dim3(256), 0, stream, P, w.ctx, nbricks, 1,
                        (float)n_max);
+    // Samples per lane: the cross-lane scan and the chunk bookkeeping are paid once per K*64 samples, but lanes K
+    // samples apart share fewer LDS words (more read cycles, more bank conflicts). Measured at 512^3: K = 2 wins up
+    // at sampling rate 1 (-3 %), K = 4 from 2 on (-13 % at 2, -16 % at 4 and 8 vs K = 1: samples are closer together); K = 8 loses.
+#define DR_LAUNCH_F1(MODE_, K_) DR_LAUNCH_BOTH(MODE_, false, false, false, false, K_, FNT_FWD)
+    const bool k_hi = a.sr >= 1.75f;
     if (prepass) {
         // The pre-pass runs front to back in G groups of brick layers; after each group the rays that have reached
         // alpha >= 0.99 are known and the next group does not march them (with the reference's tf1 preset three
         // quarters of all samples lie behind the termination point): ground-truth renders at sampling rate 8 take
         // 11.0 instead of 15.0 ms (8 views, 256^3). Each extra group costs the non-terminating case two empty
         // launches (~10 us: +0.7 % on the 512^3 headline at G = 2 for -2.5 % with tf1), so below sampling rate 3: G = 1.
-        const int G = (a.sr >= 3.0f) ? DR_PP_GROUPS : 1;
+        const int G = (a.sr >= 3.0f || (a.hints & DR_HINT_EARLY_TERMINATION)) ? DR_PP_GROUPS : 1;
         MarchArgs pa = a;
         for (int gi = 0; gi < G; ++gi) {
             pa.pp_l0 = g.NL * gi / G; pa.pp_l1 = g.NL * (gi + 1) / G; pa.pp_first = gi == 0;
@@ -1496,11 +1503,6 @@ static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     MarchArgs b = a;
     b.use_live = prepass ? 1 : 0;
     P.use_live = b.use_live;
-    // Samples per lane: the cross-lane scan and the chunk bookkeeping are paid once per K*64 samples, but lanes K
-    // samples apart share fewer LDS words (more read cycles, more bank conflicts). Measured at 512^3: K = 2 wins up
-    // at sampling rate 1 (-3 %), K = 4 from 2 on (-13 % at 2, -16 % at 4 and 8 vs K = 1: samples are closer together); K = 8 loses.
-#define DR_LAUNCH_F1(MODE_, K_) DR_LAUNCH_BOTH(MODE_, false, false, false, false, K_, FNT_FWD)
-    const bool k_hi = a.sr >= 1.75f;
     if (a.mode == DR_MODE_DIFF) { if (k_hi) DR_LAUNCH_F1(DR_MODE_DIFF, DR_FWD_K_HI) else DR_LAUNCH_F1(DR_MODE_DIFF, DR_FWD_K) }
     else { if (k_hi) DR_LAUNCH_F1(DR_MODE_NONDIFF, DR_FWD_K_HI) else DR_LAUNCH_F1(DR_MODE_NONDIFF, DR_FWD_K) }
 #undef DR_LAUNCH_F1

@@ -52,6 +52,7 @@ __global__ __launch_bounds__(256) void ray_compose_kernel(BrickParams<VT> P) {
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, A = 0.f;
     int steps = 0;
     uint8_t flag = 0;
+    if (pl == 0 && P.hint_noterm && P.vflags[view] != 0u) atomicAdd(&P.stats[ST_HINT_BAD], 1u);  // (see below)
     if (rg.n > 0) {
         VolView<VT> vol = P.vol;
         vol.p += view * P.vol_vs;
@@ -62,6 +63,10 @@ __global__ __launch_bounds__(256) void ray_compose_kernel(BrickParams<VT> P) {
         const int nfull = nmarch;
         const size_t seg0 = (size_t)view * P.g.NL * NP + pl;
         bool regular = ray_is_regular(rg.n);
+        // DR_HINT_NO_EARLY_TERMINATION was given (no pre-pass was launched) but this view's TF CAN make rays opaque: the
+        // bricks marched every planned sample, early termination was not applied -- march every ray of the view whole
+        // (uniform over the view; correct, slow, counted)
+        if (P.hint_noterm && P.vflags[view] != 0u) regular = false;
         // with an alpha pre-pass the bricks marched exactly the live samples of the ray
         const bool use_live = P.use_live && P.vflags[view] != 0u;
         if (regular && use_live) nmarch = min(nmarch, P.ws_steps[p]);

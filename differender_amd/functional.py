@@ -5,13 +5,15 @@ current torch stream. Volume tensors live in the reference's field index space (
 (W, D, H) of the user's (1, D, H, W) tensor (VR.py:481) and may have arbitrary strides, so the
 permuted view of VR.py:566,571 is consumed without a copy.
 """
+import math
+
 import numpy as np
 import torch
 
 from . import _native as N
 
 __all__ = ["ray_setup", "march_fwd", "march_bwd", "new_jitter_seed", "alloc_workspace", "workspace_stats",
-           "mse_loss_grad", "tf_momentum_step", "as_volume", "bwd_is_sanitised"]
+           "mse_loss_grad", "tf_momentum_step", "as_volume", "bwd_is_sanitised", "termination_hints"]
 
 
 def _stream():
@@ -96,8 +98,9 @@ def workspace_stats(workspace):
     """Diagnostics the last forward left in the workspace header: [0] = rays whose segments failed the
     sample-count check and were marched individually (expected 0), [2] = all rays the per-ray fallback marched
     (those plus the irregular ones: single-sample rays), [4] = bricks whose d_volume box accumulated in double (last
-    backward), [5] = overflow work items heavy bricks were cut into."""
-    return workspace[:32].view(torch.int32).cpu()
+    backward), [5] = overflow work items heavy bricks were cut into, [8] = views for which a DR_HINT_NO_EARLY_TERMINATION
+    hint turned out wrong (their rays were marched one by one), [3] = the forward's fingerprint (0: nobody's)."""
+    return workspace[:64].view(torch.int32).cpu()
 
 
 def _ws_args(workspace):
@@ -138,12 +141,106 @@ def ray_setup(cam, out_shape, vol_shape, sampling_rate, fov_deg=30.0, near=0.1, 
     return entry, exit_, rays, n
 
 
+class _TerminationHints:
+    """DR_HINT_* for march_fwd, derived from the transfer function WITHOUT ever synchronising with the device.
+
+    Whether a ray can reach alpha 0.99 at all is a property of the TF's largest alpha (and of the longest possible ray): the
+    library decides it on the device at the start of every forward and gates its alpha pre-pass off -- but the gated
+    launches themselves (five per forward: ~45 us at 512^3, ~25 us at 256^3) are still issued, and how finely a pre-pass
+    that DOES run should proceed front to back is a host decision too. A TF that is rendered again and again unchanged (a
+    fixed TF under volume optimisation, OPT.py; the ground-truth TF; every benchmark) lets the host know: the largest alpha
+    of a TF tensor is computed once per tensor VERSION (torch bumps `_version` on every in-place write, for every view and
+    `.detach()` of the tensor alike), copied to pinned memory asynchronously, and used by later calls once the copy has landed
+    (event.query(), never a wait). A TF seen for the
+    first time, or one that changes every iteration, simply gets no hint. A stale answer (data changed behind the version
+    counter's back) cannot produce a wrong image: the device re-checks and repairs (include/differender_hip.h)."""
+
+    def __init__(self, capacity=8):
+        # key -> [tensor, version, state, host value / tensor, event]; state 0 = seen once, 1 = copy in flight, 2 = known.
+        # The key is WHERE the data lives (storage address, offset, shape, strides) and the entry holds a reference to the
+        # tensor, so that the memory cannot be handed to anybody else while the entry exists (a TF is a few KB; at most
+        # `capacity` of them are kept): `tf.detach()` -- a new Python object every call, same storage, same version counter
+        # -- matches; a temporary such as `tf.permute(1, 0).contiguous()` gets another address every call and never does.
+        self._seen = {}
+        self._capacity = capacity
+
+    @staticmethod
+    def _key(tf):
+        return (tf.untyped_storage().data_ptr(), tf.storage_offset(), tuple(tf.shape), tuple(tf.stride()), tf.dtype)
+
+    def invalidate(self, tf):
+        base = tf.untyped_storage().data_ptr()
+        for k in [k for k in self._seen if k[0] == base]:
+            del self._seen[k]
+
+    def amax(self, tf, alpha=lambda t: t[..., 3]):
+        """Largest alpha of `tf` (inf if any alpha is NaN), or None while it is not known yet. `alpha` selects the alpha
+        entries ((..., R, 4) layout by default)."""
+        key = self._key(tf)
+        ent = self._seen.get(key)
+        if ent is not None and ent[1] != tf._version:
+            ent = None
+        if ent is None:
+            self._seen.pop(key, None)
+            if len(self._seen) >= self._capacity:
+                self._seen.pop(next(iter(self._seen)))
+            self._seen[key] = [tf.detach(), tf._version, 0, None, None]
+            return None
+        if ent[2] == 0:   # second sighting of this very version: worth three tiny launches
+            host = torch.empty((), dtype=torch.float32, pin_memory=True)
+            with torch.no_grad():
+                host.copy_(torch.nan_to_num(alpha(tf.detach()).float(), nan=float("inf")).max(), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            ent[2], ent[3], ent[4] = 1, host, ev
+            return None
+        if ent[2] == 1:
+            if not ent[4].query():
+                return None
+            ent[2], ent[3], ent[4] = 2, float(ent[3].item()), None
+        return ent[3]
+
+    def hints(self, tf, vol_shape, sampling_rate, max_samples, mode, alpha=lambda t: t[..., 3]):
+        a = self.amax(tf, alpha)
+        if a is None:
+            return 0
+        # may_terminate() of the device (csrc/dr_brick_common.h), in double, with a margin on either side of its 0.02
+        VX, VY, VZ = (int(v) for v in vol_shape)
+        diag = math.sqrt((VX - 1) ** 2 + (VY - 1) ** 2 + (VZ - 1) ** 2)
+        n_max = math.floor(float(sampling_rate) * 2.0 * math.sqrt(3.0) * diag) + 1.0
+        if mode == N.DR_MODE_DIFF and n_max > max_samples:
+            n_max = float(max_samples)
+        n_max = max(n_max, 1.0)
+        if not (a == a) or a == float("inf"):
+            return 0
+        base = max(1.0 - min(a, 1.0), 0.0)
+        op = 1.0 - base ** (1.0 / float(sampling_rate))
+        remain = (1.0 - op) ** n_max if op < 1.0 else 0.0
+        if remain > 0.03:   # (the device's threshold is 0.02, evaluated in float: 1.5 x is a wide margin for rounding)
+            return N.DR_HINT_NO_EARLY_TERMINATION
+        if remain < 1e-4:
+            return N.DR_HINT_EARLY_TERMINATION
+        return 0
+
+
+_hints = _TerminationHints()
+
+
+def termination_hints(tf, vol_shape, sampling_rate, max_samples, mode, alpha=lambda t: t[..., 3]):
+    """DR_HINT_* bits for march_fwd(hints=...) from a TF tensor the CALLER holds on to (see _TerminationHints); `alpha`
+    selects its alpha entries when the layout is not (..., R, 4) -- e.g. `lambda t: t[..., 3, :]` for the user-facing
+    ([BS,] 4, R) layout of Raycaster."""
+    return _hints.hints(tf, vol_shape, sampling_rate, max_samples, mode, alpha)
+
+
 def march_fwd(vol, tf, cam, entry, exit_, rays, n, max_samples, sampling_rate, mode=N.DR_MODE_DIFF,
-              variant=N.DR_VARIANT_AUTO, want_steps=True, fov_deg=30.0, near=0.1, workspace="auto", rows=None):
+              variant=N.DR_VARIANT_AUTO, want_steps=True, fov_deg=30.0, near=0.1, workspace="auto", rows=None,
+              hints="auto"):
     """raycast + get_final_image (VR.py:261-306,363-372) or the nondiff pair (VR.py:308-361).
     Returns out (views,W,H,4) and steps (views,W,H) int32 (or None).
     workspace: a buffer from alloc_workspace() (keep it for march_bwd), "auto" to allocate a throw-away one,
-    or None to force the baseline kernels."""
+    or None to force the baseline kernels.
+    hints: "auto" (DR_HINT_* from the TF's largest alpha once it is known, see _TerminationHints), 0 / None, or explicit bits."""
     _require_gpu(vol, "volume")
     V, W, H = n.shape
     dev = vol.device
@@ -154,11 +251,13 @@ def march_fwd(vol, tf, cam, entry, exit_, rays, n, max_samples, sampling_rate, m
     targs = _tf_args(tf, V)
     if isinstance(workspace, str):
         workspace = alloc_workspace(V, (W, H), vargs[2:5], targs[1], dev) if variant == N.DR_VARIANT_AUTO else None
+    if isinstance(hints, str):
+        hints = _hints.hints(tf, vargs[2:5], sampling_rate, max_samples, mode) if variant == N.DR_VARIANT_AUTO else 0
     with torch.cuda.device(dev):
         rc = N.lib().dr_march_fwd_rows(*vargs, targs[0], targs[1], targs[2], cam.data_ptr(), entry.data_ptr(),
                                        exit_.data_ptr(), rays.data_ptr(), n.data_ptr(), V, W, H, int(max_samples),
                                        float(sampling_rate), float(np.radians(fov_deg)), float(near), int(mode),
-                                       int(variant), out.data_ptr(), steps.data_ptr() if want_steps else None,
+                                       int(variant) | int(hints or 0), out.data_ptr(), steps.data_ptr() if want_steps else None,
                                        *_ws_args(workspace), *_rows(rows, W), _stream())
     N.check(rc, "dr_march_fwd_rows")
     return out, steps
@@ -234,4 +333,5 @@ def tf_momentum_step(tf, d_tf, momentum, lr, gamma, max_grad):
         rc = N.lib().dr_tf_momentum_step(tf.data_ptr(), d_tf.data_ptr(), momentum.data_ptr(), tf.numel(), float(lr),
                                          float(gamma), float(max_grad), _stream())
     N.check(rc, "dr_tf_momentum_step")
+    _hints.invalidate(tf)   # written through its raw pointer: torch's version counter did not see it
     return tf, momentum

@@ -229,7 +229,7 @@ class RaycastFunction(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, vr, volume, tf, look_from, sampling_rate, batched, jitter=True):
+    def forward(ctx, vr, volume, tf, look_from, sampling_rate, batched, jitter=True, hints="auto"):
         is_batched, bs = batched
         cam = look_from.reshape(-1, 3)
         if is_batched and cam.shape[0] != bs:
@@ -240,7 +240,7 @@ class RaycastFunction(torch.autograd.Function):
         e, x, r, n = F.ray_setup(cam, vr.resolution, volume.shape[-3:], sampling_rate, vr.fov_deg, vr.near, seed)
         ws = F.alloc_workspace(cam.shape[0], vr.resolution, volume.shape[-3:], tf.shape[-2], volume.device)
         out, steps = F.march_fwd(volume, tf, cam, e, x, r, n, vr.max_samples, sampling_rate, N.DR_MODE_DIFF,
-                                 fov_deg=vr.fov_deg, near=vr.near, workspace=ws)
+                                 fov_deg=vr.fov_deg, near=vr.near, workspace=ws, hints=hints)
         ctx.save_for_backward(volume, tf, cam, e, x, r, n, out)
         ctx.workspace = ws  # coarse tape of the forward (per-segment prefixes), consumed by backward
         ctx.vr, ctx.sampling_rate, ctx.batched, ctx.jitter_seed = vr, sampling_rate, is_batched, seed
@@ -265,7 +265,7 @@ class RaycastFunction(torch.autograd.Function):
                 dv = torch.nan_to_num(dv)
             if dt is not None:
                 dt = torch.nan_to_num(dt)
-        return None, dv, dt, None, None, None, None
+        return None, dv, dt, None, None, None, None, None
 
 
 class Raycaster(torch.nn.Module):
@@ -297,6 +297,14 @@ class Raycaster(torch.nn.Module):
             return True, bs, vol_out, tf_out, lf_out
         return False, 0, volume.squeeze(0).permute(2, 0, 1), tf.permute(1, 0), look_from
 
+    def _hints(self, tf, vol_in, sampling_rate, mode):
+        """DR_HINT_* from the USER's TF tensor ([BS,] 4, R) -- the object that lives across iterations and whose version
+        counter torch keeps; the (R, 4) copy handed to the kernels is a fresh temporary every call."""
+        if not tf.is_cuda:
+            return 0
+        return F.termination_hints(tf, vol_in.shape[-3:], sampling_rate, self.vr.max_samples, mode,
+                                   alpha=lambda t: t[..., 3, :])
+
     def raycast_nondiff(self, volume, tf, look_from, sampling_rate=None):
         """VR.py:490-523: non-differentiable render (never jittered); default rate 4x the module's."""
         with torch.no_grad(), torch.autocast("cuda", enabled=False):
@@ -306,7 +314,8 @@ class Raycaster(torch.nn.Module):
             cam = lf_in.reshape(-1, 3).float()
             e, x, r, n = F.ray_setup(cam, self.vr.resolution, vol_in.shape[-3:], sr, self.vr.fov_deg, self.vr.near, 0)
             out, steps = F.march_fwd(vol_in, tf_in.float().contiguous(), cam, e, x, r, n, self.vr.max_samples, sr,
-                                     N.DR_MODE_NONDIFF, fov_deg=self.vr.fov_deg, near=self.vr.near)
+                                     N.DR_MODE_NONDIFF, fov_deg=self.vr.fov_deg, near=self.vr.near,
+                                     hints=self._hints(tf, vol_in, sr, N.DR_MODE_NONDIFF))
             self.vr._steps = steps if batched else steps[0]
             if batched:  # (BS,W,H,4) -> flip H -> (BS,4,H,W), VR.py:513
                 return torch.flip(out, (2,)).permute(0, 3, 2, 1).contiguous()
@@ -315,7 +324,8 @@ class Raycaster(torch.nn.Module):
     def forward(self, volume, tf, look_from):
         """VR.py:525-548. volume ([BS,]1,D,H,W), tf ([BS,]4,R), look_from ([BS,]3) -> ([BS,]4,H,W)."""
         batched, bs, vol_in, tf_in, lf_in = self._determine_batch(volume, tf, look_from)
-        res = RaycastFunction.apply(self.vr, vol_in, tf_in, lf_in, self.sampling_rate, (batched, bs), self.jitter)
+        res = RaycastFunction.apply(self.vr, vol_in, tf_in, lf_in, self.sampling_rate, (batched, bs), self.jitter,
+                                    self._hints(tf, vol_in, self.sampling_rate, N.DR_MODE_DIFF))
         if batched:
             return torch.flip(res, (2,)).permute(0, 3, 2, 1).contiguous()
         return torch.flip(res, (1,)).permute(2, 1, 0).contiguous()

@@ -41,6 +41,16 @@ enum { DR_MODE_DIFF = 0, DR_MODE_NONDIFF = 1 };
  * per sample); BASELINE forces the plain one-lane-per-ray kernels (kept for differential testing and as the
  * fallback for problems the fast kernels do not serve). */
 enum { DR_VARIANT_AUTO = 0, DR_VARIANT_BASELINE = 1 };
+/* Caller hints for dr_march_fwd[_rows], OR-ed into `variant` (bits 8 and up; the variant proper is the low byte). A hint
+ * only chooses between ways of computing the SAME result -- a wrong one costs time, never correctness:
+ *   DR_HINT_NO_EARLY_TERMINATION  "no ray can reach alpha 0.99 with this TF": the launches of the alpha pre-pass (which the
+ *       device would gate off anyway, once it has looked at the TF's largest alpha) are not issued at all. The device still
+ *       checks; if the hint was wrong, every ray of the view is marched whole by the per-ray kernels (exact early termination,
+ *       10-40 x slower) and workspace header word 8 counts the views it happened to.
+ *   DR_HINT_EARLY_TERMINATION     "many rays terminate early": the alpha pre-pass runs front to back in groups of brick
+ *       layers also below sampling rate 3, so that later groups skip the rays that are already opaque.
+ * differender_amd.functional derives both from the TF tensor (largest alpha, cached per tensor version, no host sync). */
+enum { DR_HINT_NO_EARLY_TERMINATION = 0x100, DR_HINT_EARLY_TERMINATION = 0x200 };
 
 enum {
     DR_EINVAL = -1,      /* bad argument (null pointer, non-positive extent, unknown enum) */

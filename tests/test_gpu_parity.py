@@ -561,6 +561,130 @@ def test_backward_does_not_trust_a_workspace_it_did_not_fill(oracle, hiplib):
     assert ok, err
 
 
+def test_termination_hints_choose_a_path_never_a_result(oracle, hiplib):
+    """DR_HINT_* (include/differender_hip.h) only choose between ways of computing the same image: a right hint skips or
+    refines the alpha pre-pass, a WRONG "no early termination" is detected on the device and repaired (every ray of the
+    view marched whole: the oracle's image and gradients, workspace header word 8 counts the view)."""
+    from differender_amd import functional as Fn
+    import differender_amd._native as N
+    WH = (40, 32)
+    cam_h = oracle.in_circles(0.9)
+    for tfkind in ("bench", "peaks"):
+        vol_h, tf_h, _ = scene(oracle, N=40, R=32, tf=tfkind, alpha=0.004)
+        vol, tf, cam = T(vol_h), T(tf_h), T(np.atleast_2d(cam_h))
+        e, x, r, n = Fn.ray_setup(cam, WH, vol.shape, 1.0)
+        eh, xh, rh, nh = (t[0].cpu().numpy() for t in (e, x, r, n))
+        ref, ref_steps = oracle.march_fwd(vol_h, tf_h, cam_h, eh, xh, rh, nh, 4096, 1.0, 0)
+        g_h = np.random.default_rng(9).standard_normal((1, *WH, 4)).astype(np.float32)
+        dv_o, dt_o = oracle.march_bwd(vol_h, tf_h, cam_h, eh, xh, rh, nh, 4096, 1.0, g_h[0])
+        terminates = bool((ref_steps < nh).any())
+        assert terminates == (tfkind == "peaks")
+        for hint in (0, N.DR_HINT_NO_EARLY_TERMINATION, N.DR_HINT_EARLY_TERMINATION):
+            ws = Fn.alloc_workspace(1, WH, vol.shape, tf.shape[0], dev())
+            out, steps = Fn.march_fwd(vol, tf, cam, e, x, r, n, 4096, 1.0, workspace=ws, hints=hint)
+            assert np.array_equal(steps[0].cpu().numpy(), ref_steps), (tfkind, hint)
+            assert np.abs(out[0].cpu().numpy() - ref).max() <= FWD_TOL, (tfkind, hint)
+            dv, dt = Fn.march_bwd(vol, tf, cam, e, x, r, n, 4096, 1.0, T(g_h), out, workspace=ws)
+            ok, err = grad_close(dv.cpu().numpy(), dv_o)
+            assert ok, (tfkind, hint, err)
+            ok, err = grad_close(dt.cpu().numpy(), dt_o)
+            assert ok, (tfkind, hint, err)
+            wrong = terminates and hint == N.DR_HINT_NO_EARLY_TERMINATION
+            st = Fn.workspace_stats(ws)
+            assert int(st[8]) == (1 if wrong else 0), (tfkind, hint, st[:10])
+            if wrong:
+                assert int(st[2]) == int((nh > 0).sum())      # every ray that hits was marched whole
+    # unknown hint bits and contradicting hints are rejected
+    for bad in (0x400, N.DR_HINT_NO_EARLY_TERMINATION | N.DR_HINT_EARLY_TERMINATION):
+        with pytest.raises(RuntimeError):
+            Fn.march_fwd(vol, tf, cam, e, x, r, n, 4096, 1.0, hints=bad)
+
+
+@pytest.mark.parametrize("sr", [1.0, 3.0, 8.0])
+def test_nondiff_render_under_the_termination_hint(oracle, hiplib, sr):
+    """DR_HINT_EARLY_TERMINATION on a non-differentiable render: the alpha pre-pass runs front to back in groups of brick
+    layers at every sampling rate, rays that have crossed alpha 0.99 drop out of later groups. Image and step counts must be
+    what the sequential oracle gives -- also for a view whose TF cannot terminate at all, and from inside the volume.
+    (Round 3 also built the "one-pass" variant -- colour in the grouped pass, a fix-up launch for the crossing segments;
+    this test passed on it, it was 7 % slower and is gone: profiles/r03_ab_experiments.txt.)"""
+    from differender_amd import functional as Fn
+    import differender_amd._native as N
+    vol_h = oracle.synth_volume(48)
+    WH = (40, 48)
+    tf_a = oracle.peaks_tf(32)
+    tf_b = oracle.bench_tf(32, 0.001)                       # this view's TF never reaches alpha 0.99
+    tf_c = oracle.peaks_tf(32); tf_c[:, 3] = np.minimum(1.0, 3.0 * tf_c[:, 3])
+    cams_h = np.stack([oracle.in_circles(0.4), oracle.in_circles(2.0), np.array([0.2, 0.1, -0.3], np.float32)]).astype(np.float32)
+    tfs_h = np.stack([tf_a, tf_b, tf_c]).astype(np.float32)
+    vol, tfs, cams = T(vol_h), T(tfs_h), T(cams_h)
+    e, x, r, n = Fn.ray_setup(cams, WH, vol.shape, sr)
+    outs = {}
+    for hint in (0, N.DR_HINT_EARLY_TERMINATION):
+        ws = Fn.alloc_workspace(3, WH, vol.shape, 32, dev())
+        out, steps = Fn.march_fwd(vol, tfs, cams, e, x, r, n, 1 << 20, sr, N.DR_MODE_NONDIFF, workspace=ws, hints=hint)
+        outs[hint] = (out.cpu().numpy(), steps.cpu().numpy())
+        st = Fn.workspace_stats(ws)
+        assert int(st[0]) == 0, st[:10]                      # no ray needed the count-check repair
+    terminated = 0
+    for v in range(3):
+        eh, xh, rh, nh = (t[v].cpu().numpy() for t in (e, x, r, n))
+        ref, ref_steps = oracle.march_fwd(vol_h, tfs_h[v], cams_h[v], eh, xh, rh, nh, 1 << 20, sr, 1)
+        terminated += int((ref_steps < nh).sum())
+        for hint, (o, s) in outs.items():
+            reg = nh != 1
+            assert np.array_equal(s[v][reg], ref_steps[reg]), (v, hint)
+            assert np.abs(o[v] - ref).max(-1)[reg].max() <= FWD_TOL, (v, hint)
+    assert terminated > 500
+
+
+def test_automatic_hints_follow_the_tensor_not_its_address(oracle, hiplib):
+    """hints="auto": the largest alpha of a TF tensor is learnt asynchronously once the same tensor VERSION has been seen
+    twice, and forgotten when the tensor is written to; a temporary that merely reuses an address never inherits it."""
+    from differender_amd import functional as Fn
+    import differender_amd._native as N
+    vol_h, tf_h, cam_h = scene(oracle, N=32, R=16, tf="bench", alpha=0.004)
+    WH = (24, 24)
+    vol, tf, cam = T(vol_h), T(tf_h), T(np.atleast_2d(cam_h))
+    e, x, r, n = Fn.ray_setup(cam, WH, vol.shape, 1.0)
+    H = Fn._TerminationHints()
+    args = (vol.shape, 1.0, 4096, N.DR_MODE_DIFF)
+    assert H.hints(tf, *args) == 0                     # first sighting
+    assert H.hints(tf, *args) == 0                     # second: the copy is started
+    torch.cuda.synchronize()
+    assert H.hints(tf, *args) == N.DR_HINT_NO_EARLY_TERMINATION
+    tf[:, 3] = 0.9                                     # in-place write: new version, nothing is assumed
+    assert H.hints(tf, *args) == 0 and H.hints(tf, *args) == 0
+    torch.cuda.synchronize()
+    assert H.hints(tf, *args) == N.DR_HINT_EARLY_TERMINATION
+    tf[3, 3] = float("nan")                            # a NaN alpha: anything can happen, no hint
+    H.hints(tf, *args); H.hints(tf, *args); torch.cuda.synchronize()
+    assert H.hints(tf, *args) == 0
+    # temporaries: a fresh tensor per call never inherits anything (the entry keeps its predecessor's memory alive, so the
+    # allocator cannot hand the same address out again) ...
+    for k in range(4):
+        t = T((tf_h * 1.0).astype(np.float32))
+        assert H.hints(t, *args) == 0
+        del t
+    # ... while `.detach()` and other views of ONE tensor -- new Python objects, same storage and version counter -- do
+    tf3 = T(tf_h)
+    assert H.hints(tf3.detach(), *args) == 0 and H.hints(tf3.detach(), *args) == 0
+    torch.cuda.synchronize()
+    assert H.hints(tf3.detach(), *args) == N.DR_HINT_NO_EARLY_TERMINATION
+    tf3.mul_(0.5)                                      # a write through the base is seen by every view
+    assert H.hints(tf3.detach(), *args) == 0
+    # and through march_fwd the automatic hint reproduces the unhinted image bit for bit
+    tf2 = T(tf_h)
+    outs = []
+    for k in range(4):
+        out, _ = Fn.march_fwd(vol, tf2, cam, e, x, r, n, 4096, 1.0)
+        torch.cuda.synchronize()
+        outs.append(out.cpu().numpy())
+    assert Fn._hints.amax(tf2) is not None
+    base, _ = Fn.march_fwd(vol, tf2, cam, e, x, r, n, 4096, 1.0, hints=0)
+    for o in outs:
+        assert np.array_equal(o, base.cpu().numpy())
+
+
 def test_many_views_without_prepass(oracle, hiplib):
     """More than 48 views in one call (the per-view termination flags once lived in the 2 KiB workspace header and the
     alpha pre-pass was skipped beyond 48 views; they now have their own array behind the header and the pre-pass runs
