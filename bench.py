@@ -345,7 +345,11 @@ def main():
     gen = torch.Generator(device="cpu").manual_seed(4321)
     V = args.views
     bands = args.split == "rows" and world > 1
-    row0, ROWS = shard_rows(IMG, rank, world) if bands else (0, IMG)
+    # (one view for all ranks: the cameras are host numbers, so the per-row work can be estimated without touching the device;
+    #  the bands of a step are cut for the FIRST timed camera and kept -- buffers and workspace keep their shapes)
+    from differender_amd.distributed import row_work_estimate
+    band_weights = row_work_estimate(in_circles(0.1 * args.warmup * args.views), IMG, IMG) if bands and args.cam == "orbit" else None
+    row0, ROWS = shard_rows(IMG, rank, world, weights=band_weights) if bands else (0, IMG)
     rows_arg = (row0, IMG) if bands else None
     target = torch.rand((1, IMG, IMG, 4), generator=gen).to(dev)[:, row0:row0 + ROWS].expand(V, ROWS, IMG, 4).contiguous()
     loss_acc = torch.zeros((), dtype=torch.float64, device=dev)

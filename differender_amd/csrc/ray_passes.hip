@@ -81,15 +81,19 @@ __global__ __launch_bounds__(256) void ray_compose_kernel(BrickParams<VT> P) {
             // for. Safety net: the segments must account for every sample, else this ray is marched whole below.
             // (four layers per step, their loads issued together: the walk is a chain of memory latencies otherwise)
             int total = 0;
-            for (int l = 0; l <= l_hi; l += 4) {
-                int cnt[4];
-                float4 sg[4];
+#ifndef DR_F2_WIDE
+#define DR_F2_WIDE 4   // layers per step of the walk
+#endif
+            constexpr int FW = DR_F2_WIDE;
+            for (int l = 0; l <= l_hi; l += FW) {
+                int cnt[FW];
+                float4 sg[FW];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) cnt[k] = (l + k <= l_hi) ? (int)P.seg_cnt[seg0 + (size_t)(l + k) * NP] : 0;
+                for (int k = 0; k < FW; ++k) cnt[k] = (l + k <= l_hi) ? (int)P.seg_cnt[seg0 + (size_t)(l + k) * NP] : 0;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) sg[k] = cnt[k] ? P.seg_rgba[seg0 + (size_t)(l + k) * NP] : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int k = 0; k < FW; ++k) sg[k] = cnt[k] ? P.seg_rgba[seg0 + (size_t)(l + k) * NP] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < FW; ++k) {
                     if (cnt[k] == 0) continue;
                     if (MODE == DR_MODE_DIFF) P.seg_rgba[seg0 + (size_t)(l + k) * NP] = make_float4(C0, C1, C2, A);  // prefix for the backward
                     const float T = 1.0f - A;

@@ -7,7 +7,7 @@ d_volume / d_tf over them. The only exchange step is one sum all-reduce of those
 """
 import torch
 
-__all__ = ["shard_views", "shard_rows", "all_reduce_gradients", "GradientReducer"]
+__all__ = ["shard_views", "shard_rows", "row_work_estimate", "all_reduce_gradients", "GradientReducer"]
 
 
 def shard_views(n_views, rank=None, world_size=None):
@@ -18,17 +18,61 @@ def shard_views(n_views, rank=None, world_size=None):
     return list(range(rank, n_views, world_size))
 
 
-def shard_rows(image_rows, rank=None, world_size=None):
+def shard_rows(image_rows, rank=None, world_size=None, weights=None):
     """A single view split into `world_size` bands of image rows: returns (row0, n_rows) of
-    rank `rank`; the bands differ by at most one row and tile the image. Pass `rows=(row0, image_rows)` and an output
-    shape of (n_rows, H) to functional.ray_setup / march_fwd / march_bwd; the bands' gradients are summed with
-    all_reduce_gradients exactly like those of different views."""
+    rank `rank`; the bands tile the image. Pass `rows=(row0, image_rows)` and an output shape of (n_rows, H) to
+    functional.ray_setup / march_fwd / march_bwd; the bands' gradients are summed with all_reduce_gradients exactly like
+    those of different views.
+    weights: per-row work estimates (row_work_estimate): the bands then carry equal WORK instead of equal rows -- the rows
+    through the middle of the volume hold several times the samples of the rows at the image's edge (equal rows: the
+    slowest of 8 bands has 1.4 x the mean, profiles/r03_band_prediction_*.txt). Every rank must pass the same weights."""
     if rank is None or world_size is None:
         import torch.distributed as dist
         rank, world_size = dist.get_rank(), dist.get_world_size()
-    base, extra = divmod(int(image_rows), int(world_size))
-    row0 = rank * base + min(rank, extra)
-    return row0, base + (1 if rank < extra else 0)
+    image_rows, world_size = int(image_rows), int(world_size)
+    if weights is None:
+        base, extra = divmod(image_rows, world_size)
+        row0 = rank * base + min(rank, extra)
+        return row0, base + (1 if rank < extra else 0)
+    import numpy as np
+    w = np.asarray(weights, np.float64)
+    if w.shape != (image_rows,) or not np.isfinite(w).all() or (w < 0).any():
+        raise ValueError("weights must be one finite, non-negative number per image row")
+    w = w + max(float(w.sum()), 1.0) * 1e-3 / image_rows        # every row costs something (ray setup, image I/O)
+    cum = np.concatenate([[0.0], np.cumsum(w)])
+    cuts = [0]
+    for k in range(1, world_size):                              # first row at which the cumulated work reaches k / G
+        c = int(np.searchsorted(cum, cum[-1] * k / world_size, side="left"))
+        cuts.append(min(max(c, cuts[-1] + 1), image_rows - (world_size - k)))   # at least one row per band
+    cuts.append(image_rows)
+    return cuts[rank], cuts[rank + 1] - cuts[rank]
+
+
+def row_work_estimate(look_from, image_rows, image_cols, fov_deg=30.0, near=0.1, cols=48):
+    """Marched samples per image row, up to a factor: the chord through the volume [-1, 1]^3 of `cols` rays per row, from the
+    pinhole model of compute_entry_exit (VR.py:127-151, 28-53, 221-259) evaluated on the HOST in numpy (the sample count
+    of a ray is its chord length x the sampling rate x the volume diagonal, VR.py:251-253). look_from: three host numbers
+    (a camera that only exists on the device would need a synchronising copy: pass its host original). An estimate for
+    load balancing only -- it decides who renders which rows, never what is rendered."""
+    import numpy as np
+    W, H = int(image_rows), int(image_cols)
+    o = np.asarray(look_from, np.float64).reshape(3)
+    vd = -o / np.linalg.norm(o)
+    right = np.cross(vd, [0.0, 1.0, 0.0]); right /= np.linalg.norm(right)
+    up = np.cross(right, vd); up /= np.linalg.norm(up)
+    near_h = 2.0 * np.tan(np.radians(fov_deg)) * near
+    near_w = near_h * (W / H)
+    x = (np.arange(W) + 0.5) / W - 0.5
+    y = (np.linspace(0, H - 1, min(cols, H)) + 0.5) / H - 0.5
+    d = near * vd + x[:, None, None] * near_w * right + y[None, :, None] * near_h * up
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t1 = (-1.0 - o) / d
+        t2 = (1.0 - o) / d
+    tmin = np.nanmax(np.minimum(t1, t2), axis=-1)
+    tmax = np.nanmin(np.maximum(t1, t2), axis=-1)
+    hit = ~((tmax < 0.0) | (tmin > tmax))
+    return np.where(hit, tmax - tmin, 0.0).sum(axis=1)
 
 
 def all_reduce_gradients(grads, group=None, async_op=False):

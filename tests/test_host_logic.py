@@ -88,3 +88,31 @@ def test_shard_rows_tiles_the_image():
             assert row0 == pos and n >= 0
             pos += n
         assert max(n for _, n in bands) - min(n for _, n in bands) <= 1
+
+
+def test_work_balanced_row_bands():
+    """shard_rows(weights=...): bands tile the image, every band has a row, and the bands carry equal estimated work; the
+    estimate itself is the pinhole + slab test of compute_entry_exit (VR.py:127-151, 28-53) on a coarse grid, checked
+    here against the oracle's sample counts."""
+    import numpy as np
+    from differender_amd.distributed import row_work_estimate, shard_rows
+    from oracle import oracle as O
+    cam = O.in_circles(0.3)
+    W = H = 96
+    w = row_work_estimate(cam, W, H)
+    e, x, r, n = O.ray_setup(cam, W, H, (64, 64, 64), 1.0)
+    true = n.sum(axis=1).astype(np.float64)
+    assert np.corrcoef(w, true)[0, 1] > 0.999
+    for G in (2, 3, 4, 8):
+        bands = [shard_rows(W, k, G, weights=w) for k in range(G)]
+        assert bands[0][0] == 0 and all(b[1] >= 1 for b in bands)
+        assert all(bands[k][0] + bands[k][1] == bands[k + 1][0] for k in range(G - 1)) and bands[-1][0] + bands[-1][1] == W
+        work = np.array([true[r0:r0 + nr].sum() for r0, nr in bands])
+        even = np.array([true[r0:r0 + nr].sum() for r0, nr in (shard_rows(W, k, G) for k in range(G))])
+        assert work.max() / work.mean() < 1.12, (G, work)
+        assert work.max() <= even.max()
+    # degenerate weights still give every rank a band
+    assert [shard_rows(5, k, 5, weights=np.array([0, 0, 9.0, 0, 0])) for k in range(5)] == [(k, 1) for k in range(5)]
+    assert sum(nr for _, nr in (shard_rows(10, k, 4, weights=np.zeros(10)) for k in range(4))) == 10
+    with pytest.raises(ValueError):
+        shard_rows(10, 0, 2, weights=np.ones(9))

@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench as B                                   # synthetic scene of the headline
 from differender_amd import functional as F
-from differender_amd.distributed import shard_rows
+from differender_amd.distributed import row_work_estimate, shard_rows
 
 
 def main():
@@ -33,13 +33,17 @@ def main():
     ap.add_argument("--tf-res", type=int, default=256)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--gs", default="1,2,4,8")
+    ap.add_argument("--balance", default="rows", choices=["rows", "work"],
+                    help="rows: bands of equal height; work: bands of equal estimated work (distributed.row_work_estimate)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     N, IMG, R = a.vol, a.img, a.tf_res
     vol = B.synth_volume_torch(N, dev)
     n_max = 2.0 * math.sqrt(3.0) * math.sqrt(3.0) * (N - 1)
     tf = B.bench_tf_torch(R, 3.0 / n_max, dev)
-    cam = torch.tensor([B.in_circles(0.3)], dtype=torch.float32, device=dev)
+    cam_host = B.in_circles(0.3)
+    cam = torch.tensor([cam_host], dtype=torch.float32, device=dev)
+    weights = row_work_estimate(cam_host, IMG, IMG) if a.balance == "work" else None
     gen = torch.Generator(device="cpu").manual_seed(4321)
     target = torch.rand((1, IMG, IMG, 4), generator=gen).to(dev)
     S, sr = 1 << 20, 1.0
@@ -47,7 +51,7 @@ def main():
     for G in [int(g) for g in a.gs.split(",")]:
         bands = []
         for rank in range(G):
-            row0, rows = shard_rows(IMG, rank, G)
+            row0, rows = shard_rows(IMG, rank, G, weights=weights)
             rows_arg = (row0, IMG) if G > 1 else None
             ws = F.alloc_workspace(1, (rows, IMG), (N, N, N), R, dev)
             e, x, r, n = F.ray_setup(cam, (rows, IMG), (N, N, N), sr, rows=rows_arg)
@@ -72,7 +76,7 @@ def main():
         res[G] = bands
     t1 = res[1][0]["fwd_ms"] + res[1][0]["bwd_ms"] if 1 in res else None
     grad_bytes = N ** 3 * 4 + R * 16
-    print(f"# band predictor: {N}^3 f32 volume, {IMG}^2 image, one view in G row bands, camera in_circles(0.3); ms per band (median of {a.reps})")
+    print(f"# band predictor: {N}^3 f32 volume, {IMG}^2 image, one view in G row bands of equal {'height' if a.balance == 'rows' else 'estimated work'}, camera in_circles(0.3); ms per band (median of {a.reps})")
     summary = {}
     for G, bands in res.items():
         slow = max(b["fwd_ms"] + b["bwd_ms"] for b in bands)
