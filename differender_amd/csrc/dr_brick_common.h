@@ -59,6 +59,7 @@ enum {
     ST_DONE = 7,
     ST_NITEMS = 5,         // diagnostic copy of the number of overflow work items of the last forward (heavy bricks: BrickItem)
     ST_HINT_BAD = 8,       // forward: views for which DR_HINT_NO_EARLY_TERMINATION was wrong (their rays were marched one by one)
+    ST_STALE_BWD = 9,      // backward calls that did not find their forward's fingerprint here and marched every ray one by one
     ST_F64_BRICKS = 4,     // backward: (view, brick) pairs whose d_volume box accumulated in double (wide local range of |grad_out|)
     ST_TIMING = 16,        // DR_PHASE_TIMING: u64 x3 forward phases, u64 x3 backward phases, u64 backward lifetime
     ST_WORDS = 512         // header size in words (2 KiB)
@@ -195,6 +196,7 @@ __device__ __forceinline__ int near_first_brick(const BrickParams<VT> &P, int i,
 // workspace that holds something else (never filled, filled by another call, forward served by the baseline kernels, which
 // clear the mark) makes B1 return at once and B2 march every ray: slow, correct, and no index read from garbage.
 static_assert(ST_MARK == WS_MARK_WORD, "capi.hip clears this word through flat_invalidate_workspace");
+static_assert(ST_STALE_BWD == WS_MARK_WORD + 6, "march_baseline.hip counts stale backward calls at ws_mark[6]");
 static inline unsigned int ws_fingerprint(const MarchArgs &a) {
     unsigned long long h = 0xcbf29ce484222325ull;
     auto mix = [&h](unsigned long long v) { for (int k = 0; k < 8; ++k) { h ^= (v >> (8 * k)) & 0xffu; h *= 0x100000001b3ull; } };
@@ -206,7 +208,10 @@ static inline unsigned int ws_fingerprint(const MarchArgs &a) {
     mix((unsigned long long)a.vol_dtype); mix((unsigned long long)a.sx); mix((unsigned long long)a.sy); mix((unsigned long long)a.sz);
     mix((unsigned long long)a.vol_vs);
     mix((unsigned long long)(uintptr_t)a.vol); mix((unsigned long long)(uintptr_t)a.entry); mix((unsigned long long)(uintptr_t)a.exit_);
-    mix((unsigned long long)(uintptr_t)a.rays); mix((unsigned long long)(uintptr_t)a.nsamp); mix((unsigned long long)(uintptr_t)a.cam);
+    mix((unsigned long long)(uintptr_t)a.rays); mix((unsigned long long)(uintptr_t)a.nsamp);
+    // (not the camera's address: hosts hand over `cam.contiguous()` -- a fresh temporary per call for an expanded or
+    //  converted look_from -- and a backward that did not recognise its own forward would silently run 10-40 x slower;
+    //  the ray buffers, which are derived from the camera, identify the call)
     const unsigned int f = (unsigned int)(h ^ (h >> 32));
     return f ? f : 1u;   // 0 = "nobody's" (what flat_invalidate_workspace writes)
 }
@@ -239,7 +244,7 @@ static __global__ __launch_bounds__(256) void brick_ctx_kernel(BrickParams<VT> P
                 const float lim = 1.0f + 1e-3f;
                 P.vflags[view] = flag;
                 P.vflags[P.n_views + view] = (fabsf(cx) <= lim && fabsf(cy) <= lim && fabsf(cz) <= lim) ? 1u : 0u;
-                if (view == 0) { P.stats[ST_REPAIR] = 0u; P.stats[ST_BASELINE_RAYS] = 0u; P.stats[ST_HINT_BAD] = 0u; P.stats[ST_F64_BRICKS] = 0u; P.stats[ST_TICKET] = 0u; P.stats[ST_DONE] = 0u; P.stats[ST_MARK] = P.mark; }
+                if (view == 0) { P.stats[ST_REPAIR] = 0u; P.stats[ST_BASELINE_RAYS] = 0u; P.stats[ST_HINT_BAD] = 0u; P.stats[ST_STALE_BWD] = 0u; P.stats[ST_F64_BRICKS] = 0u; P.stats[ST_TICKET] = 0u; P.stats[ST_DONE] = 0u; P.stats[ST_MARK] = P.mark; }
             }
         }
     }

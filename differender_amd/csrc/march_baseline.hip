@@ -102,6 +102,8 @@ __global__ __launch_bounds__(256) void march_bwd_baseline_kernel(MarchParams<VT>
     // second pass of the brick-centric backward: only the rays the forward flagged -- unless the workspace is not that
     // forward's (uniform): then the flags mean nothing, B1 has done nothing, and every ray is marched here
     const bool stale_ws = P.ws_mark != nullptr && *P.ws_mark != P.ws_mark_expect;
+    if (stale_ws && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+        atomicAdd(const_cast<unsigned int *>(P.ws_mark) + 6, 1u);   // header word 9 (ST_STALE_BWD): the host layer warns
     if (active && P.only_flagged && !stale_ws) active = P.only_flagged[((size_t)view * P.W + i) * P.H + j] != 0;
     if (active) {
         const size_t p = ((size_t)view * P.W + i) * P.H + j;

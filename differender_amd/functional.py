@@ -99,7 +99,8 @@ def workspace_stats(workspace):
     sample-count check and were marched individually (expected 0), [2] = all rays the per-ray fallback marched
     (those plus the irregular ones: single-sample rays), [4] = bricks whose d_volume box accumulated in double (last
     backward), [5] = overflow work items heavy bricks were cut into, [8] = views for which a DR_HINT_NO_EARLY_TERMINATION
-    hint turned out wrong (their rays were marched one by one), [3] = the forward's fingerprint (0: nobody's)."""
+    hint turned out wrong (their rays were marched one by one), [9] = backward calls that did not find their forward's
+    fingerprint in this workspace and marched every ray one by one, [3] = the forward's fingerprint (0: nobody's)."""
     return workspace[:64].view(torch.int32).cpu()
 
 

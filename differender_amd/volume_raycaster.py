@@ -109,10 +109,11 @@ class VolumeRaycaster:
         self._stats_host, self._stats_event, self._stats_rays = None, None, 0
         self.last_stats = None         # workspace header of the most recent forward whose snapshot has arrived (int32 x32)
         self._warned_fallback = False
+        self._warned_stale = False
 
     def _watch_workspace(self, workspace, n_rays):
-        """Keeps an eye on the fast path's fallback counter without ever synchronising: a 128-byte snapshot of the
-        workspace header is copied to pinned memory after a forward, and looked at when a LATER call finds it
+        """Keeps an eye on the fast path's fallback counters without ever synchronising: a 128-byte snapshot of the
+        workspace header is copied to pinned memory after a forward or a backward, and looked at when a LATER call finds it
         complete. Warns once if more than 1 % of the rays had to be marched one by one (single-sample rays or rays whose
         segments failed the count check: correct, but the 10-40x slower kernels)."""
         if workspace is None:
@@ -120,6 +121,12 @@ class VolumeRaycaster:
         if self._stats_event is not None and self._stats_event.query():
             self.last_stats = self._stats_host.clone()
             slow = int(self.last_stats[2])
+            if int(self.last_stats[9]) and not self._warned_stale:
+                self._warned_stale = True
+                warnings.warn("differender_amd: a backward pass did not find its forward's coarse tape in the workspace it "
+                              "was given (fingerprint mismatch) and marched every ray with the per-ray kernels: correct, "
+                              "but 10-40x slower -- pass the forward's ray buffers, volume and workspace unchanged",
+                              RuntimeWarning, stacklevel=3)
             if slow > 0.01 * self._stats_rays and not self._warned_fallback:
                 self._warned_fallback = True
                 warnings.warn(f"differender_amd: {slow} of {self._stats_rays} rays were marched by the per-ray fallback "
@@ -257,6 +264,7 @@ class RaycastFunction(torch.autograd.Function):
         dv, dt = F.march_bwd(volume, tf, cam, e, x, r, n, ctx.vr.max_samples, ctx.sampling_rate, g, out,
                              want_vol=want_vol, want_tf=want_tf, fov_deg=ctx.vr.fov_deg, near=ctx.vr.near,
                              workspace=ctx.workspace)
+        ctx.vr._watch_workspace(ctx.workspace, n.numel())
         # VR.py:463-464,474-475: nan_to_num. The fast kernels drop NaN adjoints and clamp infinite ones themselves
         # ("non-finite upstream gradients"), so the two full passes over d_volume are only run when the
         # plain kernels served the call.

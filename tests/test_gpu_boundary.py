@@ -206,3 +206,34 @@ def test_backward_skips_nan_to_num_only_on_the_fast_path(hiplib):
     from differender_amd import _native as N
     assert N.lib().dr_march_bwd_variant(1, 8, 8, 16, 16, 16, 8, 256, 16, 1, 256, 16, 1, 1, 0, 1) == N.DR_VARIANT_AUTO
     assert N.lib().dr_march_bwd_variant(1, 40000, 40000, 16, 16, 16, 8, 256, 16, 1, 256, 16, 1, 1, 0, 1) == N.DR_VARIANT_BASELINE
+
+
+def test_module_backward_recognises_its_forward_whatever_the_argument_layout(oracle, hiplib):
+    """The fast backward only runs under its own forward's fingerprint (sizes, strides, addresses of volume and ray
+    buffers). Through the module every combination of batched / un-batched, converted and expanded arguments must still
+    match -- a mismatch would be correct but 10-40 x slower, so it is counted (workspace header word 9) and warned about."""
+    import warnings
+    from differender_amd.volume_raycaster import Raycaster
+    vol_h, tf_h, cam_h = _scene(oracle, N=24, R=16)
+    WH = (24, 24)
+    vol_u, tf_u = _user_layout(vol_h, tf_h)
+    rc = Raycaster(vol_u.shape[-3:], WH, tf_h.shape[0], jitter=True, max_samples=4096)
+    cam = T(cam_h)
+    cases = [
+        (vol_u, tf_u, cam),                                               # nothing batched
+        (vol_u, tf_u[None].expand(3, -1, -1).contiguous(), cam),          # batched TF, ONE look_from (expanded inside)
+        (vol_u, tf_u, torch.stack([cam, cam * 0.9, cam * 1.1])),          # batched cameras, shared volume and TF
+        (vol_u.double(), tf_u.double(), cam.double()),                    # everything converted on the way in
+        (vol_u[None].expand(2, -1, -1, -1, -1), tf_u, cam),               # expanded (stride-0) batch of volumes
+    ]
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                                    # the stale-workspace warning would raise
+        for vol_in, tf_in, lf in cases:
+            vol_in = vol_in.clone().requires_grad_(True)
+            tf_in = tf_in.clone().requires_grad_(True)
+            rc(vol_in, tf_in, lf).square().sum().backward()
+            torch.cuda.synchronize()
+            rc(vol_in.detach(), tf_in.detach(), lf)                       # a later call looks at the backward's snapshot
+            torch.cuda.synchronize()
+            st = rc.vr.last_stats
+            assert st is not None and int(st[9]) == 0 and int(st[3]) != 0, st[:12]

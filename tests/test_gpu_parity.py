@@ -531,6 +531,7 @@ def test_backward_does_not_trust_a_workspace_it_did_not_fill(oracle, hiplib):
     assert int(Fn.workspace_stats(ws)[3]) == 0            # the mark word: nobody's
     dv, dt = Fn.march_bwd(vol, tf, cam, e, x, r, n, 4096, 1.0, g, out, workspace=ws)
     torch.cuda.synchronize()
+    assert int(Fn.workspace_stats(ws)[9]) == 0x5A5A5A5A + 1   # counted (the header was garbage: the counter started there)
     ok, err = grad_close(dv.cpu().numpy(), dv_o)
     assert ok, err
     ok, err = grad_close(dt.cpu().numpy(), dt_o)
@@ -554,9 +555,16 @@ def test_backward_does_not_trust_a_workspace_it_did_not_fill(oracle, hiplib):
     ok, err = grad_close(dt.cpu().numpy(), dt_o)
     assert ok, err
 
+    assert int(Fn.workspace_stats(ws)[9]) == 1            # ... and counted, for the host layer's warning
     # (4) and the matching pair still takes the fast path: B2 marches nothing but irregular rays
     out4, _ = Fn.march_fwd(vol, tf, cam, e, x, r, n, 4096, 1.0, workspace=ws)
     dv, dt = Fn.march_bwd(vol, tf, cam, e, x, r, n, 4096, 1.0, g, out4, workspace=ws)
+    assert int(Fn.workspace_stats(ws)[9]) == 0
+    # the camera may be handed over as a fresh copy every call (hosts do `cam.contiguous()` on an expanded look_from):
+    # its address is not part of the fingerprint
+    out5, _ = Fn.march_fwd(vol, tf, cam.clone(), e, x, r, n, 4096, 1.0, workspace=ws)
+    dv, dt = Fn.march_bwd(vol, tf, cam.clone(), e, x, r, n, 4096, 1.0, g, out5, workspace=ws)
+    assert int(Fn.workspace_stats(ws)[9]) == 0
     ok, err = grad_close(dv.cpu().numpy(), dv_o)
     assert ok, err
 
