@@ -152,16 +152,19 @@ class _TerminationHints:
     fixed TF under volume optimisation, OPT.py; the ground-truth TF; every benchmark) lets the host know: the largest alpha
     of a TF tensor is computed once per tensor VERSION (torch bumps `_version` on every in-place write, for every view and
     `.detach()` of the tensor alike), copied to pinned memory asynchronously, and used by later calls once the copy has landed
-    (event.query(), never a wait). A TF seen for the
-    first time, or one that changes every iteration, simply gets no hint. A stale answer (data changed behind the version
-    counter's back) cannot produce a wrong image: the device re-checks and repairs (include/differender_hip.h)."""
+    (event.query(), never a wait). A TF seen for the first time gets no hint; one that is written to between calls gets
+    "no early termination" never, and "early termination" from its last reading (refreshed every few calls). A stale answer
+    (data changed behind the version counter's back) cannot produce a wrong image: the device re-checks and repairs
+    (include/differender_hip.h)."""
+
+    REFRESH_EVERY = 8   # a TF that is written to between calls has its largest alpha re-read on every 8th call at most
 
     def __init__(self, capacity=8):
-        # key -> [tensor, version, state, host value / tensor, event]; state 0 = seen once, 1 = copy in flight, 2 = known.
-        # The key is WHERE the data lives (storage address, offset, shape, strides) and the entry holds a reference to the
-        # tensor, so that the memory cannot be handed to anybody else while the entry exists (a TF is a few KB; at most
-        # `capacity` of them are kept): `tf.detach()` -- a new Python object every call, same storage, same version counter
-        # -- matches; a temporary such as `tf.permute(1, 0).contiguous()` gets another address every call and never does.
+        # key -> entry. The key is WHERE the data lives (storage address, offset, shape, strides) and the entry holds a
+        # reference to the tensor, so that the memory cannot be handed to anybody else while the entry exists (a TF is a few
+        # KB; at most `capacity` of them are kept): `tf.detach()` -- a new Python object every call, same storage, same
+        # version counter -- matches; a temporary such as `tf.permute(1, 0).contiguous()` gets another address every call
+        # and never does.
         self._seen = {}
         self._capacity = capacity
 
@@ -174,35 +177,43 @@ class _TerminationHints:
         for k in [k for k in self._seen if k[0] == base]:
             del self._seen[k]
 
+    def _start_read(self, ent, tf, alpha):
+        host = torch.empty((), dtype=torch.float32, pin_memory=True)
+        with torch.no_grad():
+            host.copy_(torch.nan_to_num(alpha(tf.detach()).float(), nan=float("inf")).max(), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        ent["pending"] = (host, ev, tf._version)
+        ent["since"] = 0
+
     def amax(self, tf, alpha=lambda t: t[..., 3]):
-        """Largest alpha of `tf` (inf if any alpha is NaN), or None while it is not known yet. `alpha` selects the alpha
-        entries ((..., R, 4) layout by default)."""
+        """(value, exact): the largest alpha of `tf` (inf if any alpha is NaN) as last read, and whether that reading is of
+        the tensor's CURRENT version; (None, False) while nothing is known. Never waits for the device."""
         key = self._key(tf)
         ent = self._seen.get(key)
-        if ent is not None and ent[1] != tf._version:
-            ent = None
         if ent is None:
-            self._seen.pop(key, None)
             if len(self._seen) >= self._capacity:
                 self._seen.pop(next(iter(self._seen)))
-            self._seen[key] = [tf.detach(), tf._version, 0, None, None]
-            return None
-        if ent[2] == 0:   # second sighting of this very version: worth three tiny launches
-            host = torch.empty((), dtype=torch.float32, pin_memory=True)
-            with torch.no_grad():
-                host.copy_(torch.nan_to_num(alpha(tf.detach()).float(), nan=float("inf")).max(), non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            ent[2], ent[3], ent[4] = 1, host, ev
-            return None
-        if ent[2] == 1:
-            if not ent[4].query():
-                return None
-            ent[2], ent[3], ent[4] = 2, float(ent[3].item()), None
-        return ent[3]
+            self._seen[key] = {"tensor": tf.detach(), "seen": tf._version, "value": None, "value_version": None,
+                               "pending": None, "since": 0}
+            return None, False
+        if ent["pending"] is not None and ent["pending"][1].query():
+            host, _, ver = ent["pending"]
+            ent["value"], ent["value_version"], ent["pending"] = float(host.item()), ver, None
+        v = tf._version
+        if ent["value_version"] == v:
+            return ent["value"], True
+        ent["since"] += 1
+        if ent["pending"] is None:
+            # an unchanged tensor is read on the second sighting of its version; one that is written to between calls on
+            # every REFRESH_EVERY-th call (its last reading keeps serving the harmless hint meanwhile)
+            if ent["seen"] == v or ent["since"] >= self.REFRESH_EVERY:
+                self._start_read(ent, tf, alpha)
+        ent["seen"] = v
+        return ent["value"], False
 
     def hints(self, tf, vol_shape, sampling_rate, max_samples, mode, alpha=lambda t: t[..., 3]):
-        a = self.amax(tf, alpha)
+        a, exact = self.amax(tf, alpha)
         if a is None:
             return 0
         # may_terminate() of the device (csrc/dr_brick_common.h), in double, with a margin on either side of its 0.02
@@ -217,7 +228,10 @@ class _TerminationHints:
         base = max(1.0 - min(a, 1.0), 0.0)
         op = 1.0 - base ** (1.0 / float(sampling_rate))
         remain = (1.0 - op) ** n_max if op < 1.0 else 0.0
-        if remain > 0.03:   # (the device's threshold is 0.02, evaluated in float: 1.5 x is a wide margin for rounding)
+        # "no ray terminates" only from a reading of the CURRENT version (a wrong one costs a slow repair on the device);
+        # "many rays terminate" also from the last reading of a tensor that has been written to since (OPT.py clamps its TF
+        # in place every iteration): that hint only chooses how finely the pre-pass proceeds
+        if exact and remain > 0.03:   # (the device's threshold is 0.02, evaluated in float: 1.5 x is a wide margin for rounding)
             return N.DR_HINT_NO_EARLY_TERMINATION
         if remain < 1e-4:
             return N.DR_HINT_EARLY_TERMINATION
