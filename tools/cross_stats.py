@@ -21,6 +21,7 @@ for (N, IMG, R, V, sr, mode, noise) in ((256, 256, 128, 8, 8.0, 1, True), (256, 
     st = ws[:2048].view(torch.int32).cpu()
     st64 = ws[:2048].view(torch.int64).cpu()
     r0, r1 = int(st[32]), int(st[33]); w0, w1 = int(st64[18]), int(st64[19])
-    print(f"   exact walk: passes skipped as stagnant {int(st[34])}, passes walked sample by sample {int(st[35])}")
+    print(f"   exact walk: passes skipped as stagnant {int(st[34])}, passes walked sample by sample {int(st[35])}; clock ticks per ray "
+          f"{int(st64[20]) / max(int(st[33]), 1):.0f} (longest {int(st64[21])})")
     print(f"{N}^3 {IMG}^2 x{V} sr={sr} mode={mode}: rays {V*IMG*IMG}, terminated early {int((steps < n).sum())}, resolved by ray_cross {r0} "
           f"(samples walked {w0}, {w0/max(r0,1):.1f}/ray), exact restarts {r1} ({100*r1/max(r0,1):.1f} %, samples walked {w1}, {w1/max(r1,1):.0f}/ray)")
