@@ -34,8 +34,8 @@ namespace dr {
 #ifndef DR_FNT_FWD
 #define DR_FNT_FWD 256
 #endif
-constexpr int FNT_FWD = DR_FNT_FWD;      // threads per workgroup (forward: 30 KB of LDS, 96 VGPRs -> 5 workgroups per CU)
-constexpr int FNT_BWD = DR_FNT_BWD;     // (backward: 66 KB of LDS, 128 VGPRs -> two 8-wave workgroups per CU)
+// DR_FNT_*: threads per workgroup (forward: 30 KB of LDS, 96 VGPRs -> 5 four-wave workgroups per CU; backward with a gradient
+// box: 67 KB of LDS, 128 VGPRs -> two 8-wave workgroups per CU); gathered in FlatCfg below
 #ifndef DR_FEC_FWD
 #define DR_FEC_FWD 256
 #endif
@@ -66,8 +66,7 @@ constexpr int FNT_BWD = DR_FNT_BWD;     // (backward: 66 KB of LDS, 128 VGPRs ->
 #ifndef DR_BWD_UNEVEN
 #define DR_BWD_UNEVEN 7   // backward: candidates dealt to a later wave for every 8 of an earlier one (0: even); 7: -1.1 %, 6: -0.5 %, 5: +2 %
 #endif
-constexpr int FEC_FWD = DR_FEC_FWD;      // ray segments listed per round (<= threads: one candidate per thread)
-constexpr int FEC_BWD = DR_FEC_BWD;      // (backward: the entry table also holds prefix / gradient / output)
+// DR_FEC_*: ray segments listed per round (<= threads: one candidate per thread)
 // The backward w.r.t. the TF only (C3) has no gradient box, 33 KB of LDS instead of 67: FOUR-wave workgroups, four per CU
 // (the same 4 waves per SIMD its 127 VGPRs allow, but from four workgroups in different phases instead of two): 3.22 ms
 // against 3.80 with the 8-wave shape at 512^3 (same device, profiles/r03_ab_experiments.txt); 96 VGPRs for a fifth
@@ -1470,7 +1469,7 @@ static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     // Samples per lane: the cross-lane scan and the chunk bookkeeping are paid once per K*64 samples, but lanes K
     // samples apart share fewer LDS words (more read cycles, more bank conflicts). Measured at 512^3: K = 2 wins up
     // at sampling rate 1 (-3 %), K = 4 from 2 on (-13 % at 2, -16 % at 4 and 8 vs K = 1: samples are closer together); K = 8 loses.
-#define DR_LAUNCH_F1(MODE_, K_) DR_LAUNCH_BOTH(MODE_, false, false, false, false, K_, FNT_FWD)
+#define DR_LAUNCH_F1(MODE_, K_) DR_LAUNCH_BOTH(MODE_, false, false, false, false, K_, (FlatCfg<false, false>::FNT))
     const bool k_hi = a.sr >= 1.75f;
     if (prepass) {
         // The pre-pass runs front to back in G groups of brick layers; after each group the rays that have reached
@@ -1486,9 +1485,9 @@ static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
             // (several bricks per workgroup would quarter the cost of this launch when it is gated off -- 27 us of workgroup
             // exits at 512^3 -- but the looped kernel needs 96 VGPRs instead of 66 and is 3-5 % slower when it runs)
             if (a.mode == DR_MODE_DIFF) {
-                DR_LAUNCH_BOTH(DR_MODE_DIFF, false, false, false, true, DR_ALPHA_K, FNT_FWD)
+                DR_LAUNCH_BOTH(DR_MODE_DIFF, false, false, false, true, DR_ALPHA_K, (FlatCfg<false, false>::FNT))
             } else {
-                DR_LAUNCH_BOTH(DR_MODE_NONDIFF, false, false, false, true, DR_ALPHA_K, FNT_FWD)
+                DR_LAUNCH_BOTH(DR_MODE_NONDIFF, false, false, false, true, DR_ALPHA_K, (FlatCfg<false, false>::FNT))
             }
             if ((e = hipGetLastError()) != hipSuccess) return (int)e;
             const int rc = launch_ray_alpha(pa, stream);
@@ -1535,8 +1534,8 @@ static int flat_bwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     const dim3 grid1(g.NBx * g.NBy * g.NBz, a.n_views);
     hipError_t e = hipSuccess;
     // (the brick records, live flags and work items are the forward's: same inputs, same workspace)
-    if (wv && wt) DR_LAUNCH_BOTH(DR_MODE_DIFF, true, true, true, false, 1, FNT_BWD)
-    else if (wv) DR_LAUNCH_BOTH(DR_MODE_DIFF, true, true, false, false, 1, FNT_BWD)
+    if (wv && wt) DR_LAUNCH_BOTH(DR_MODE_DIFF, true, true, true, false, 1, (FlatCfg<true, true>::FNT))
+    else if (wv) DR_LAUNCH_BOTH(DR_MODE_DIFF, true, true, false, false, 1, (FlatCfg<true, true>::FNT))
     else DR_LAUNCH_BOTH(DR_MODE_DIFF, true, false, true, false, 1, (FlatCfg<true, false>::FNT))
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
     MarchArgs b = a;

@@ -84,14 +84,18 @@ __global__ __launch_bounds__(256) void ray_compose_kernel(BrickParams<VT> P) {
 #ifndef DR_F2_WIDE
 #define DR_F2_WIDE 4   // layers per step of the walk
 #endif
+
             constexpr int FW = DR_F2_WIDE;
             for (int l = 0; l <= l_hi; l += FW) {
                 int cnt[FW];
                 float4 sg[FW];
 #pragma unroll
                 for (int k = 0; k < FW; ++k) cnt[k] = (l + k <= l_hi) ? (int)P.seg_cnt[seg0 + (size_t)(l + k) * NP] : 0;
+                // (the partials are requested together with the counts, not after them: one memory round trip per step instead
+                // of two -- 80.5 -> 73.9 us at 512^2; nearly every layer between a ray's first and last brick holds samples, so
+                // little is read in vain. The kernel moves 330 MB in 74 us: it is HBM-bound, wider steps change nothing.)
 #pragma unroll
-                for (int k = 0; k < FW; ++k) sg[k] = cnt[k] ? P.seg_rgba[seg0 + (size_t)(l + k) * NP] : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int k = 0; k < FW; ++k) sg[k] = (l + k <= l_hi) ? P.seg_rgba[seg0 + (size_t)(l + k) * NP] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int k = 0; k < FW; ++k) {
                     if (cnt[k] == 0) continue;
