@@ -179,10 +179,10 @@ class _TerminationHints:
 
     def _start_read(self, ent, tf, alpha):
         host = torch.empty((), dtype=torch.float32, pin_memory=True)
-        with torch.no_grad():
+        with torch.no_grad(), torch.cuda.device(tf.device):   # (the event must sit on the stream the copy runs on)
             host.copy_(torch.nan_to_num(alpha(tf.detach()).float(), nan=float("inf")).max(), non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
+            ev = torch.cuda.Event()
+            ev.record()
         ent["pending"] = (host, ev, tf._version)
         ent["since"] = 0
 

@@ -136,9 +136,10 @@ class VolumeRaycaster:
         if self._stats_event is None:
             if self._stats_host is None:
                 self._stats_host = torch.empty(32, dtype=torch.int32, pin_memory=True)
-            self._stats_host.copy_(workspace[:128].view(torch.int32), non_blocking=True)
-            self._stats_event = torch.cuda.Event()
-            self._stats_event.record()
+            with torch.cuda.device(workspace.device):   # (the event must sit on the stream the copy runs on)
+                self._stats_host.copy_(workspace[:128].view(torch.int32), non_blocking=True)
+                self._stats_event = torch.cuda.Event()
+                self._stats_event.record()
             self._stats_rays = int(n_rays)
 
     def _field_shape(self, name):

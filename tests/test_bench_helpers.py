@@ -1,0 +1,54 @@
+"""Host-side pieces of bench.py that need no GPU: the byte model of the roofline, the all-reduce cost model, the core count
+of the CPU baseline, and the guard that keeps the live-counter pass from nesting profilers."""
+import importlib.util
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    argv, sys.argv = sys.argv, sys.argv[:1]
+    try:
+        spec.loader.exec_module(mod)
+    finally:
+        sys.argv = argv
+    return mod
+
+
+def test_algorithmic_bytes_follow_the_storage_type():
+    B = _bench()
+    assert B.algorithmic_bytes("f32") == (32.0, 96.0, 32.0)     # 8 corners x 4 B; + 64 B of gradient RMW
+    assert B.algorithmic_bytes("f16") == (16.0, 80.0, 16.0)
+
+
+def test_allreduce_model_matches_the_survey_figures():
+    B = _bench()
+    m = B.allreduce_model(512 * 2 ** 20, 8)                      # ~6.1 ms one link, ~0.9 ms all links
+    assert abs(m["one_link_ring_ms"] - 6.14) < 0.02 and abs(m["all_links_ms"] - 0.877) < 0.005
+    m = B.allreduce_model(4 * 2 ** 30, 8)                        # 1024^3 f32 gradients: ~49 / ~7 ms
+    assert abs(m["one_link_ring_ms"] - 49.1) < 0.2 and abs(m["all_links_ms"] - 7.02) < 0.05
+    assert B.allreduce_model(512 * 2 ** 20, 1) is None and B.allreduce_model(None, 8) is None
+
+
+def test_host_cores_reports_what_the_process_may_use():
+    B = _bench()
+    n, note = B.host_cores()
+    assert 1 <= n <= len(os.sched_getaffinity(0)) and "affinity" in note
+
+
+def test_live_counters_are_not_collected_under_a_profiler(monkeypatch):
+    """bench.py under `rocprofv3 -- python3 bench.py` must not start a rocprofv3 of its own: the child would inherit the
+    profiler's preload, which initialises the GPU before rocprofv3 exec's its target."""
+    B = _bench()
+    assert not B.under_profiler({})
+    assert B.under_profiler({"LD_PRELOAD": "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so"})
+    assert B.under_profiler({"ROCP_TOOL_LIBRARIES": "x"}) and B.under_profiler({"ROCPROF_OUTPUT_PATH": "/tmp"})
+    monkeypatch.setenv("ROCP_TOOL_LIBRARIES", "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so")
+    monkeypatch.setattr(B.shutil, "which", lambda name: "/bin/false")   # "rocprofv3 is there" -- it must not be started
+    started = []
+    monkeypatch.setattr(B.subprocess, "run", lambda *a, **k: started.append(a))
+    res, note = B.measure_traffic_live([])
+    assert res is None and "profiler" in note and not started
