@@ -395,7 +395,8 @@ struct FixScale {
     int shift;   // value = x * 2^shift
     float lim;   // adjoints beyond +-lim = 2^12 * gmax do not go through the box
     double inv;  // 2^-shift
-    int sh;      // wave-uniform, set per pass (fix_wave_scale): addend = cvt(x * 2^(shift - sh)) << sh, 1 <= sh <= 31
+    int sh;      // wave-uniform, set per pass (fix_wave_scale): addend = cvt(x * 2^(shift - sh)) << sh, 1 <= sh <= 24
+    int pw;      // 2^sh
 };
 __device__ __forceinline__ FixScale make_fix_scale(float gmax) {
     if (!(gmax > 0.0f) || !(gmax < 3.0e38f)) gmax = 1.0f;  // all-zero upstream gradient
@@ -406,7 +407,7 @@ __device__ __forceinline__ FixScale make_fix_scale(float gmax) {
     f.shift = DR_FIX_BITS - e;   // gmax * 2^shift < 2^DR_FIX_BITS
     f.lim = ldexpf(1.0f, e + DR_FIX_LIM_BITS);
     f.inv = ldexp(1.0, -f.shift);
-    f.sh = 1;
+    f.sh = 1; f.pw = 2;
     return f;
 }
 // A NaN adjoint (NaN pixel in grad_out, NaN voxel) contributes nothing: the reference lets it poison every voxel and
@@ -426,16 +427,19 @@ __device__ __forceinline__ float fix_wave_scale(float bmax, FixScale &f) {
     // bmax < 2^eb; addends < 2^30 after scaling by 2^(30 - eb): sh = shift - (30 - eb), kept in [1, 31]
     const int eb = (bmax > 0.0f) ? (int)((__float_as_uint(bmax) >> 23) & 0xff) - 126 : -126;  // (a denormal bmax counts as 2^-126)
     int sh = f.shift - 30 + eb;
-    sh = sh < 1 ? 1 : (sh > 31 ? 31 : sh);  // sh > 31 cannot happen below 4 lim (DR_FIX_BITS + DR_FIX_LIM_BITS + 2 - 30 <= 31)
-    f.sh = sh;
+    static_assert(DR_FIX_BITS + DR_FIX_LIM_BITS + 2 - 30 <= 30, "2^sh must fit a positive int32 (fix_add_scaled)");
+    sh = sh < 1 ? 1 : (sh > 30 ? 30 : sh);  // sh > 24 cannot happen below 4 lim (DR_FIX_BITS + DR_FIX_LIM_BITS + 2 - 30)
+    f.sh = sh; f.pw = 1 << sh;
     return __uint_as_float((unsigned int)(127 + f.shift - sh) << 23);  // 2^(shift - sh): the exponent stays within [-119, 119]
 }
 // x already carries the factor 2^(shift - sh) and |x| < 2^31
 __device__ __forceinline__ void fix_add_scaled(unsigned long long *p, float x, const FixScale &f) {
     const int q = cvt_rn_i32(x);
-    const unsigned int lo = (unsigned int)q << f.sh;
-    const int hi = q >> (32 - f.sh);  // arithmetic: the sign extension
-    const unsigned long long v = ((unsigned long long)(unsigned int)hi << 32) | lo;
+    // q << sh as a 64-bit integer: ONE v_mad_i64_i32 with the wave-uniform 2^sh (4.4 issue cycles) instead of a 32-bit left
+    // shift + an arithmetic right shift for the sign-extended high word (4.5 + 2.6)
+    // (spelled in assembly: from C the compiler turns the multiplication by 2^sh back into a sign extension + a 64-bit shift)
+    unsigned long long v, carry_unused;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, 0" : "=v"(v), "=s"(carry_unused) : "v"(q), "s"(f.pw));
 #ifdef DR_ABL_NOATOMIC
     asm volatile("" :: "v"(p), "v"(v));
 #else
