@@ -321,17 +321,20 @@ __device__ __forceinline__ void sample_normal_taps_lds(const float *box, const T
     dz = tri_lds(box, bx + by + t.lzp, t.fx, t.fy, t.fzp) - tri_lds(box, bx + by + t.lzm, t.fx, t.fy, t.fzm);
 }
 
-// Tap coordinates of a sample at (sm.px, sm.py, sm.pz); returns whether the sample's cell lies in this brick.
+// Tap coordinates of a sample at (sm.px, sm.py, sm.pz), in two halves: the centre tap (returns whether the sample's cell
+// lies in this brick), and the six normal taps -- needed only where the sample is lit (forward) or always (backward).
 template <typename VT>
-__device__ __forceinline__ bool sample_coords_at(const VolView<VT> &vol, const BrickCtx &c, Sample &sm, TapCoords &t) {
+__device__ __forceinline__ bool sample_centre_coords_at(const VolView<VT> &vol, const BrickCtx &c, const Sample &sm, TapCoords &t) {
     int x0, y0, z0;
     axis_coord(sm.px, vol.scx, x0, t.fx);
     axis_coord(sm.py, vol.scy, y0, t.fy);
     axis_coord(sm.pz, vol.scz, z0, t.fz);
     t.lx = x0 - c.ox; t.ly = y0 - c.oy; t.lz = z0 - c.oz;
     // the brick's cells are box elements 1 .. BRK along each axis (element 0 is the voxel below the brick)
-    if ((unsigned)(t.lx - 1) >= (unsigned)BRK || (unsigned)(t.ly - 1) >= (unsigned)BRK || (unsigned)(t.lz - 1) >= (unsigned)BRK)
-        return false;
+    return (unsigned)(t.lx - 1) < (unsigned)BRK && (unsigned)(t.ly - 1) < (unsigned)BRK && (unsigned)(t.lz - 1) < (unsigned)BRK;
+}
+template <typename VT>
+__device__ __forceinline__ void sample_normal_coords_at(const VolView<VT> &vol, const BrickCtx &c, const Sample &sm, TapCoords &t) {
     const float delta = 1e-3f;
     int k;
     axis_coord(sm.px + delta, vol.scx, k, t.fxp); t.lxp = k - c.ox;
@@ -340,6 +343,11 @@ __device__ __forceinline__ bool sample_coords_at(const VolView<VT> &vol, const B
     axis_coord(sm.py - delta, vol.scy, k, t.fym); t.lym = k - c.oy;
     axis_coord(sm.pz + delta, vol.scz, k, t.fzp); t.lzp = k - c.oz;
     axis_coord(sm.pz - delta, vol.scz, k, t.fzm); t.lzm = k - c.oz;
+}
+template <typename VT>
+__device__ __forceinline__ bool sample_coords_at(const VolView<VT> &vol, const BrickCtx &c, Sample &sm, TapCoords &t) {
+    if (!sample_centre_coords_at(vol, c, sm, t)) return false;
+    sample_normal_coords_at(vol, c, sm, t);
     return true;
 }
 __device__ __forceinline__ void load_ray(const float *entry, const float *exit_, const float *rays, const int32_t *nsamp,

@@ -1055,7 +1055,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
             if (KS == 1) {
                 if (act) {
                     sample_pos_rcp(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, cam.x, cam.y, cam.z, s, sm.px, sm.py, sm.pz);
-                    valid = sample_coords_at(vol, c, sm, t);
+                    valid = BWD ? sample_coords_at(vol, c, sm, t) : sample_centre_coords_at(vol, c, sm, t);
                 }
                 if (valid) {
                     sm.I = sample_centre_lds(L.box, t);
@@ -1064,6 +1064,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                 const bool lit = !ALPHA && valid && (BWD || (MODE == DR_MODE_NONDIFF ? (sm.a > 1e-3f) : (sm.op != 0.0f)));
                 if (BWD || __any(lit)) {
                     if (lit) {
+                        if (!BWD) sample_normal_coords_at(vol, c, sm, t);
                         sample_normal_taps_lds(L.box, t, dx, dy, dz);
                         shade_from_grad<true>(dx, dy, dz, light, vd, MODE == DR_MODE_DIFF, sm);
                     }
@@ -1090,7 +1091,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                     bool vj = false;
                     if (actj) {
                         sample_pos_rcp(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, cam.x, cam.y, cam.z, s + j, sm.px, sm.py, sm.pz);
-                        vj = sample_coords_at(vol, c, sm, t);
+                        vj = sample_centre_coords_at(vol, c, sm, t);
                     }
                     if (vj) {
                         sm.I = sample_centre_lds(L.box, t);
@@ -1100,6 +1101,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                     Over ej = {0.f, 0.f, 0.f, 0.f};
                     if (__any(lit)) {
                         if (lit) {
+                            sample_normal_coords_at(vol, c, sm, t);  // (not before: transparent stretches never need them)
                             sample_normal_taps_lds(L.box, t, dx, dy, dz);
                             shade_from_grad<true>(dx, dy, dz, light, vd, MODE == DR_MODE_DIFF, sm);
                             ej.c0 = sm.L * sm.r * sm.op; ej.c1 = sm.L * sm.g * sm.op; ej.c2 = sm.L * sm.b * sm.op; ej.a = sm.op;
