@@ -196,17 +196,32 @@ __device__ __forceinline__ float pow_spec(float x, float y) {
     q = q * r + 0.5; q = q * r + 1.0; q = q * r + 1.0;
     return (float)(q * __longlong_as_double((long long)((int)n + 1023) << 52));
 }
+// Correctly rounded square root for x = 0, normal x, NaN or x < 0 (-> NaN): v_sqrt_f32 (1 ulp) and the compiler's own
+// one-ulp correction from the two exact fma residuals -- without the scaling that sqrtf() wraps around it for DENORMAL
+// arguments (9 instead of 17 instructions; three of them per sample at sampling rate 8). 1 - alpha is never denormal:
+// the difference is exact for alpha in [0.5, 1] and then 0 or >= 2^-24, and the nested roots only move towards 1.
+// Checked against the host's sqrtf on every one of the 2^31 non-negative floats (tools/microbench/sqrt_cr_check.hip).
+__device__ __forceinline__ float sqrt_cr(float x) {
+    const float y = __builtin_amdgcn_sqrtf(x);
+    const float ym = __int_as_float(__float_as_int(y) - 1), yp = __int_as_float(__float_as_int(y) + 1);
+    const float rd = fmaf(-ym, y, x), ru = fmaf(-yp, y, x);  // x - (y -+ ulp) y
+    float r = (rd <= 0.0f) ? ym : y;
+    r = (ru > 0.0f) ? yp : r;
+    return r;
+}
 __device__ __forceinline__ float pow_inv_sr(float base, float inv_sr) {
     if (inv_sr == 1.0f) return base;
-    if (inv_sr == 0.5f) return sqrtf(base);
-    if (inv_sr == 0.25f) return sqrtf(sqrtf(base));
-    if (inv_sr == 0.125f) return sqrtf(sqrtf(sqrtf(base)));
-    if (inv_sr == 0.0625f) return sqrtf(sqrtf(sqrtf(sqrtf(base))));
+    if (inv_sr == 0.5f) return sqrt_cr(base);
+    if (inv_sr == 0.25f) return sqrt_cr(sqrt_cr(base));
+    if (inv_sr == 0.125f) return sqrt_cr(sqrt_cr(sqrt_cr(base)));
+    if (inv_sr == 0.0625f) return sqrt_cr(sqrt_cr(sqrt_cr(sqrt_cr(base))));
     return pow_spec(base, inv_sr);
 }
 
 // VR.py:205-219 + 284-285. tf is a [R][4] table (LDS or global). sm.I must be set.
-__device__ __forceinline__ void classify_from_I(const float4 *tf, int R, float tf_len, float inv_sr, Sample &sm) {
+// Two halves: the TF lookup, and the opacity of the sample's alpha at this sampling rate -- at rates other than 1 a
+// power of 10 - 60 instructions that the non-differentiable march only needs where alpha > 1e-3 (VR.py:334).
+__device__ __forceinline__ void tf_lookup_from_I(const float4 *tf, int R, float tf_len, Sample &sm) {
     sm.xtf = sm.I * tf_len;
     low_high_frac(sm.xtf, sm.lo, sm.fr);
     sm.lo = min(sm.lo, R - 1);  // defined-domain guard for I > 1 (reference reads out of bounds)
@@ -214,7 +229,11 @@ __device__ __forceinline__ void classify_from_I(const float4 *tf, int R, float t
     float4 t0 = tf[sm.lo], t1 = tf[sm.hi];
     sm.r = mixf(t0.x, t1.x, sm.fr); sm.g = mixf(t0.y, t1.y, sm.fr);
     sm.b = mixf(t0.z, t1.z, sm.fr); sm.a = mixf(t0.w, t1.w, sm.fr);
-    sm.op = 1.0f - pow_inv_sr(1.0f - sm.a, inv_sr);
+}
+__device__ __forceinline__ float opacity_of_alpha(float a, float inv_sr) { return 1.0f - pow_inv_sr(1.0f - a, inv_sr); }
+__device__ __forceinline__ void classify_from_I(const float4 *tf, int R, float tf_len, float inv_sr, Sample &sm) {
+    tf_lookup_from_I(tf, R, tf_len, sm);
+    sm.op = opacity_of_alpha(sm.a, inv_sr);
 }
 template <typename VT>
 __device__ __forceinline__ void classify(const VolView<VT> &v, const float4 *tf, int R, float tf_len, float inv_sr,

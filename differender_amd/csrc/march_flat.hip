@@ -886,9 +886,17 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                     }
                     if (va) {
                         sa.I = tri_lds(L.box, (x0 - c.ox) * BOX_SX + (y0 - c.oy) * BOX_SY + (z0 - c.oz), fx, fy, fz);
-                        classify_from_I(L.tf, P.R, P.tf_len, P.inv_sr, sa);
-                        if (!(MODE == DR_MODE_NONDIFF && !(sa.a > 1e-3f))) Tl *= 1.0f - sa.op;
+                        tf_lookup_from_I(L.tf, P.R, P.tf_len, sa);
+                        if constexpr (MODE != DR_MODE_NONDIFF) Tl *= 1.0f - opacity_of_alpha(sa.a, P.inv_sr);
                         ++cnt_lane;
+                    }
+                    // the opacity (a power at sampling rates other than 1) only where it counts: the nondiff march skips
+                    // alpha <= 1e-3 (VR.py:334), and transparent stretches are wave-uniform (lanes = consecutive samples)
+                    if constexpr (MODE == DR_MODE_NONDIFF) {
+                        const bool vis = va && sa.a > 1e-3f;
+                        if (__any(vis)) {
+                            if (vis) Tl *= 1.0f - opacity_of_alpha(sa.a, P.inv_sr);
+                        }
                     }
                 }
                 Tl = seg_scan_prod(Tl, lane, sl);
@@ -1095,12 +1103,14 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                     }
                     if (vj) {
                         sm.I = sample_centre_lds(L.box, t);
-                        classify_from_I(L.tf, P.R, P.tf_len, P.inv_sr, sm);
+                        tf_lookup_from_I(L.tf, P.R, P.tf_len, sm);
+                        if (MODE != DR_MODE_NONDIFF) sm.op = opacity_of_alpha(sm.a, P.inv_sr);
                     }
                     const bool lit = vj && (MODE == DR_MODE_NONDIFF ? (sm.a > 1e-3f) : (sm.op != 0.0f));
                     Over ej = {0.f, 0.f, 0.f, 0.f};
                     if (__any(lit)) {
                         if (lit) {
+                            if (MODE == DR_MODE_NONDIFF) sm.op = opacity_of_alpha(sm.a, P.inv_sr);  // (a power: only where lit)
                             sample_normal_coords_at(vol, c, sm, t);  // (not before: transparent stretches never need them)
                             sample_normal_taps_lds(L.box, t, dx, dy, dz);
                             shade_from_grad<true>(dx, dy, dz, light, vd, MODE == DR_MODE_DIFF, sm);

@@ -242,11 +242,24 @@ __global__ __launch_bounds__(256) void ray_cross_kernel(BrickParams<VT> P) {
         const int nmarch = (MODE == DR_MODE_DIFF && rg.n > P.S) ? P.S : rg.n;
         // opacity of sample sl (0 beyond the ray's end; a skipped nondiff sample leaves A unchanged: fma(T, 0, A) == A)
         auto opacity = [&](int sl) -> float {
-            if (sl >= nmarch) return 0.0f;
             Sample sm;
-            sample_pos(rg, cam.x, cam.y, cam.z, sl, sm.px, sm.py, sm.pz);
-            classify(vol, lds_tf, P.R, P.tf_len, P.inv_sr, sm);
-            return (MODE == DR_MODE_NONDIFF && !(sm.a > 1e-3f)) ? 0.0f : sm.op;
+            sm.a = 0.0f;
+            if (sl < nmarch) {
+                sample_pos(rg, cam.x, cam.y, cam.z, sl, sm.px, sm.py, sm.pz);
+                sm.I = tri_sample(vol, sm.px, sm.py, sm.pz);
+                tf_lookup_from_I(lds_tf, P.R, P.tf_len, sm);
+            }
+            // (the power behind the opacity only where a lane needs it: transparent stretches are wave-uniform)
+            float op = 0.0f;
+            if constexpr (MODE == DR_MODE_NONDIFF) {
+                const bool vis = sl < nmarch && sm.a > 1e-3f;
+                if (__any(vis)) {
+                    if (vis) op = opacity_of_alpha(sm.a, P.inv_sr);
+                }
+            } else {
+                if (sl < nmarch) op = opacity_of_alpha(sm.a, P.inv_sr);
+            }
+            return op;
         };
         float A = parked.x, A_prev = A;
         int s = __float_as_int(parked.y);
