@@ -99,6 +99,10 @@ def parse_args(argv=None):
     ap.add_argument("--views", type=int, default=None, help="views per rank per step (one native batched launch; opt: 8)")
     ap.add_argument("--vol-dtype", default="f32", choices=["f32", "f16"], help="volume storage (arithmetic is f32 either way; C5 uses f16)")
     ap.add_argument("--jitter", action="store_true", help="jittered ray starts (C5)")
+    ap.add_argument("--scene", default="blobs", choices=["blobs", "ct"],
+                    help="blobs: the headline's field (no voxel is 0); ct: the same field inside a ball of radius 0.6, exactly "
+                         "0 (air) outside it -- with --tf tf1, whose alpha is 0 below intensity 0.084, three bricks in four hold "
+                         "nothing but transparent samples (a CT-like scene; reported separately)")
     ap.add_argument("--cam", default="orbit", choices=["orbit", "inside"], help="inside: camera inside the volume (every ray starts behind the eye)")
     ap.add_argument("--split", default="views", choices=["views", "rows"],
                     help="N > 1: 'views' = one view per rank per step (weak scaling, the default); 'rows' = ONE view per "
@@ -336,6 +340,11 @@ def main():
     n_max = 2.0 * math.sqrt(3.0) * math.sqrt(3.0) * (N - 1)
     alpha = 3.0 / n_max
     vol = synth_volume_torch(N, dev)
+    if args.scene == "ct":
+        ax = torch.linspace(-1.0, 1.0, N, device=dev)
+        r2 = ax[:, None, None] ** 2 + ax[None, :, None] ** 2 + ax[None, None, :] ** 2
+        vol = torch.where(r2 < 0.36, vol, torch.zeros_like(vol))
+        del r2
     if args.vol_dtype == "f16":
         vol = vol.half()
     tf = bench_tf_torch(R, alpha, dev)
@@ -515,7 +524,7 @@ def main():
                                   (" + all-reduce(d_vol,d_tf)" if world > 1 else ""),
                    "backend": ({"nccl": "RCCL (nccl) over xGMI", "gloo": "gloo REHEARSAL: ranks share the card(s)"}.get(backend, backend)
                                if world > 1 else None),
-                   "passes_per_voxel_step": passes, "kernel_variant": args.variant, "tf": args.tf},
+                   "passes_per_voxel_step": passes, "kernel_variant": args.variant, "tf": args.tf, "scene": args.scene},
         "voxel_steps_per_step": int(vsteps / max(args.steps, 1)),
         "planned_steps_per_step": int(int(planned_steps.item()) / max(args.steps, 1)),  # executed/planned < 1 = early termination
         "ms_per_step_ranks": [round(v, 4) for v in rank_ms],

@@ -934,3 +934,67 @@ def test_module_gradients_are_finite_with_a_nan_pixel(oracle, hiplib):
     v2 = vol_u.detach().clone().requires_grad_(True); t2 = tf_u.detach().clone().requires_grad_(True)
     clean(v2, t2, T(oracle.in_circles(0.5))).sum().backward()
     assert float(vol_u.grad.abs().max()) <= 1.5 * float(v2.grad.abs().max())
+
+
+def _ct_like_scene(N=72, R=64, poison=None):
+    """An object in air: voxels 0 outside a ball, 0.35 .. 0.9 inside; the TF is exactly transparent below intensity 0.3."""
+    ax = np.linspace(-1, 1, N, dtype=np.float32)
+    z, y, x = np.meshgrid(ax, ax, ax, indexing="ij")
+    r = np.sqrt(x * x + y * y + z * z)
+    vol = np.where(r < 0.45, 0.6 + 0.25 * np.sin(9 * x) * np.cos(7 * y) + 0.05 * z, 0.0).astype(np.float32)
+    if poison is not None:   # one voxel far out in the air
+        vol[3, 4, 5] = poison
+    tf = np.zeros((R, 4), np.float32)
+    k = np.arange(R) / (R - 1)
+    tf[:, 0] = 0.5 + 0.5 * np.sin(6 * k); tf[:, 1] = k; tf[:, 2] = 1 - k
+    tf[:, 3] = np.where(k > 0.3, 0.05 + 0.1 * k, 0.0)
+    return vol, tf
+
+
+@pytest.mark.parametrize("mode,sr", [(0, 1.0), (0, 2.0), (1, 4.0)], ids=["diff", "diff_sr2", "nondiff_sr4"])
+def test_object_in_air(oracle, hiplib, mode, sr):
+    """A CT-like scene: most bricks hold nothing but exactly transparent samples (whole passes of the forward take the
+    unlit path, the lazily evaluated opacity and normal-tap coordinates are never needed there), the rays that hit the
+    ball terminate inside it. Same image, step counts and gradients as the oracle, which marches every sample in full."""
+    from differender_amd import functional as Fn
+    vol, tf = _ct_like_scene()
+    cam = oracle.in_circles(0.7)
+    WH = (64, 64)
+    e0, x0, r0, n0 = oracle.ray_setup(cam, *WH, vol.shape, sr=sr)
+    ref, sref = oracle.march_fwd(vol, tf, cam, e0, x0, r0, n0, 1 << 20, sr, mode)
+    vt, tt, ct = T(vol), T(tf), T(cam[None])
+    e, x, r, n = Fn.ray_setup(ct, WH, vol.shape, sr)
+    ws = Fn.alloc_workspace(1, WH, vol.shape, tf.shape[0], dev())
+    out, steps = Fn.march_fwd(vt, tt, ct, e, x, r, n, 1 << 20, sr, mode, workspace=ws)
+    assert int(Fn.workspace_stats(ws)[0]) == 0                  # no ray failed its sample count
+    assert np.array_equal(steps[0].cpu().numpy(), sref)
+    assert np.abs(out[0].cpu().numpy() - ref).max() <= FWD_TOL
+    assert ref[..., 3].max() > 0.5 and (ref[..., 3] == 0).mean() > 0.3   # the ball is there, and so is the air around it
+    if mode == 0:
+        g = np.random.RandomState(3).randn(*WH, 4).astype(np.float32)
+        dv0, dt0 = oracle.march_bwd(vol, tf, cam, e0, x0, r0, n0, 1 << 20, sr, g)
+        dv, dt = Fn.march_bwd(vt, tt, ct, e, x, r, n, 1 << 20, sr, T(g[None]), out, workspace=ws)
+        ok, err = grad_close(dt.cpu().numpy(), dt0); assert ok, f"d_tf rel err {err}"
+        ok, err = grad_close(dv.cpu().numpy(), dv0); assert ok, f"d_vol rel err {err}"
+
+
+@pytest.mark.parametrize("poison", [float("nan"), 5.0, -1.0, 0.31], ids=["nan", "above_one", "negative", "just_visible"])
+def test_object_in_air_with_odd_voxels(oracle, hiplib, poison):
+    """One odd voxel out in the air: a NaN sends its samples to TF entries 0 and 1, one above 1 to the last entry, a negative
+    one clamps to entry 0, and one just inside the visible range must be rendered. (An infinite or > 2^31 / R voxel is outside
+    the oracle's domain: its float -> int conversion is undefined in C.)"""
+    from differender_amd import functional as Fn
+    vol, tf = _ct_like_scene(N=48, poison=poison)
+    cam = oracle.in_circles(2.1)
+    WH = (48, 48)
+    e0, x0, r0, n0 = oracle.ray_setup(cam, *WH, vol.shape, sr=1.0)
+    ref, sref = oracle.march_fwd(vol, tf, cam, e0, x0, r0, n0, 1 << 20, 1.0, 0)
+    vt, tt, ct = T(vol), T(tf), T(cam[None])
+    e, x, r, n = Fn.ray_setup(ct, WH, vol.shape, 1.0)
+    ws = Fn.alloc_workspace(1, WH, vol.shape, tf.shape[0], dev())
+    out, steps = Fn.march_fwd(vt, tt, ct, e, x, r, n, 1 << 20, 1.0, 0, workspace=ws)
+    got = out[0].cpu().numpy()
+    assert np.array_equal(steps[0].cpu().numpy(), sref)
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    fin = ~np.isnan(ref)
+    assert np.abs(got[fin] - ref[fin]).max() <= FWD_TOL
