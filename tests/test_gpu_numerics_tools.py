@@ -1,0 +1,21 @@
+"""Device-side numerics that no rendering test can cover exhaustively: the kernels' own correctly rounded square root
+(dr_device.h sqrt_cr, behind (1 - alpha)^(1/sr) at sampling rates 2, 4, 8, 16 -- DESIGN.md D6) against the host's sqrtf on
+EVERY non-negative float. The checker is a small HIP program built by __graft_entry__.build()."""
+import os
+import re
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+EXE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "microbench", "sqrt_cr_check")
+
+
+def test_sqrt_cr_matches_sqrtf_on_every_float_of_its_contract():
+    if not os.path.exists(EXE):
+        pytest.skip("tools/microbench/sqrt_cr_check not built (python __graft_entry__.py)")
+    env = dict(os.environ, OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "16"))
+    p = subprocess.run([EXE], capture_output=True, text=True, timeout=600, env=env)
+    m = re.search(r"(\d+) arguments; (\d+) mismatches for x = 0 or x >= 2\^-96", p.stdout)
+    assert p.returncode == 0 and m, p.stdout + p.stderr
+    assert int(m.group(1)) == 0x7f800000 + 1 and int(m.group(2)) == 0
