@@ -1274,10 +1274,15 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                             bnd = in_box ? fabsf(I_bar) + (fabsf(gq[0]) + fabsf(gq[1]) + fabsf(gq[2])) : 0.0f;
                         }
                         // block floating point: the pass's addends share the exponent of its largest adjoint
-                        FixScale fw = fs;
-                        const float mul = fix_wave_scale(wave_max_nonneg(bnd), fw);
-                        const float gs[3] = {gq[0] * mul, gq[1] * mul, gq[2] * mul};
-                        scatter_sample<ACC_FIX>(L.dbox, t, in_box, cbase_i, I_bar * mul, gs, fw);
+                        // (a pass none of whose samples has an adjoint -- a stretch of the ray where the TF is transparent and
+                        // flat: opacity 0, alpha slope 0 -- would add twenty zeros per lane: it adds nothing instead)
+                        const float wmax = wave_max_nonneg(bnd);
+                        if (wmax > 0.0f) {  // uniform
+                            FixScale fw = fs;
+                            const float mul = fix_wave_scale(wmax, fw);
+                            const float gs[3] = {gq[0] * mul, gq[1] * mul, gq[2] * mul};
+                            scatter_sample<ACC_FIX>(L.dbox, t, in_box, cbase_i, I_bar * mul, gs, fw);
+                        }
                     }
                 }
             }
