@@ -1443,11 +1443,14 @@ bool brick_path_supported(int VX, int VY, int VZ, int R) {
 #define DR_GRID1 grid1
 #endif
 // one pass over the bricks: the main launch (one workgroup per brick and view) + the overflow items of heavy bricks
+#ifndef DR_ABL_EXTRA_LDS_ALPHA
+#define DR_ABL_EXTRA_LDS_ALPHA 0   // what-if: bytes of unused LDS per workgroup of the alpha pre-pass (fewer workgroups per CU)
+#endif
 #define DR_LAUNCH_BOTH(MODE_, BWD_, VOL_, TF_, ALPHA_, K_, NT_)                                                                       \
     {                                                                                                                                 \
         if ((e = allow_lds(brick_flat_kernel<VT, MODE_, BWD_, VOL_, TF_, ALPHA_, K_>, lds)) != hipSuccess) return (int)e;             \
         if ((e = allow_lds(brick_flat_items_kernel<VT, MODE_, BWD_, VOL_, TF_, ALPHA_, K_>, align16(lds) + ITEM_EXTRA_LDS)) != hipSuccess) return (int)e; \
-        hipLaunchKernelGGL((brick_flat_kernel<VT, MODE_, BWD_, VOL_, TF_, ALPHA_, K_>), DR_GRID1, dim3(NT_), lds, stream, P);         \
+        hipLaunchKernelGGL((brick_flat_kernel<VT, MODE_, BWD_, VOL_, TF_, ALPHA_, K_>), DR_GRID1, dim3(NT_), lds + ((ALPHA_) ? DR_ABL_EXTRA_LDS_ALPHA : 0), stream, P);         \
         hipLaunchKernelGGL((brick_flat_items_kernel<VT, MODE_, BWD_, VOL_, TF_, ALPHA_, K_>), dim3(BWD_ ? (VOL_ ? ITEM_GRID_BWD : 2 * ITEM_GRID_BWD) : ITEM_GRID_FWD), dim3(NT_), align16(lds) + ITEM_EXTRA_LDS, stream, P); \
     }
 
