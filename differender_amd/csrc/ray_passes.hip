@@ -218,6 +218,101 @@ __device__ __forceinline__ float wave_incl_prod(float v) {  // inclusive product
     { const float o = __int_as_float(__builtin_amdgcn_update_dpp(0x3f800000, __float_as_int(v), 0x143, 0xc, 0xf, false)); v *= o; }  // row_bcast:31 -> rows 2, 3
     return v;
 }
+// opacity of sample sl of a ray (0 beyond the ray's end; a skipped nondiff sample leaves A unchanged: fma(T, 0, A) == A).
+// rg may differ from lane to lane (ray_cross_quad_kernel: one ray per 16-lane row).
+template <typename VT, int MODE>
+__device__ __forceinline__ float cross_opacity(const BrickParams<VT> &P, const VolView<VT> &vol, const float4 *lds_tf, const RayGeom &rg,
+                                               f3 cam, int nmarch, int sl) {
+    Sample sm;
+    sm.a = 0.0f;
+    if (sl < nmarch) {
+        sample_pos(rg, cam.x, cam.y, cam.z, sl, sm.px, sm.py, sm.pz);
+        sm.I = tri_sample(vol, sm.px, sm.py, sm.pz);
+        tf_lookup_from_I(lds_tf, P.R, P.tf_len, sm);
+    }
+    // (the power behind the opacity only where a lane needs it: transparent stretches are wave-uniform)
+    float op = 0.0f;
+    if constexpr (MODE == DR_MODE_NONDIFF) {
+        const bool vis = sl < nmarch && sm.a > 1e-3f;
+        if (__any(vis)) {
+            if (vis) op = opacity_of_alpha(sm.a, P.inv_sr);
+        }
+    } else {
+        if (sl < nmarch) op = opacity_of_alpha(sm.a, P.inv_sr);
+    }
+    return op;
+}
+
+// Round 1 of the crossing search: the exact sequential recurrence from the ray's first sample, by ONE WAVE (rg, nmarch
+// wave-uniform), 256 samples' gathers in flight per step. Returns the number of live samples.
+// In sequential f32 arithmetic alpha can STAGNATE just below the threshold: once (1 - A) * op_s is under half
+// an ulp of A, fma(1 - A, op_s, A) returns A again, for every sample whose opacity is no larger (the product
+// is monotone in op_s). These are the rays that get here -- the re-associated alpha crossed, the sequential
+// one does not -- and they then march to their last sample: if even the largest opacity of a pass leaves A
+// unchanged, so do all 64.
+#ifndef DR_CROSS_BATCH
+#define DR_CROSS_BATCH 4   // 64-sample passes whose gathers are in flight together (8 and 16: no faster -- the walk is VALU-bound)
+#endif
+template <typename VT, int MODE>
+__device__ __forceinline__ int cross_exact_walk(const BrickParams<VT> &P, const VolView<VT> &vol, const float4 *lds_tf, const RayGeom &rg,
+                                                f3 cam, int nmarch, int lane) {
+    float A = 0.0f;
+    int s = 0;
+    bool done = false;
+#ifdef DR_CROSS_STATS
+    const long long tx0 = clock64();
+#endif
+    constexpr int CB = DR_CROSS_BATCH;
+    for (int base = 0; base < nmarch && !done; base += 64 * CB) {  // uniform
+        float op4[CB];
+#pragma unroll
+        for (int j = 0; j < CB; ++j) op4[j] = cross_opacity<VT, MODE>(P, vol, lds_tf, rg, cam, nmarch, base + 64 * j + lane);
+#pragma unroll
+        for (int j = 0; j < CB; ++j) {
+            const int cnt = min(64, nmarch - (base + 64 * j));
+            if (cnt <= 0 || done) continue;  // uniform
+            float opmax = op4[j];
+            for (int o = 32; o > 0; o >>= 1) opmax = fmaxf(opmax, __shfl_xor(opmax, o));
+            if (A < 0.99f && fmaf(1.0f - A, opmax, A) == A) {  // uniform
+#ifdef DR_CROSS_STATS
+                if (lane == 0) atomicAdd(&P.stats[ST_TIMING + 18], 1u);
+#endif
+                s += cnt; continue;
+            }
+#ifdef DR_CROSS_STATS
+            if (lane == 0) atomicAdd(&P.stats[ST_TIMING + 19], 1u);
+#endif
+            if (cnt == 64) {
+                // A whole pass without looking at the threshold: alpha never decreases, so if it is still below 0.99
+                // after the 64th sample it was below it before every one of them -- the same 64 roundings as the
+                // checked walk below, as a straight chain of sub + fma (constant lane indices: no scalar hazards, no
+                // branch per sample: ~4 x faster). Only the pass in which the ray crosses is walked with the test.
+                float Ab = A;
+#pragma unroll
+                for (int i = 0; i < 64; ++i)
+                    Ab = fmaf(1.0f - Ab, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(op4[j]), i)), Ab);
+                if (Ab < 0.99f) { A = Ab; s += 64; continue; }  // uniform
+            }
+            for (int i = 0; i < cnt; ++i) {  // uniform
+                if (!(A < 0.99f)) { done = true; break; }
+                const float opi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(op4[j]), i));
+                A = fmaf(1.0f - A, opi, A);
+                ++s;
+            }
+        }
+    }
+#ifdef DR_CROSS_STATS
+    if (lane == 0) {
+        const unsigned long long dt = (unsigned long long)(clock64() - tx0);
+        atomicAdd(reinterpret_cast<unsigned long long *>(P.stats + ST_TIMING + 24), dt);       // ticks in the exact walk, all rays
+        atomicMax(reinterpret_cast<unsigned long long *>(P.stats + ST_TIMING + 26), dt);       // ... the longest one
+        atomicAdd(&P.stats[ST_TIMING + 17], 1u);
+        atomicAdd(reinterpret_cast<unsigned long long *>(P.stats + ST_TIMING + 20) + 1, (unsigned long long)s);
+    }
+#endif
+    return s;
+}
+
 template <typename VT, int MODE>
 __global__ __launch_bounds__(256) void ray_cross_kernel(BrickParams<VT> P) {
     extern __shared__ __attribute__((aligned(16))) float4 lds_tf[];
@@ -240,32 +335,11 @@ __global__ __launch_bounds__(256) void ray_cross_kernel(BrickParams<VT> P) {
         load_ray(P.entry, P.exit_, P.rays, P.nsamp, p, rg);
         if (flag != -1) continue;  // wave-uniform: no crossing to resolve
         const int nmarch = (MODE == DR_MODE_DIFF && rg.n > P.S) ? P.S : rg.n;
-        // opacity of sample sl (0 beyond the ray's end; a skipped nondiff sample leaves A unchanged: fma(T, 0, A) == A)
-        auto opacity = [&](int sl) -> float {
-            Sample sm;
-            sm.a = 0.0f;
-            if (sl < nmarch) {
-                sample_pos(rg, cam.x, cam.y, cam.z, sl, sm.px, sm.py, sm.pz);
-                sm.I = tri_sample(vol, sm.px, sm.py, sm.pz);
-                tf_lookup_from_I(lds_tf, P.R, P.tf_len, sm);
-            }
-            // (the power behind the opacity only where a lane needs it: transparent stretches are wave-uniform)
-            float op = 0.0f;
-            if constexpr (MODE == DR_MODE_NONDIFF) {
-                const bool vis = sl < nmarch && sm.a > 1e-3f;
-                if (__any(vis)) {
-                    if (vis) op = opacity_of_alpha(sm.a, P.inv_sr);
-                }
-            } else {
-                if (sl < nmarch) op = opacity_of_alpha(sm.a, P.inv_sr);
-            }
-            return op;
-        };
         float A = parked.x, A_prev = A;
         int s = __float_as_int(parked.y);
         // ---- round 0: re-associated alphas of 64 samples per pass
         for (int base = s; base < nmarch && A < 0.99f; base += 64) {  // uniform
-            const float op = opacity(base + lane);
+            const float op = cross_opacity<VT, MODE>(P, vol, lds_tf, rg, cam, nmarch, base + lane);
             // alpha after every sample of the pass: A_i = A + (1 - A) (1 - prod_{j <= i} (1 - op_j))
             const float Ai = fmaf(1.0f - A, 1.0f - wave_incl_prod(1.0f - op), A);
             const unsigned long long over = __ballot(!(Ai < 0.99f));
@@ -287,71 +361,94 @@ __global__ __launch_bounds__(256) void ray_cross_kernel(BrickParams<VT> P) {
 #ifdef DR_CROSS_NORESTART
         ambiguous = false;  // (timing experiment only: wrong decisions for ambiguous rays)
 #endif
-        if (ambiguous) {
-            // ---- round 1: the exact sequential recurrence from the first sample, 256 samples' gathers in flight per step.
-            // In sequential f32 arithmetic alpha can STAGNATE just below the threshold: once (1 - A) * op_s is under half
-            // an ulp of A, fma(1 - A, op_s, A) returns A again, for every sample whose opacity is no larger (the product
-            // is monotone in op_s). These are the rays that get here -- the re-associated alpha crossed, the sequential
-            // one does not -- and they then march to their last sample: if even the largest opacity of a pass leaves A
-            // unchanged, so do all 64.
-            A = 0.0f; s = 0;
-            bool done = false;
-#ifdef DR_CROSS_STATS
-            const long long tx0 = clock64();
-#endif
-#ifndef DR_CROSS_BATCH
-#define DR_CROSS_BATCH 4   // 64-sample passes whose gathers are in flight together (8 and 16: no faster -- the walk is VALU-bound)
-#endif
-            constexpr int CB = DR_CROSS_BATCH;
-            for (int base = 0; base < nmarch && !done; base += 64 * CB) {  // uniform
-                float op4[CB];
-#pragma unroll
-                for (int j = 0; j < CB; ++j) op4[j] = opacity(base + 64 * j + lane);
-#pragma unroll
-                for (int j = 0; j < CB; ++j) {
-                    const int cnt = min(64, nmarch - (base + 64 * j));
-                    if (cnt <= 0 || done) continue;  // uniform
-                    float opmax = op4[j];
-                    for (int o = 32; o > 0; o >>= 1) opmax = fmaxf(opmax, __shfl_xor(opmax, o));
-                    if (A < 0.99f && fmaf(1.0f - A, opmax, A) == A) {  // uniform
-#ifdef DR_CROSS_STATS
-                        if (lane == 0) atomicAdd(&P.stats[ST_TIMING + 18], 1u);
-#endif
-                        s += cnt; continue;
-                    }
-#ifdef DR_CROSS_STATS
-                    if (lane == 0) atomicAdd(&P.stats[ST_TIMING + 19], 1u);
-#endif
-                    if (cnt == 64) {
-                        // A whole pass without looking at the threshold: alpha never decreases, so if it is still below 0.99
-                        // after the 64th sample it was below it before every one of them -- the same 64 roundings as the
-                        // checked walk below, as a straight chain of sub + fma (constant lane indices: no scalar hazards, no
-                        // branch per sample: ~4 x faster). Only the pass in which the ray crosses is walked with the test.
-                        float Ab = A;
-#pragma unroll
-                        for (int i = 0; i < 64; ++i)
-                            Ab = fmaf(1.0f - Ab, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(op4[j]), i)), Ab);
-                        if (Ab < 0.99f) { A = Ab; s += 64; continue; }  // uniform
-                    }
-                    for (int i = 0; i < cnt; ++i) {  // uniform
-                        if (!(A < 0.99f)) { done = true; break; }
-                        const float opi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(op4[j]), i));
-                        A = fmaf(1.0f - A, opi, A);
-                        ++s;
-                    }
-                }
-            }
-#ifdef DR_CROSS_STATS
-            if (lane == 0) {
-                const unsigned long long dt = (unsigned long long)(clock64() - tx0);
-                atomicAdd(reinterpret_cast<unsigned long long *>(P.stats + ST_TIMING + 24), dt);       // ticks in the exact walk, all rays
-                atomicMax(reinterpret_cast<unsigned long long *>(P.stats + ST_TIMING + 26), dt);       // ... the longest one
-                atomicAdd(&P.stats[ST_TIMING + 17], 1u);
-                atomicAdd(reinterpret_cast<unsigned long long *>(P.stats + ST_TIMING + 20) + 1, (unsigned long long)s);
-            }
-#endif
-        }
+        if (ambiguous) s = cross_exact_walk<VT, MODE>(P, vol, lds_tf, rg, cam, nmarch, lane);  // ---- round 1
         if (lane == 0) P.ws_steps[p] = s;
+    }
+}
+
+// The same search with FOUR rays per wave, one per 16-lane row: at sampling rates below 2 a crossing segment holds at most
+// ~40 samples (12 cells x sqrt 3 x the rate), and a 64-sample pass per ray leaves two thirds of the lanes without work.
+// Sixteen samples per ray and pass, products within the row (DPP row shifts), the pass's first crossing from the row's 16
+// bits of the ballot. The association of the products differs from the one-ray kernel's (and from the pre-pass's) by
+// rounding, which is what the ambiguity band is for: a ray whose alpha lands within 2e-6 of the threshold is walked
+// exactly (round 1, by the whole wave, one ambiguous ray after the other), so the decision is the oracle's either way.
+__device__ __forceinline__ float row_incl_prod(float v) {  // inclusive product over the lanes of a 16-lane row
+    { const float o = __int_as_float(__builtin_amdgcn_update_dpp(0x3f800000, __float_as_int(v), 0x111, 0xf, 0xf, false)); v *= o; }
+    { const float o = __int_as_float(__builtin_amdgcn_update_dpp(0x3f800000, __float_as_int(v), 0x112, 0xf, 0xf, false)); v *= o; }
+    { const float o = __int_as_float(__builtin_amdgcn_update_dpp(0x3f800000, __float_as_int(v), 0x114, 0xf, 0xf, false)); v *= o; }
+    { const float o = __int_as_float(__builtin_amdgcn_update_dpp(0x3f800000, __float_as_int(v), 0x118, 0xf, 0xf, false)); v *= o; }
+    return v;
+}
+template <typename VT, int MODE>
+__global__ __launch_bounds__(256) void ray_cross_quad_kernel(BrickParams<VT> P) {
+    extern __shared__ __attribute__((aligned(16))) float4 lds_tf[];
+    const int view = blockIdx.y;
+    if (P.vflags[view] == 0u) return;  // uniform: no ray of this view can terminate
+    const float4 *tfg = P.tf + view * P.tf_vs;
+    for (int k = threadIdx.x; k < P.R; k += 256) lds_tf[k] = tfg[k];
+    __syncthreads();
+    const int NP = P.W * P.H;
+    const int lane = threadIdx.x & 63, row = lane >> 4, rl = lane & 15;
+    VolView<VT> vol = P.vol;
+    vol.p += view * P.vol_vs;
+    const f3 cam = make_f3(P.cam[3 * view], P.cam[3 * view + 1], P.cam[3 * view + 2]);
+    for (int pl4 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4; pl4 < NP; pl4 += 16 * (int)gridDim.x) {  // wave-uniform: 4 neighbouring pixels
+        const int pl = pl4 + row;
+        const bool in = pl < NP;
+        const size_t p = (size_t)view * NP + (in ? pl : NP - 1);
+        const int flag = P.ws_steps[p];
+        const float4 parked = reinterpret_cast<const float4 *>(P.out)[p];
+        RayGeom rg;
+        load_ray(P.entry, P.exit_, P.rays, P.nsamp, p, rg);
+        const bool act = in && flag == -1;  // row-uniform
+        const unsigned long long actm = __ballot(act);
+        if (actm == 0ull) continue;  // wave-uniform: none of the four rays crosses
+        const int nmarch = (MODE == DR_MODE_DIFF && rg.n > P.S) ? P.S : rg.n;
+        float A = parked.x, A_prev = A;
+        int s = __float_as_int(parked.y);
+        bool open = act;  // the row is still looking for its crossing
+        // ---- round 0: re-associated alphas of 16 samples per ray and pass
+        while (true) {
+            const bool go = open && s < nmarch && A < 0.99f;  // row-uniform
+            if (!__any(go)) break;                            // wave-uniform
+            const float op = cross_opacity<VT, MODE>(P, vol, lds_tf, rg, cam, go ? nmarch : 0, s + rl);
+            const float Ai = fmaf(1.0f - A, 1.0f - row_incl_prod(1.0f - op), A);
+            const unsigned long long over = __ballot(go && !(Ai < 0.99f));
+            const unsigned int m = (unsigned int)(over >> (16 * row)) & 0xffffu;
+            const int ix = m ? __ffs((int)m) - 1 : 15;   // first sample of the row at or above the threshold (15: none -- the row's last)
+            const float a_ix = __shfl(Ai, 16 * row + ix);
+            const float a_before = __shfl(Ai, 16 * row + max(ix - 1, 0));
+            if (go) {
+                if (m == 0u) { A_prev = A = a_ix; s += min(16, nmarch - s); }
+                else { A_prev = ix > 0 ? a_before : A; A = a_ix; s += ix + 1; open = false; }
+            }
+        }
+        // decided at A (>= 0.99, or the ray ran out of samples) with A_prev (< 0.99) before it
+        bool ambiguous = act && (fabsf(A - 0.99f) < 2e-6f || fabsf(A_prev - 0.99f) < 2e-6f);
+#ifdef DR_CROSS_STATS
+        if (act && rl == 0) {
+            atomicAdd(&P.stats[ST_TIMING + 16], 1u);
+            atomicAdd(reinterpret_cast<unsigned long long *>(P.stats + ST_TIMING + 20), (unsigned long long)(s - __float_as_int(parked.y)));
+        }
+#endif
+#ifdef DR_CROSS_NORESTART
+        ambiguous = false;
+#endif
+        const unsigned long long ambm = __ballot(ambiguous);
+        if (ambm != 0ull) {  // wave-uniform, rare
+            for (int r = 0; r < 4; ++r) {
+                if (!((ambm >> (16 * r)) & 1ull)) continue;  // uniform
+                // ---- round 1 for the ray of row r: its geometry to every lane, then the one-ray walk by the whole wave
+                RayGeom ru;
+                ru.entry = __shfl(rg.entry, 16 * r); ru.exit_ = __shfl(rg.exit_, 16 * r);
+                ru.vx = __shfl(rg.vx, 16 * r); ru.vy = __shfl(rg.vy, 16 * r); ru.vz = __shfl(rg.vz, 16 * r);
+                ru.n = __shfl(rg.n, 16 * r); ru.t0 = __shfl(rg.t0, 16 * r); ru.inv_nm1 = 0.0f;
+                const int nm_u = __shfl(nmarch, 16 * r);
+                const int s_u = cross_exact_walk<VT, MODE>(P, vol, lds_tf, ru, cam, nm_u, lane);
+                if (row == r) s = s_u;
+            }
+        }
+        if (act && rl == 0) P.ws_steps[p] = s;
     }
 }
 
@@ -391,11 +488,19 @@ static int ray_alpha_dispatch(const MarchArgs &a, hipStream_t stream, bool cross
     BrickParams<VT> P = make_brick_params<VT>(a, w);
     const dim3 grid2((NP + 255) / 256, a.n_views), grid3((NP + 3) / 4 < 16384 ? (NP + 3) / 4 : 16384, a.n_views);
     const size_t lds3 = (size_t)a.R * 16;
+    // below sampling rate 2 a crossing segment is short: four rays per wave (ray_cross_quad_kernel)
+#ifndef DR_CROSS_QUAD_BELOW
+#define DR_CROSS_QUAD_BELOW 2.0f
+#endif
+    const bool quad = a.sr < DR_CROSS_QUAD_BELOW;
+    const dim3 grid3q((NP + 15) / 16 < 16384 ? (NP + 15) / 16 : 16384, a.n_views);
     if (a.mode == DR_MODE_DIFF) {
         if (!cross) hipLaunchKernelGGL((ray_alpha_kernel<VT, DR_MODE_DIFF>), grid2, dim3(256), 0, stream, P);
+        else if (quad) hipLaunchKernelGGL((ray_cross_quad_kernel<VT, DR_MODE_DIFF>), grid3q, dim3(256), lds3, stream, P);
         else hipLaunchKernelGGL((ray_cross_kernel<VT, DR_MODE_DIFF>), grid3, dim3(256), lds3, stream, P);
     } else {
         if (!cross) hipLaunchKernelGGL((ray_alpha_kernel<VT, DR_MODE_NONDIFF>), grid2, dim3(256), 0, stream, P);
+        else if (quad) hipLaunchKernelGGL((ray_cross_quad_kernel<VT, DR_MODE_NONDIFF>), grid3q, dim3(256), lds3, stream, P);
         else hipLaunchKernelGGL((ray_cross_kernel<VT, DR_MODE_NONDIFF>), grid3, dim3(256), lds3, stream, P);
     }
     return (int)hipGetLastError();

@@ -214,8 +214,32 @@ def run_case(c):
                     bv, bt = Fn.march_bwd(vol, tf, cam, e, x, r, n, S, sr, T(g), out, True, True, variant=1)
                     base = {"d_vol": bv.float().cpu().numpy(), "d_tf": bt.cpu().numpy()}
                 e_base = float(np.abs(base[name] - ref).max()) / scale
-                if not err <= 3.0 * e_base + 1e-4:
-                    fails.append(f"{name} error {err:.3e} of max {scale:.3e} (baseline kernels: {e_base:.3e})")
+                ok = err <= 3.0 * e_base + 1e-4
+                e64 = None
+                if not ok:
+                    # One run of the baseline kernels is a noisy gauge (their own distance from the oracle moves by 8 x from run
+                    # to run on such cases). The conditioning itself can be measured: the same backward in float64. Where the
+                    # f32 oracle is more than 1 % of the maximum away from it, two f32 evaluations in different summation orders
+                    # cannot be asked to agree to 1e-4: the fast path may be 1 % of THAT distance away (still 100 x closer to
+                    # the f32 oracle than the f32 oracle is to the exact result).
+                    if "_ref64" not in c:
+                        f8 = np.float64
+                        dv64 = np.zeros(src.shape, f8); dt64 = np.zeros(tf_h_dev.shape, f8)
+                        for v in range(c["n_views"]):
+                            a, b = O.march_bwd(vol_v[v].astype(f8), tf_v[v].astype(f8), cam_h[v].astype(f8), eh[v].astype(f8),
+                                               xh[v].astype(f8), rh[v].astype(f8), nh[v], S, sr, g[v].astype(f8))
+                            if batched:
+                                dv64[v] = a; dt64[v] = b
+                            else:
+                                dv64 += a; dt64 += b
+                        c["_ref64"] = {"d_vol": dv64, "d_tf": dt64}
+                    r64 = c["_ref64"][name]
+                    if np.isfinite(r64).all():
+                        e64 = float(np.abs(ref - r64).max()) / scale
+                        ok = e64 > 1e-2 and err <= 1e-2 * e64
+                if not ok:
+                    fails.append(f"{name} error {err:.3e} of max {scale:.3e} (baseline kernels: {e_base:.3e}"
+                                 + (f", f32 oracle vs f64: {e64:.3e})" if e64 is not None else ")"))
                 else:
                     c["_illcond"] = True
     return fails
