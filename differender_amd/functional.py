@@ -6,6 +6,7 @@ current torch stream. Volume tensors live in the reference's field index space (
 permuted view of VR.py:566,571 is consumed without a copy.
 """
 import math
+import warnings
 
 import numpy as np
 import torch
@@ -155,9 +156,16 @@ class _TerminationHints:
     (event.query(), never a wait). A TF seen for the first time gets no hint; one that is written to between calls gets
     "no early termination" never, and "early termination" from its last reading (refreshed every few calls). A stale answer
     (data changed behind the version counter's back) cannot produce a wrong image: the device re-checks and repairs
-    (include/differender_hip.h)."""
+    (include/differender_hip.h).
 
-    REFRESH_EVERY = 8   # a TF that is written to between calls has its largest alpha re-read on every 8th call at most
+    Writes the version counter does NOT see (`tf.data.add_()`, a raw-pointer write: `_version` stays put) would leave a
+    reading "exact" for ever, and a TF whose alphas grow under such updates would keep getting "no early termination" -- which
+    the device repairs correctly, but by marching every ray of the view with the per-ray kernels (10-40 x slower). Two
+    safeguards: the largest alpha is re-read every REFRESH_EVERY-th call even when the version has not moved, and the device's
+    own verdict feeds back -- when a workspace header reports a wrong hint (word 8, `report_wrong_hint`), every cached TF
+    loses the right to that hint for good (a wrong "no termination" is the only hint that costs anything)."""
+
+    REFRESH_EVERY = 8   # the largest alpha of a TF is re-read on every 8th call at most (whether or not its version moved)
 
     def __init__(self, capacity=8):
         # key -> entry. The key is WHERE the data lives (storage address, offset, shape, strides) and the entry holds a
@@ -167,6 +175,18 @@ class _TerminationHints:
         # and never does.
         self._seen = {}
         self._capacity = capacity
+        self._distrust_all = False   # a wrong hint was reported before any entry could be blamed
+
+    def report_wrong_hint(self):
+        """The device found DR_HINT_NO_EARLY_TERMINATION wrong for some view (workspace header word 8): whatever TF that
+        was, its data moved behind the version counter's back. No cached TF gets that hint again."""
+        warnings.warn("differender_amd: the hint DR_HINT_NO_EARLY_TERMINATION (derived from the transfer function's largest "
+                      "alpha) was wrong for a recent render -- the TF was written to without torch's version counter seeing "
+                      "it (`tf.data`, a raw pointer). The device repaired the render (every ray marched one by one: slow); "
+                      "the hint is withheld from now on.", RuntimeWarning, stacklevel=4)
+        self._distrust_all = True
+        for ent in self._seen.values():
+            ent["no_noterm"] = True
 
     @staticmethod
     def _key(tf):
@@ -195,15 +215,18 @@ class _TerminationHints:
             if len(self._seen) >= self._capacity:
                 self._seen.pop(next(iter(self._seen)))
             self._seen[key] = {"tensor": tf.detach(), "seen": tf._version, "value": None, "value_version": None,
-                               "pending": None, "since": 0}
+                               "pending": None, "since": 0, "no_noterm": self._distrust_all}
             return None, False
         if ent["pending"] is not None and ent["pending"][1].query():
             host, _, ver = ent["pending"]
             ent["value"], ent["value_version"], ent["pending"] = float(host.item()), ver, None
         v = tf._version
-        if ent["value_version"] == v:
-            return ent["value"], True
         ent["since"] += 1
+        if ent["value_version"] == v:
+            # (re-read now and then all the same: `tf.data` writes do not bump the version)
+            if ent["pending"] is None and ent["since"] >= self.REFRESH_EVERY:
+                self._start_read(ent, tf, alpha)
+            return ent["value"], not ent["no_noterm"]
         if ent["pending"] is None:
             # an unchanged tensor is read on the second sighting of its version; one that is written to between calls on
             # every REFRESH_EVERY-th call (its last reading keeps serving the harmless hint meanwhile)

@@ -121,6 +121,8 @@ class VolumeRaycaster:
         if self._stats_event is not None and self._stats_event.query():
             self.last_stats = self._stats_host.clone()
             slow = int(self.last_stats[2])
+            if int(self.last_stats[8]):   # the device found a "no early termination" hint wrong: never give it again
+                F._hints.report_wrong_hint()
             if int(self.last_stats[9]) and not self._warned_stale:
                 self._warned_stale = True
                 warnings.warn("differender_amd: a backward pass did not find its forward's coarse tape in the workspace it "

@@ -67,17 +67,24 @@ def test_hip_matches_autograd(hiplib, path, variant):
     e, x, r, n = T(d["entry"][None]), T(d["exit"][None]), T(d["rays"][None]), T(d["n"][None], np.int32)
     ws = F.alloc_workspace(1, d["n"].shape, d["vol"].shape, d["tf"].shape[0], dev) if variant == 0 else None
     out, steps = F.march_fwd(vol, tf, cam, e, x, r, n, S, sr, variant=variant, workspace=ws)
+    from oracle import oracle as O
+    f4 = np.float32
+    args32 = (d["vol"].astype(f4), d["tf"].astype(f4), d["cam"].astype(f4), d["entry"].astype(f4), d["exit"].astype(f4),
+              d["rays"].astype(f4), d["n"])
+    # parity proper, forward: the f32 oracle on the fixture's inputs -- sample counts identical, every pixel within 1e-5
+    out32, steps32 = O.march_fwd(*args32, S, sr, 0)
+    assert np.array_equal(steps[0].cpu().numpy(), steps32), int((steps[0].cpu().numpy() != steps32).sum())
+    assert np.abs(out[0].cpu().numpy() - out32).max() <= 1e-5
+    # The slack below is for the FIXTURE only: its vectors are float64, and a float32 evaluation (oracle and kernels alike) may
+    # take a termination decision one sample earlier or later than float64 does; single-sample rays (0/0 position,
+    # VR.py:279-280) are not in the autograd program at all. Those rays are taken out of the f64 comparison, nothing else.
     ok = d["n"] != 1
-    same = (steps[0].cpu().numpy() == d["steps"]) | ~ok      # f32 inputs may move a termination decision by one sample
+    same = (steps32 == d["steps"]) | ~ok
     assert same.mean() > 0.98
     assert np.abs(out[0].cpu().numpy() - d["rgba"]).max(-1)[same & ok].max() <= 1e-5
     g = d["grad_out"].copy(); g[~same] = 0.0
     dv, dt = F.march_bwd(vol, tf, cam, e, x, r, n, S, sr, T(g[None]), out, variant=variant, workspace=ws)
     dv, dt = dv.cpu().numpy(), dt.cpu().numpy()
-    from oracle import oracle as O
-    f4 = np.float32
-    args32 = (d["vol"].astype(f4), d["tf"].astype(f4), d["cam"].astype(f4), d["entry"].astype(f4), d["exit"].astype(f4),
-              d["rays"].astype(f4), d["n"])
     dv32, dt32 = O.march_bwd(*args32, S, sr, g.astype(f4))
     # parity proper: the f32 oracle on the fixture's inputs
     assert np.abs(dv - dv32).max() <= 1e-4 * np.abs(dv32).max()

@@ -77,6 +77,47 @@ def test_patch_parity_with_oracle(scene, oracle):
 
 
 @pytest.mark.parametrize("tfname", ["bench", "tf1"])
+def test_whole_view_parity_with_oracle(scene, oracle, tfname):
+    """The ENTIRE 512^2 view of the headline configuration against the CPU oracle (OpenMP on the box's cores, ~20 s): sample
+    counts identical for every ray, RGBA within 1e-5 on every pixel, all 1.3e8 voxels of d_volume and every texel of d_tf
+    within 1e-4 of the tensor's maximum (north_star's bars) -- once with the bench TF (no ray terminates), once with the
+    reference's tf1 preset (most rays terminate early: alpha pre-pass, ray_cross_quad_kernel, live-sample backward)."""
+    import bench
+    F = scene["F"]
+    cores, _ = bench.host_cores()
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    try:
+        import ctypes
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)
+    except OSError:
+        pass
+    tf = scene["tf"]
+    if tfname == "tf1":
+        from differender_amd.utils import get_tf
+        tf = get_tf("tf1", R).t().contiguous().to(scene["dev"])
+    e, x, r, n = (t[0].cpu().numpy() for t in scene["rays"])
+    vol_h = scene["vol"].cpu().numpy(); tf_h = tf.cpu().numpy(); cam_h = scene["cam"][0].cpu().numpy()
+    out, steps, ws = _fwd(scene, 0, tf=tf)
+    assert int(F.workspace_stats(ws)[0]) == 0, "rays fell back to individual marching"
+    ref, st = oracle.march_fwd(vol_h, tf_h, cam_h, e, x, r, n, 1 << 20, 1.0, 0)
+    assert np.array_equal(steps[0].cpu().numpy(), st), int((steps[0].cpu().numpy() != st).sum())
+    if tfname == "tf1":
+        assert (st < n).mean() > 0.5          # early termination is what this case is about
+    else:
+        assert np.array_equal(st, n)
+    assert np.abs(out[0].cpu().numpy() - ref).max() <= 1e-5
+    g = torch.randn(out.shape, generator=torch.Generator().manual_seed(23))
+    dv, dt = F.march_bwd(scene["vol"], tf, scene["cam"], *scene["rays"], 1 << 20, 1.0, g.to(scene["dev"]), out, workspace=ws)
+    assert int(F.workspace_stats(ws)[9]) == 0, "the backward did not recognise its forward's workspace"
+    dv_ref, dt_ref = oracle.march_bwd(vol_h, tf_h, cam_h, e, x, r, n, 1 << 20, 1.0, g[0].numpy())
+    dv_h = dv.cpu().numpy(); del dv
+    err_v = np.abs(dv_h - dv_ref).max() / np.abs(dv_ref).max()
+    err_t = np.abs(dt.cpu().numpy() - dt_ref).max() / np.abs(dt_ref).max()
+    print(f"whole view [{tfname}]: {int(st.sum())} voxel-steps, d_vol rel err {err_v:.2e} over {dv_ref.size} voxels, d_tf rel err {err_t:.2e}")
+    assert err_v <= 1e-4 and err_t <= 1e-4
+
+
+@pytest.mark.parametrize("tfname", ["bench", "tf1"])
 def test_whole_gradient_tensor_matches_sequential_kernels(scene, tfname):
     """EVERY voxel of d_volume (1.3e8) and every texel of d_tf, a full-image random upstream gradient: the fast path against
     the sequential kernels, which are the oracle's arithmetic twin (the oracle itself is too slow for the whole image; the

@@ -110,12 +110,9 @@ def test_forward_parity_early_termination(oracle, F):
     tf[:, 3] = np.linspace(0.0, 0.4, 128)
     ref, sref, out, steps, (e0, x0, r0, n0), _ = _fwd_both(oracle, F, vol, tf, cam, (64, 64))
     assert (sref < n0)[n0 > 40].mean() > 0.3, "scene must exercise early termination"
-    # a ray whose alpha lands within rounding of 0.99 may legitimately take one sample more or fewer
-    diff = np.abs(out - ref).max(-1)
-    same = steps == sref
-    assert same.mean() > 0.995
-    assert diff[same].max() <= FWD_TOL
-    assert diff.max() <= 2e-3
+    # termination decisions are the oracle's (a decision within rounding of 0.99 is re-taken sequentially)
+    assert np.array_equal(steps, sref), int((steps != sref).sum())
+    assert np.abs(out - ref).max() <= FWD_TOL
 
 
 def test_forward_max_samples_and_rect(oracle, F):
@@ -187,8 +184,8 @@ def test_backward_parity_early_termination(oracle, F):
     vol, tf, cam = scene(oracle, N=40, tf="peaks", R=64, cam_i=1.1)
     tf[:, 3] = np.linspace(0.0, 0.4, 64)
     dv0, dt0, dv, dt = _bwd_both(oracle, F, vol, tf, cam, (48, 48))
-    ok, err = grad_close(dt, dt0, 5e-4); assert ok, f"d_tf rel err {err}"
-    ok, err = grad_close(dv, dv0, 5e-4); assert ok, f"d_vol rel err {err}"
+    ok, err = grad_close(dt, dt0); assert ok, f"d_tf rel err {err}"
+    ok, err = grad_close(dv, dv0); assert ok, f"d_vol rel err {err}"
 
 
 def test_backward_selective_outputs(oracle, F):
@@ -376,15 +373,13 @@ def test_unusual_cameras(oracle, F, cam):
         assert int(st[0]) == 0, "rays failed the sample-count check"
         assert int(st[2]) == int((n0 == 1).sum()), "only single-sample rays may take the per-ray fallback"
     o = out[0].cpu().numpy()
-    same = steps[0].cpu().numpy() == sref
-    assert same.mean() > 0.99
-    assert np.abs(o - ref).max(-1)[same].max() <= FWD_TOL
+    assert np.array_equal(steps[0].cpu().numpy(), sref), int((steps[0].cpu().numpy() != sref).sum())
+    assert np.abs(o - ref).max() <= FWD_TOL
     g = np.random.RandomState(4).randn(*WH, 4).astype(np.float32)
-    g[~same] = 0.0
     dv0, dt0 = oracle.march_bwd(vol, tf, cam, e0, x0, r0, n0, 1 << 20, 1.0, g)
     dv, dt = F.march_bwd(T(vol), T(tf), T(cam[None]), e, x, r, n, 1 << 20, 1.0, T(g[None]), out)
-    ok, err = grad_close(dv.cpu().numpy(), dv0, 2e-4); assert ok, err
-    ok, err = grad_close(dt.cpu().numpy(), dt0, 2e-4); assert ok, err
+    ok, err = grad_close(dv.cpu().numpy(), dv0); assert ok, err
+    ok, err = grad_close(dt.cpu().numpy(), dt0); assert ok, err
 
 
 @pytest.mark.parametrize("mode,sr", [(0, 1.0), (1, 4.0)], ids=["diff", "nondiff_sr4"])
@@ -398,9 +393,8 @@ def test_camera_inside_with_early_termination(oracle, F, mode, sr):
     ref, sref, out, steps, (e0, x0, r0, n0), _ = _fwd_both(oracle, F, vol, tf, cam, WH, sr=sr, mode=mode)
     assert (e0[n0 > 0] < 0).all(), "every ray of a camera inside the box starts at negative t"
     assert (sref < n0)[n0 > 40].mean() > 0.3
-    same = steps == sref
-    assert same.mean() > 0.995
-    assert np.abs(out - ref).max(-1)[same].max() <= FWD_TOL
+    assert np.array_equal(steps, sref), int((steps != sref).sum())
+    assert np.abs(out - ref).max() <= FWD_TOL
 
 
 @pytest.mark.parametrize("vshape,WH,R", [((2, 2, 2), (8, 8), 2), ((5, 7, 3), (3, 5), 1), ((13, 12, 14), (1, 1), 4),
@@ -453,10 +447,8 @@ def test_high_sampling_rate_with_termination(oracle, F, mode):
     WH = (96, 80)
     ref, sref, out, steps, (e0, x0, r0, n0), _ = _fwd_both(oracle, F, vol, tf, cam, WH, sr=8.0, mode=mode)
     assert n0.max() > 1500 and (sref < n0)[n0 > 100].mean() > 0.5
-    same = steps == sref
-    assert same.mean() > 0.995
-    assert np.abs(out - ref).max(-1)[same].max() <= FWD_TOL
-    assert np.abs(out - ref).max() <= 2e-3
+    assert np.array_equal(steps, sref), int((steps != sref).sum())
+    assert np.abs(out - ref).max() <= FWD_TOL
 
 
 def test_huge_strides_take_the_64bit_path(oracle, hiplib):
@@ -694,6 +686,31 @@ def test_automatic_hints_follow_the_tensor_not_its_address(oracle, hiplib):
     assert H.hints(tf3.detach(), *args) == N.DR_HINT_NO_EARLY_TERMINATION
     tf3.mul_(0.5)                                      # a write through the base is seen by every view
     assert H.hints(tf3.detach(), *args) == 0
+    # writes torch's version counter does NOT see (`tf.data`, raw pointers): the reading is refreshed every REFRESH_EVERY-th
+    # call all the same, so a stale "no termination" dies out by itself ...
+    tf4 = T(tf_h)
+    for k in range(3):
+        H.hints(tf4, *args); torch.cuda.synchronize()
+    assert H.hints(tf4, *args) == N.DR_HINT_NO_EARLY_TERMINATION
+    v0 = tf4._version
+    tf4.data[:, 3] = 0.9
+    assert tf4._version == v0
+    got = []
+    for k in range(H.REFRESH_EVERY + 3):
+        got.append(H.hints(tf4, *args)); torch.cuda.synchronize()
+    assert got[-1] == N.DR_HINT_EARLY_TERMINATION, got
+    # ... and the device's verdict (workspace header word 8, fed back by VolumeRaycaster._watch_workspace) withdraws it for good
+    tf5 = T(tf_h)
+    for k in range(3):
+        H.hints(tf5, *args); torch.cuda.synchronize()
+    assert H.hints(tf5, *args) == N.DR_HINT_NO_EARLY_TERMINATION
+    with pytest.warns(RuntimeWarning, match="DR_HINT_NO_EARLY_TERMINATION"):
+        H.report_wrong_hint()
+    for k in range(4):
+        assert H.hints(tf5, *args) == 0; torch.cuda.synchronize()
+    tf6 = T(tf_h)                                      # a tensor first seen afterwards inherits the distrust
+    for k in range(4):
+        assert H.hints(tf6, *args) == 0; torch.cuda.synchronize()
     # and through march_fwd the automatic hint reproduces the unhinted image bit for bit
     tf2 = T(tf_h)
     outs = []
