@@ -193,10 +193,17 @@ def under_profiler(env=None):
     return any(k.startswith(PROFILER_ENV_PREFIXES) for k in env)
 
 
+# One rocprofv3 pass per tuple (MI355X guide, "rocprofv3 PMC slots": TCC has 4 slots -- FETCH_SIZE costs 3, WRITE_SIZE 2, so
+# they cannot share a pass; SQ has 8 slots, GRBM 2 of its own). Counter passes run with --kernel-trace only.
+PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",),
+              ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_LDS_BANK_CONFLICT",
+               "SQ_LDS_IDX_ACTIVE", "SQ_WAVES", "GRBM_GUI_ACTIVE"))
+
+
 def measure_traffic_live(argv_workload):
-    """roofline.traffic, measured in THIS job: rocprofv3 --pmc around short child runs of the same command, FETCH_SIZE
-    and WRITE_SIZE in separate passes (the TCC block has 4 slots: 3 + 2 do not fit, MI355X guide "rocprofv3 PMC slots"),
-    --kernel-trace only. Returns ({kernel: {"FETCH_SIZE": KB, "WRITE_SIZE": KB, "launches": n}}, note)."""
+    """roofline.traffic and roofline_valu, measured in THIS job: rocprofv3 --pmc around short child runs of the same
+    command, one pass per entry of PMC_PASSES, --kernel-trace only.
+    Returns ({kernel: {counter: average per launch, "launches": n}}, note)."""
     exe = shutil.which("rocprofv3")
     if exe is None:
         return None, "rocprofv3 not found"
@@ -213,31 +220,91 @@ def measure_traffic_live(argv_workload):
             env.pop(k, None)
     if "rocprof" in env.get("LD_PRELOAD", "").lower():
         env.pop("LD_PRELOAD", None)
+    failed = []
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = os.path.join(work, counter)
-            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--",
+        for counters in PMC_PASSES:
+            out = os.path.join(work, counters[0])
+            cmd = [exe, "--pmc", *counters, "--kernel-trace", "--output-format", "csv", "-d", out, "--",
                    sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
                    "--pmc", "off"] + argv_workload
             p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=420)
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             if p.returncode != 0 or not files:
-                return None, f"rocprofv3 --pmc {counter} failed (rc {p.returncode})"
+                if counters[0] in ("FETCH_SIZE", "WRITE_SIZE"):
+                    return None, f"rocprofv3 --pmc {counters[0]} failed (rc {p.returncode})"
+                failed.append(counters[0])   # the instruction counters are an extra: the traffic figures stand without them
+                continue
             agg, cnt = {}, {}
             for row in csv.DictReader(open(files[0])):
-                if "dr::" not in row["Kernel_Name"] or row["Counter_Name"] != counter:
+                if "dr::" not in row["Kernel_Name"] or row["Counter_Name"] not in counters:
                     continue
-                k = row["Kernel_Name"].split("(")[0].replace("void ", "")
+                k = (row["Kernel_Name"].split("(")[0].replace("void ", ""), row["Counter_Name"])
                 agg[k] = agg.get(k, 0.0) + float(row["Counter_Value"])
                 cnt[k] = cnt.get(k, 0) + 1
-            for k in agg:
-                res.setdefault(k, {})[counter] = agg[k] / cnt[k]
-                res[k]["launches"] = cnt[k]
+            for (k, c) in agg:
+                res.setdefault(k, {})[c] = agg[(k, c)] / cnt[(k, c)]
+                res[k]["launches"] = cnt[(k, c)]
     except (subprocess.TimeoutExpired, OSError) as ex:
         return None, f"live PMC pass failed: {ex}"
     finally:
         shutil.rmtree(work, ignore_errors=True)
-    return res, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) around child runs of this command, same job"
+    note = "rocprofv3 --pmc, one pass per counter group (" + " | ".join(" ".join(c) for c in PMC_PASSES) + \
+           ") around child runs of this command, same job"
+    if failed:
+        note += f"; pass(es) {failed} failed"
+    return res, note
+
+
+def _dominant_kernel(pm, want_bwd_kernel):
+    for k, v in pm.items():
+        if "brick_flat_kernel<" not in k:
+            continue
+        targs = [t.strip(" >") for t in k.split("<")[1].split(",")]  # <VT, MODE, BWD, VOL, TF, ALPHA, K>
+        if len(targs) >= 6 and targs[5] == "true":
+            continue  # the (gated) alpha pre-pass
+        if (targs[2] == "true") == want_bwd_kernel:
+            return k, v
+    return None, None
+
+
+# Issue cost of a VALU wave-instruction on gfx950 with four waves on the SIMD (tools/microbench/oprate_bench,
+# profiles/r02_microbench_oprate.txt): f32 add / mul / fma, v_mov, v_add_u32, v_ashrrev 2.6 cycles; every other class (min / max,
+# compares, conversions, v_fract, v_cndmask, DPP, shifts, 3-operand integer ops) 4.5. Share of the first class in the hot loops,
+# from the listings (tools/isa_hist.py, blocks of the per-sample loop + the per-pass scan): forward 0.70, backward 0.43.
+VALU_COST_FAST, VALU_COST_SLOW = 2.6, 4.5
+VALU_FAST_SHARE = {False: 0.70, True: 0.43}
+N_SIMD, N_CU, N_XCD = 1024, 256, 8
+
+
+def valu_roofline(pm, want_bwd_kernel, steps_per_launch):
+    """What actually bounds the brick kernels: VALU issue slots and the LDS, from the SQ counters of
+    the dominant kernel, per launch. SQ cycle counters tick once per 4 clocks per wave; SQ_LDS_* are LDS-array cycles summed
+    over the CUs; GRBM_GUI_ACTIVE is summed over the 8 XCDs."""
+    k, v = _dominant_kernel(pm, want_bwd_kernel)
+    if not v or "SQ_INSTS_VALU" not in v or not v.get("GRBM_GUI_ACTIVE"):
+        return None
+    clocks = v["GRBM_GUI_ACTIVE"] / N_XCD                       # kernel duration in shader clocks
+    per_simd = v["SQ_INSTS_VALU"] / N_SIMD
+    cyc_per_instr = clocks / per_simd
+    share = VALU_FAST_SHARE[want_bwd_kernel]
+    model = share * VALU_COST_FAST + (1.0 - share) * VALU_COST_SLOW
+    wc = max(v.get("SQ_WAVE_CYCLES", 0.0), 1.0)
+    return {"kernel": k, "bound": "valu-issue",
+            "valu_lane_instr_per_voxel_step": round(v["SQ_INSTS_VALU"] * 64.0 / max(steps_per_launch, 1), 1),
+            "valu_wave_instr_per_simd": int(per_simd), "kernel_clocks": int(clocks),
+            "clocks_per_valu_instr": round(cyc_per_instr, 3),
+            "issue_cost_model_clocks_per_instr": round(model, 3),
+            "issue_slot_utilisation": round(min(model / cyc_per_instr, 1.0), 3),
+            "issue_slot_utilisation_if_all_full_rate": round(VALU_COST_FAST / cyc_per_instr, 3),
+            "lds_conflict_ratio": round(v.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(v.get("SQ_LDS_IDX_ACTIVE", 0.0), 1.0), 3),
+            "lds_array_busy": round(v.get("SQ_LDS_IDX_ACTIVE", 0.0) / N_CU / clocks, 3),
+            "lds_instr_per_voxel_step": round(v.get("SQ_INSTS_LDS", 0.0) * 64.0 / max(steps_per_launch, 1), 1),
+            "waves_per_simd": round(4.0 * wc / N_SIMD / clocks, 2),
+            "wave_time_split": {"parked_waitcnt_or_barrier": round(v.get("SQ_WAIT_ANY", 0.0) / wc, 3),
+                                "issue_stalled": round(v.get("SQ_WAIT_INST_ANY", 0.0) / wc, 3)},
+            "note": "issue_slot_utilisation = (share of full-rate VALU x 2.6 + rest x 4.5 clocks, measured issue costs and the "
+                    "static mix of the hot loop) / observed clocks per VALU wave-instruction per SIMD; the HBM fractions in "
+                    "`roofline` price a kernel that is bound HERE"}
 
 
 def traffic_bytes(pm, want_bwd_kernel):
@@ -245,14 +312,9 @@ def traffic_bytes(pm, want_bwd_kernel):
     FETCH_SIZE counts 128-B fabric requests at 64 B on gfx950: doubled, as the MI355X guide prescribes (calibrated on
     this access pattern: tools/microbench/fetch_calib.hip, profiles/r01_fetch_calibration.txt). WRITE_SIZE is exact for
     16-B stores and float atomics. Both are in KB. Memory-side requests include Infinity-Cache hits: an upper bound."""
-    for k, v in pm.items():
-        if "brick_flat_kernel<" not in k or "FETCH_SIZE" not in v:
-            continue
-        targs = [t.strip(" >") for t in k.split("<")[1].split(",")]  # <VT, MODE, BWD, VOL, TF, ALPHA, K>
-        if len(targs) >= 6 and targs[5] == "true":
-            continue  # the (gated) alpha pre-pass
-        if (targs[2] == "true") == want_bwd_kernel:
-            return int((2.0 * v["FETCH_SIZE"] + v.get("WRITE_SIZE", 0.0)) * 1024)
+    k, v = _dominant_kernel(pm, want_bwd_kernel)
+    if v and "FETCH_SIZE" in v:
+        return int((2.0 * v["FETCH_SIZE"] + v.get("WRITE_SIZE", 0.0)) * 1024)
     return None
 
 
@@ -445,12 +507,42 @@ def main():
         barrier()
         allreduce_ms = (time.perf_counter() - t1) / max(args.steps, 1) * 1e3
 
+    # The overlap question of the first real multi-GPU run: in the timed loop every forward runs with
+    # the previous step's gradient all-reduce in flight on RCCL's stream. The same forwards once more with nothing in
+    # flight, per rank, so that ONE run shows what the collective's channels take from the march.
+    fwd_alone_ms = None
+    if dist is not None and want_bwd:
+        barrier()
+        pairs = []
+        for k in range(min(max(args.steps, 1), 5)):
+            cam = cams_all[args.warmup + k]
+            e, x, r, n = F.ray_setup(cam, (ROWS, IMG), (N, N, N), sr, rows=rows_arg, jitter_seed=(42 if args.jitter else 0),
+                                     view_base=(args.warmup + k) * V)
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a0.record()
+            F.march_fwd(vol, tf, cam, e, x, r, n, S, sr, variant=args.variant, workspace=ws, rows=rows_arg,
+                        hints=("auto" if args.hints == "auto" else 0))
+            a1.record()
+            pairs.append((a0, a1))
+        barrier()
+        fwd_alone_ms = float(np.mean([a.elapsed_time(b) for a, b in pairs]))
+
     el = torch.tensor([elapsed_local], dtype=torch.float64, device=dev)
     rank_ms = [elapsed_local / max(args.steps, 1) * 1e3]
+    rank_phase_ms = None
     if dist is not None:
         gathered = [torch.zeros_like(el) for _ in range(world)]
         dist.all_gather(gathered, el)
         rank_ms = [float(g.item()) / max(args.steps, 1) * 1e3 for g in gathered]
+        mine = torch.tensor([float(np.mean([a.elapsed_time(b) for a, b in ev["fwd"]])) if ev["fwd"] else 0.0,
+                             fwd_alone_ms or 0.0,
+                             float(np.mean([a.elapsed_time(b) for a, b in ev["bwd"]])) if ev["bwd"] else 0.0],
+                            dtype=torch.float64, device=dev)
+        ph = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(ph, mine)
+        rank_phase_ms = {"fwd_with_allreduce_in_flight": [round(float(t[0]), 4) for t in ph],
+                         "fwd_alone": [round(float(t[1]), 4) for t in ph] if fwd_alone_ms is not None else None,
+                         "bwd": [round(float(t[2]), 4) for t in ph]}
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(total_steps, op=dist.ReduceOp.SUM)
         dist.all_reduce(planned_steps, op=dist.ReduceOp.SUM)
@@ -501,10 +593,12 @@ def main():
                 rf["hbm_gbs_measured"] = round(tb / (rf["avg_launch_ms"] * 1e-3) / 1e9, 1)
                 rf["hbm_frac_measured"] = round(rf["hbm_gbs_measured"] / HBM_PEAK_GBS, 4)
     dominant = roof_bwd if (roof_bwd and bwd_ms >= fwd_ms) else roof_fwd
+    valu_fwd = valu_roofline(pm, False, steps_per_launch) if pm else None
+    valu_bwd = valu_roofline(pm, True, steps_per_launch) if (pm and want_bwd) else None
 
     cpu_baseline = None
     if world == 1 and not args.no_cpu_baseline:
-        cpu_baseline = run_cpu_baseline(vol, tf, args, sr, want_vol, want_tf)
+        cpu_baseline = run_cpu_baseline(vol, tf, args, sr, want_vol, want_tf, gpu=(F, dev, ws))
 
     workload = {"vol+tf": "C4: fwd+bwd w.r.t. volume and TF", "tf": "C3: fwd+bwd w.r.t. TF",
                 "vol": "fwd+bwd w.r.t. volume", "none": "forward only"}[args.grads]
@@ -528,11 +622,14 @@ def main():
         "voxel_steps_per_step": int(vsteps / max(args.steps, 1)),
         "planned_steps_per_step": int(int(planned_steps.item()) / max(args.steps, 1)),  # executed/planned < 1 = early termination
         "ms_per_step_ranks": [round(v, 4) for v in rank_ms],
+        "phase_ms_ranks": rank_phase_ms,   # N > 1: per-rank forward time with / without the gradient all-reduce in flight, backward
         "allreduce_ms": None if allreduce_ms is None else round(allreduce_ms, 4),
         "allreduce_bytes": allreduce_bytes,
         "allreduce_model_ms": allreduce_model(allreduce_bytes, world),
         "rccl_channels": getattr(args, "rccl_channels", None),
         "roofline": dominant, "roofline_fwd": roof_fwd, "roofline_bwd": roof_bwd,
+        "roofline_valu": (valu_bwd if (valu_bwd and dominant is roof_bwd) else valu_fwd),
+        "roofline_valu_fwd": valu_fwd, "roofline_valu_bwd": valu_bwd,
         "traffic_source": traffic_source,
         "rays_marched_individually": (int(stats[2]) if stats is not None else None),
         "rays_repaired": (int(stats[0]) if stats is not None else None),
@@ -676,9 +773,11 @@ def host_cores():
     return n, note
 
 
-def run_cpu_baseline(vol, tf, args, sr, want_vol, want_tf):
+def run_cpu_baseline(vol, tf, args, sr, want_vol, want_tf, gpu=None):
     """Oracle (kind 'port': this repo's C restatement, not Taichi) timed on the host cores on a bounded
-    sample of the same workload: same volume/TF/camera, smaller image."""
+    sample of the same workload: same volume/TF/camera, smaller image. With `gpu` = (functional, device, workspace) the
+    same view is rendered and differentiated through the C ABI as well and compared with what the oracle just computed
+    (`parity_vs_gpu`): the checker at work, outside every timed region."""
     from oracle import oracle as O
     O.build()
     cores, cores_note = host_cores()
@@ -696,16 +795,42 @@ def run_cpu_baseline(vol, tf, args, sr, want_vol, want_tf):
     e, x, r, n = O.ray_setup(cam, W, W, (N, N, N), sr)
     t0 = time.perf_counter()
     out, steps = O.march_fwd(vol_h, tf_h, cam, e, x, r, n, 1 << 20, sr, 0)
+    dv_ref = dt_ref = g = None
     if want_vol or want_tf:
-        g = (2.0 / out.size) * (out - 0.5)
-        O.march_bwd(vol_h, tf_h, cam, e, x, r, n, 1 << 20, sr, g.astype(np.float32), want_vol, want_tf)
+        g = ((2.0 / out.size) * (out - 0.5)).astype(np.float32)
+        dv_ref, dt_ref = O.march_bwd(vol_h, tf_h, cam, e, x, r, n, 1 << 20, sr, g, want_vol, want_tf)
     dt = time.perf_counter() - t0
     nst = int(steps.sum())
+    parity = None
+    if gpu is not None and W == args.img:
+        # the same view through the C ABI (the bench's own volume, TF and kernel variant), against the oracle's results above
+        Fm, dev, ws = gpu
+        cam_t = torch.tensor(cam[None], dtype=torch.float32, device=dev)
+        eg, xg, rg, ng = Fm.ray_setup(cam_t, (W, W), (N, N, N), sr)
+        og, sg = Fm.march_fwd(vol, tf, cam_t, eg, xg, rg, ng, 1 << 20, sr, variant=args.variant, workspace=ws)
+        parity = {"view": "camera in_circles(0), whole image",
+                  "ray_buffers_bit_exact": bool(np.array_equal(ng[0].cpu().numpy(), n) and np.array_equal(rg[0].cpu().numpy(), r)),
+                  "sample_counts_equal": bool(np.array_equal(sg[0].cpu().numpy(), steps)),
+                  "rgba_max_abs_err": float(np.abs(og[0].cpu().numpy() - out).max())}
+        if g is not None:
+            dvg, dtg = Fm.march_bwd(vol, tf, cam_t, eg, xg, rg, ng, 1 << 20, sr, torch.from_numpy(g[None]).to(dev), og,
+                                    want_vol=want_vol, want_tf=want_tf, variant=args.variant, workspace=ws)
+            if dvg is not None:
+                parity["d_volume_max_err_over_max"] = float(np.abs(dvg.cpu().numpy() - dv_ref).max() / max(np.abs(dv_ref).max(), 1e-30))
+                parity["d_volume_voxels_compared"] = int(dv_ref.size)
+            if dtg is not None:
+                parity["d_tf_max_err_over_max"] = float(np.abs(dtg.cpu().numpy() - dt_ref).max() / max(np.abs(dt_ref).max(), 1e-30))
+            del dvg, dtg
+        parity["within_north_star_bars"] = bool(parity["sample_counts_equal"] and parity["rgba_max_abs_err"] <= 1e-5 and
+                                                parity.get("d_volume_max_err_over_max", 0.0) <= 1e-4 and
+                                                parity.get("d_tf_max_err_over_max", 0.0) <= 1e-4)
+    del dv_ref
     whole = "the WHOLE view" if W == args.img else f"a {W}x{W} rendering of the {args.img}x{args.img} view"
     res = {"value": round(nst / dt / 1e6, 4), "unit": "Mvoxel-steps/s", "cores": cores, "kind": "port",
            "cores_note": cores_note,
            "sample": f"same {N}^3 volume/TF, camera in_circles(0), {W}x{W} image = {whole} "
-                     f"({nst} voxel-steps, fwd{'+bwd' if (want_tf or want_vol) else ''}), C oracle with OpenMP, {dt:.1f} s"}
+                     f"({nst} voxel-steps, fwd{'+bwd' if (want_tf or want_vol) else ''}), C oracle with OpenMP, {dt:.1f} s",
+           "parity_vs_gpu": parity}
     # single-thread figure on a 16x smaller sample (SURVEY 8(d) asks for both)
     try:
         import ctypes

@@ -4,10 +4,13 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdifferender_hip.so")
+# compiler and target of every native piece (the Makefile reads the same variables from the environment)
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = os.environ.get("ARCH", "gfx950")
 
 
 def build(force=False, verbose=False):
-    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j4"]
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j4", f"HIPCC={HIPCC}", f"ARCH={ARCH}"]
     if force:
         cmd.append("-B")
     subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)

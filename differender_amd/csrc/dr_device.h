@@ -99,6 +99,25 @@ __device__ __forceinline__ float tri_sample(const VolView<VT> &v, float px, floa
     return mixf(zl, zh, c.fz);
 }
 
+// Float atomic add to a gradient in global memory that can never leave +-FLT_MAX (the "finite by construction" promise of
+// the sanitising backward). Addends up to 1e30 -- everything the kernels produce from ordinary upstream
+// gradients, and every per-sample contribution after its clamp -- go through the hardware atomic: 3e8 of them would have to
+// meet in one element before the sum overflowed. Only the rare larger addend (a brick's or a workgroup's total under
+// upstream gradients beyond ~1e30) takes a compare-and-swap loop that clamps the sum: what torch.nan_to_num would have made
+// of the infinity (VR.py:463-475), without the two extra passes over the tensor. A later ordinary addend leaves +-FLT_MAX
+// where it is (1e30 is less than half an ulp of it).
+__device__ __forceinline__ void atomic_add_sat(float *p, float v) {
+    if (fabsf(v) <= 1.0e30f) { unsafeAtomicAdd(p, v); return; }
+    if (!(v == v)) return;   // (a NaN total cannot arise from sanitised addends; dropped all the same)
+    unsigned int *u = reinterpret_cast<unsigned int *>(p);
+    unsigned int old = __hip_atomic_load(u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), assumed;
+    do {
+        assumed = old;
+        const float nv = fminf(fmaxf(__uint_as_float(assumed) + v, -3.4028234664e38f), 3.4028234664e38f);
+        old = atomicCAS(u, assumed, __float_as_uint(nv));
+    } while (old != assumed);
+}
+
 // adjoint of tri_sample w.r.t. the volume (global float atomics; baseline path)
 struct GradView {
     float *p;
@@ -196,11 +215,13 @@ __device__ __forceinline__ float pow_spec(float x, float y) {
     q = q * r + 0.5; q = q * r + 1.0; q = q * r + 1.0;
     return (float)(q * __longlong_as_double((long long)((int)n + 1023) << 52));
 }
-// Correctly rounded square root for x = 0, normal x, NaN or x < 0 (-> NaN): v_sqrt_f32 (1 ulp) and the compiler's own
-// one-ulp correction from the two exact fma residuals -- without the scaling that sqrtf() wraps around it for DENORMAL
-// arguments (9 instead of 17 instructions; three of them per sample at sampling rate 8). 1 - alpha is never denormal:
-// the difference is exact for alpha in [0.5, 1] and then 0 or >= 2^-24, and the nested roots only move towards 1.
-// Checked against the host's sqrtf on every one of the 2^31 non-negative floats (tools/microbench/sqrt_cr_check.hip).
+// Correctly rounded square root -- CONTRACT: x = 0, x >= 2^-96, NaN or x < 0 (-> NaN). v_sqrt_f32 (1 ulp) and the
+// compiler's own one-ulp correction from the two exact fma residuals -- without the scaling that sqrtf() wraps around it
+// for small arguments (9 instead of 17 instructions; three of them per sample at sampling rate 8). Below 2^-96 the
+// residuals x - (y -+ ulp) y underflow and the correction can pick the wrong neighbour: such arguments are outside the
+// contract (pow_inv_sr, the only caller, sends them to pow_spec). 1 - alpha never gets there: the difference is exact for
+// alpha in [0.5, 1] and then 0 or >= 2^-24, and the nested roots only move towards 1.
+// Checked against the host's sqrtf on every one of the 2 139 095 041 floats of the contract (tools/microbench/sqrt_cr_check.hip).
 __device__ __forceinline__ float sqrt_cr(float x) {
     const float y = __builtin_amdgcn_sqrtf(x);
     const float ym = __int_as_float(__float_as_int(y) - 1), yp = __int_as_float(__float_as_int(y) + 1);
@@ -211,10 +232,19 @@ __device__ __forceinline__ float sqrt_cr(float x) {
 }
 __device__ __forceinline__ float pow_inv_sr(float base, float inv_sr) {
     if (inv_sr == 1.0f) return base;
-    if (inv_sr == 0.5f) return sqrt_cr(base);
-    if (inv_sr == 0.25f) return sqrt_cr(sqrt_cr(base));
-    if (inv_sr == 0.125f) return sqrt_cr(sqrt_cr(sqrt_cr(base)));
-    if (inv_sr == 0.0625f) return sqrt_cr(sqrt_cr(sqrt_cr(sqrt_cr(base))));
+    // (the first root of a base below sqrt_cr's contract -- not reachable from 1 - alpha, see above -- is the library's sqrtf,
+    // scaling included: still the correctly rounded root the oracle takes, D6; one comparison, false for every lane in practice;
+    // the roots that follow are of numbers >= 2^-75)
+    if (inv_sr == 0.5f || inv_sr == 0.25f || inv_sr == 0.125f || inv_sr == 0.0625f) {
+        const bool tiny = base != 0.0f && base < 1.2621774483536189e-29f;   // 2^-96
+        float r;
+        if (__any(tiny)) r = tiny ? sqrtf(base) : sqrt_cr(base);   // (wave-uniform branch: the 17-instruction sqrtf stays off the hot path)
+        else r = sqrt_cr(base);
+        if (inv_sr <= 0.25f) r = sqrt_cr(r);
+        if (inv_sr <= 0.125f) r = sqrt_cr(r);
+        if (inv_sr <= 0.0625f) r = sqrt_cr(r);
+        return r;
+    }
     return pow_spec(base, inv_sr);
 }
 

@@ -180,7 +180,9 @@ __global__ __launch_bounds__(256) void march_bwd_baseline_kernel(MarchParams<VT>
         float *dtf = P.d_tf + view * P.dtf_vs * 4;
         for (int k = threadIdx.x; k < 4 * P.R; k += 256) {
             const float v = lds_dtf[k];
-            if (v != 0.0f) unsafeAtomicAdd(dtf + k, v);
+            if (v == 0.0f) continue;
+            if (P.only_flagged) atomic_add_sat(dtf + k, v);  // second pass of the sanitising backward: the sum stays finite
+            else unsafeAtomicAdd(dtf + k, v);
         }
     }
 }

@@ -38,6 +38,9 @@ def shard_rows(image_rows, rank=None, world_size=None, weights=None):
     w = np.asarray(weights, np.float64)
     if w.shape != (image_rows,) or not np.isfinite(w).all() or (w < 0).any():
         raise ValueError("weights must be one finite, non-negative number per image row")
+    if image_rows < world_size:
+        raise ValueError(f"cannot cut {image_rows} image rows into {world_size} non-empty weighted bands "
+                         "(fewer rows than ranks: use the unweighted split, which allows empty bands)")
     w = w + max(float(w.sum()), 1.0) * 1e-3 / image_rows        # every row costs something (ray setup, image I/O)
     cum = np.concatenate([[0.0], np.cumsum(w)])
     cuts = [0]

@@ -129,10 +129,12 @@ int dr_march_bwd(const void *vol, int vol_dtype, int VX, int VY, int VZ,
  * 32-bit indices hold: n_views, W, H as in the march call). The ONE function that decides: dr_march_bwd_rows asks it.
  * The brick-centric backward sanitises its gradients itself: a NaN adjoint (NaN pixel of grad_out, NaN voxel)
  * contributes nothing, +-inf and magnitudes beyond 1e30 are clamped per sample, a brick's flush to +-3e38 -- so its
- * caller may skip the torch.nan_to_num of VR.py:463-475. Residual case: the float atomics that combine bricks, views and
- * the few samples that bypass the LDS box can still overflow to +-inf when clamped contributions of ~1e38 meet (upstream
- * gradients beyond ~1e30); the reference's nan_to_num would turn that into +-3.4e38. The plain kernels propagate NaN
- * exactly like the reference and rely on nan_to_num. (dsx,dsy,dsz) are ignored if !has_dvol. */
+ * caller may skip the torch.nan_to_num of VR.py:463-475. The float atomics that combine bricks, views and work items
+ * saturate at +-FLT_MAX (round 4: an addend beyond 1e30 takes a clamping compare-and-swap, atomic_add_sat): where the
+ * reference's nan_to_num would turn an overflow into +-3.4e38, so does this path, and no element is ever +-inf or NaN --
+ * also when the call is served by the per-ray second pass alone (a stale workspace, a repaired wrong hint): that pass
+ * sanitises its adjoints whenever it runs on behalf of the brick-centric backward. The plain kernels (DR_VARIANT_BASELINE)
+ * propagate NaN exactly like the reference and rely on nan_to_num. (dsx,dsy,dsz) are ignored if !has_dvol. */
 int dr_march_bwd_variant(int n_views, int W, int H, int VX, int VY, int VZ, int R, int64_t sx, int64_t sy, int64_t sz,
                          int64_t dsx, int64_t dsy, int64_t dsz, int has_dvol, int variant, int has_workspace);
 

@@ -926,6 +926,22 @@ def test_backward_with_non_finite_upstream_gradient(oracle, F):
         assert (~sv & (dv_o != 0)).sum() > 1000
         d = np.abs(dv.cpu().numpy() - dv_o)[~sv]
         assert (d <= 1e-4 * np.abs(dv_o)[~sv] + 5e-6 * np.abs(dv_o).max()).all(), float(d.max() / np.abs(dv_o).max())
+    # 2b) an overflowed loss: EVERY pixel's upstream gradient at +-3e38 (clamped contributions of ~1e38 meet in the float atomics
+    # that combine bricks and work items: they saturate at +-FLT_MAX, as the reference's nan_to_num would have left them)
+    if F.variant == 0:
+        g_huge = np.sign(g).astype(np.float32) * np.float32(3e38)
+        dv, dt = F.march_bwd(vol, tf, cam, e, x, r, n, 4096, 1.0, T(g_huge), out)
+        assert torch.isfinite(dv).all() and torch.isfinite(dt).all()
+        assert float(dv.abs().max()) > 1e30 and float(dt.abs().max()) > 1e30      # (it did overflow the ordinary range)
+        # ... also when the backward is served by the per-ray second pass alone (a workspace that is not this forward's)
+        from differender_amd import functional as Fn
+        ws_other = Fn.alloc_workspace(1, WH, vol.shape, tf.shape[0], dev()); ws_other.zero_()
+        dv, dt = Fn.march_bwd(vol, tf, cam, e, x, r, n, 4096, 1.0, T(g_huge), out, workspace=ws_other)
+        assert int(Fn.workspace_stats(ws_other)[9]) == 1
+        assert torch.isfinite(dv).all() and torch.isfinite(dt).all()
+        g_nan_all = g.copy(); g_nan_all[0, ::2, :, 1] = np.nan
+        dv, dt = Fn.march_bwd(vol, tf, cam, e, x, r, n, 4096, 1.0, T(g_nan_all), out, workspace=ws_other)
+        assert torch.isfinite(dv).all() and torch.isfinite(dt).all()
     # 3) the same call with the three pixels zeroed matches the oracle in the usual sense
     dv2, dt2 = F.march_bwd(vol, tf, cam, e, x, r, n, 4096, 1.0, T(g_ok), out)
     ok, err = grad_close(dv2.cpu().numpy(), dv_o)

@@ -113,6 +113,16 @@ def test_work_balanced_row_bands():
         assert work.max() <= even.max()
     # degenerate weights still give every rank a band
     assert [shard_rows(5, k, 5, weights=np.array([0, 0, 9.0, 0, 0])) for k in range(5)] == [(k, 1) for k in range(5)]
+    # fewer rows than ranks: no weighted cut has a row for everybody (the unweighted split hands out empty bands instead)
+    with pytest.raises(ValueError, match="fewer rows than ranks"):
+        shard_rows(3, 0, 8, weights=np.ones(3))
+    assert [shard_rows(3, k, 8) for k in range(8)] == [(0, 1), (1, 1), (2, 1)] + [(3, 0)] * 5
+    # the bands of a full node (8 ranks) on the headline image, cut by estimated work
+    w8 = row_work_estimate([2.5, 0.7, 0.0], 512, 512)
+    bands8 = [shard_rows(512, k, 8, weights=w8) for k in range(8)]
+    assert bands8[0][0] == 0 and all(a[0] + a[1] == b[0] for a, b in zip(bands8, bands8[1:])) and sum(b[1] for b in bands8) == 512
+    work8 = np.array([w8[r0:r0 + nr].sum() for r0, nr in bands8])
+    assert work8.max() <= 1.05 * work8.mean()
     assert sum(nr for _, nr in (shard_rows(10, k, 4, weights=np.zeros(10)) for k in range(4))) == 10
     with pytest.raises(ValueError):
         shard_rows(10, 0, 2, weights=np.ones(9))
