@@ -71,7 +71,6 @@ struct BrickCtx {
     float lo[3], hi[3];           // world AABB of the brick's cells, with slack
     int i0, i1, j0, j1;           // candidate pixel rectangle (inclusive); empty if i0 > i1
     int live;                     // from the workspace record (see BrickCtxRec)
-    int touched;                  // ... likewise: the alpha pre-pass marched at least one sample of the view in this brick
 };
 
 // BrickCtx as stored in the workspace (64 B): every workgroup of F1 / P1 / B1 reads its record with scalar loads
@@ -82,15 +81,14 @@ struct BrickCtxRec {
     float hi[3]; int i1;
     int j0, j1;
     int live;   // set by the flat forward when the brick marched at least one sample of the view (backward skips the others)
-    int touched;  // set by the alpha pre-pass when it marched at least one sample of the view in this brick: the colour march,
-                  // whose samples are a subset of the pre-pass's, leaves every other brick after reading its record
+    int pad1;
 };
 __device__ __forceinline__ void brick_ctx_load(const BrickCtxRec *rec, BrickCtx &c) {
     const BrickCtxRec r = *rec;
     c.bx = r.bx; c.by = r.by; c.bz = r.bz; c.layer = r.layer;
     c.ox = c.bx * BRK - 1; c.oy = c.by * BRK - 1; c.oz = c.bz * BRK - 1;
     for (int k = 0; k < 3; ++k) { c.lo[k] = r.lo[k]; c.hi[k] = r.hi[k]; }
-    c.i0 = r.i0; c.i1 = r.i1; c.j0 = r.j0; c.j1 = r.j1; c.live = r.live; c.touched = r.touched;
+    c.i0 = r.i0; c.i1 = r.i1; c.j0 = r.j0; c.j1 = r.j1; c.live = r.live;
 }
 
 #ifndef DR_RECT_SLACK
@@ -257,10 +255,9 @@ static __global__ __launch_bounds__(256) void brick_ctx_kernel(BrickParams<VT> P
     BrickCtxRec r;
     r.bx = c.bx; r.by = c.by; r.bz = c.bz; r.layer = c.layer;
     for (int k = 0; k < 3; ++k) { r.lo[k] = c.lo[k]; r.hi[k] = c.hi[k]; }
-    r.i0 = c.i0; r.i1 = c.i1; r.j0 = c.j0; r.j1 = c.j1;
+    r.i0 = c.i0; r.i1 = c.i1; r.j0 = c.j0; r.j1 = c.j1; r.pad1 = 0;
     const int slot_b = near_first_brick(P, b, view);  // (an involution: slot -> brick and brick -> slot are the same flips)
     r.live = forward ? 0 : out[(size_t)view * nbricks + slot_b].live;
-    r.touched = forward ? 0 : out[(size_t)view * nbricks + slot_b].touched;
     out[(size_t)view * nbricks + slot_b] = r;
     if (forward && c.i0 <= c.i1 && c.j0 <= c.j1) {
         // a brick with more candidate pixels than the main launch takes: cut the rest into work items

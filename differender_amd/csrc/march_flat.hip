@@ -700,11 +700,6 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
     }
     // backward after a flat forward: bricks in which the forward marched nothing (rays terminated before them) have no work
     if (BWD && !DR_PHASE_TIMING && c.live == 0) return;  // uniform
-    // colour march after an alpha pre-pass that ran for this view: its samples (s < the ray's exact live count) are a subset of
-    // the pre-pass's (every sample of every ray not terminated in an earlier group), so a brick in which the pre-pass marched
-    // nothing -- with tf1 four bricks in five lie behind the termination front -- has nothing for it either: it leaves here,
-    // before the candidates' ray buffers are loaded and their segments listed
-    if (!BWD && !ALPHA && P.use_live && P.vflags[view] != 0u && c.touched == 0) return;  // uniform
 
 #if DR_SETPRIO
     __builtin_amdgcn_s_setprio(3);  // the staging / listing prologue is short and latency-bound: let it overtake sample loops
@@ -1301,8 +1296,6 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
             }
             if (!ALPHA && __any(some) && lane == 0)  // tell the backward that this brick holds live samples of the view
                 const_cast<BrickCtxRec *>(P.ctx)[(size_t)view * nbricks + slot].live = 1;
-            if (ALPHA && __any(some) && lane == 0)   // ... and the colour march that the pre-pass found samples here
-                const_cast<BrickCtxRec *>(P.ctx)[(size_t)view * nbricks + slot].touched = 1;
         }
     }
 #if DR_PHASE_TIMING == 2
