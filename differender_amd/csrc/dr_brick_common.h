@@ -321,6 +321,66 @@ __device__ __forceinline__ void sample_normal_taps_lds(const float *box, const T
     dz = tri_lds(box, bx + by + t.lzp, t.fx, t.fy, t.fzp) - tri_lds(box, bx + by + t.lzm, t.fx, t.fy, t.fzm);
 }
 
+// ---- The same seven taps with SHARED partial lerps (round 4) ------------------------------------------------------------
+// The reference interpolates x -> y -> z (VR.py:173-189). The +-delta taps along y keep the centre tap's x cell and x
+// fraction, so their four x-lerps are -- bit for bit -- the centre's own (rows ly, ly+1) plus, when the tap has crossed into the
+// neighbouring cell, ONE more row (ly+2 or ly-1); the taps along z keep x and y, so their two bilinear planes are the centre's
+// zl, zh plus at most one more plane. With delta < half a voxel (volume edges up to 991: NARROW) at most one of the two taps
+// of an axis leaves the centre's cell, so one extra row and one extra plane per sample suffice: 8 + 4 + 4 LDS words and
+// 7 + 2+6 + 3+2 lerps for five taps instead of 40 words and 35 lerps, every tap still the oracle's sequence of roundings on the
+// oracle's operands. (The taps along x change the FIRST lerp's fraction: nothing of the centre's can be reused but the
+// voxels themselves, and choosing them lane by lane costs more selects than the reads it saves: they stay as they were.)
+// The forward's LDS traffic is worth 7-10 % of its time (profiles/r04_ab_experiments.txt, half-reads what-if).
+struct CentreLerps { float a0, b0, a1, b1, zl, zh; };
+__device__ __forceinline__ float sample_centre_lds_keep(const float *box, const TapCoords &t, CentreLerps &c) {
+    const int base = t.lx * BOX_SX + t.ly * BOX_SY + t.lz;
+    c.a0 = mixf(box[base], box[base + BOX_SX], t.fx);
+    c.b0 = mixf(box[base + BOX_SY], box[base + BOX_SX + BOX_SY], t.fx);
+    c.zl = mixf(c.a0, c.b0, t.fy);
+    c.a1 = mixf(box[base + 1], box[base + BOX_SX + 1], t.fx);
+    c.b1 = mixf(box[base + BOX_SY + 1], box[base + BOX_SX + BOX_SY + 1], t.fx);
+    c.zh = mixf(c.a1, c.b1, t.fy);
+    return mixf(c.zl, c.zh, t.fz);
+}
+// NARROW: delta below half a voxel -- at most one of an axis's two taps leaves the centre's cell, one extra row / plane is
+// read (chosen per lane); otherwise (edges of 992 .. 2000 voxels, e.g. 1024^3: delta = 0.51) both may, and both extra rows /
+// planes are read: 8 + 8 + 8 words for five taps, still half of what five separate taps take.
+template <bool NARROW>
+__device__ __forceinline__ void sample_normal_taps_shared_lds(const float *box, const TapCoords &t, const CentreLerps &c,
+                                                              float &dx, float &dy, float &dz) {
+    const int by = t.ly * BOX_SY, bz = t.lz, bx = t.lx * BOX_SX;
+    // x: as before
+    dx = tri_lds(box, t.lxp * BOX_SX + by + bz, t.fxp, t.fy, t.fz) - tri_lds(box, t.lxm * BOX_SX + by + bz, t.fxm, t.fy, t.fz);
+    {   // y: the x-lerps of row ly+2 (for a +delta tap in the cell above) and of row ly-1 (a -delta tap in the cell below)
+        const bool up = t.lyp != t.ly, dn = t.lym != t.ly;
+        const int ru = bx + (NARROW ? (up ? t.ly + 2 : t.ly - 1) : t.ly + 2) * BOX_SY + bz;
+        const float u0 = mixf(box[ru], box[ru + BOX_SX], t.fx);
+        const float u1 = mixf(box[ru + 1], box[ru + BOX_SX + 1], t.fx);
+        float d0 = u0, d1 = u1;
+        if (!NARROW) {
+            const int rd = bx + (t.ly - 1) * BOX_SY + bz;
+            d0 = mixf(box[rd], box[rd + BOX_SX], t.fx);
+            d1 = mixf(box[rd + 1], box[rd + BOX_SX + 1], t.fx);
+        }
+        const float p = mixf(mixf(up ? c.b0 : c.a0, up ? u0 : c.b0, t.fyp), mixf(up ? c.b1 : c.a1, up ? u1 : c.b1, t.fyp), t.fz);
+        const float m = mixf(mixf(dn ? d0 : c.a0, dn ? c.a0 : c.b0, t.fym), mixf(dn ? d1 : c.a1, dn ? c.a1 : c.b1, t.fym), t.fz);
+        dy = p - m;
+    }
+    {   // z: the bilinear planes lz+2 and lz-1
+        const bool up = t.lzp != t.lz, dn = t.lzm != t.lz;
+        const int pu = bx + by + (NARROW ? (up ? t.lz + 2 : t.lz - 1) : t.lz + 2);
+        const float zu = mixf(mixf(box[pu], box[pu + BOX_SX], t.fx), mixf(box[pu + BOX_SY], box[pu + BOX_SX + BOX_SY], t.fx), t.fy);
+        float zd = zu;
+        if (!NARROW) {
+            const int pd = bx + by + t.lz - 1;
+            zd = mixf(mixf(box[pd], box[pd + BOX_SX], t.fx), mixf(box[pd + BOX_SY], box[pd + BOX_SX + BOX_SY], t.fx), t.fy);
+        }
+        const float p = mixf(up ? c.zh : c.zl, up ? zu : c.zh, t.fzp);
+        const float m = mixf(dn ? zd : c.zl, dn ? c.zl : c.zh, t.fzm);
+        dz = p - m;
+    }
+}
+
 // Tap coordinates of a sample at (sm.px, sm.py, sm.pz), in two halves: the centre tap (returns whether the sample's cell
 // lies in this brick), and the six normal taps -- needed only where the sample is lit (forward) or always (backward).
 template <typename VT>
@@ -520,6 +580,7 @@ static inline BrickParams<VT> make_brick_params(const MarchArgs &a, const Worksp
     const double near_h = 2.0 * tan(a.fov_rad) * a.near_plane;
     P.near_ = (float)a.near_plane; P.near_h = (float)near_h; P.near_w = (float)(near_h * ((double)P.imgW / (double)a.H));
     P.g = make_brick_grid(a.VX, a.VY, a.VZ);
+
     P.seg_rgba = w.seg_rgba; P.seg_cnt = w.seg_cnt; P.rayflag = w.rayflag; P.stats = w.stats; P.vflags = w.vflags; P.n_views = a.n_views; P.ws_steps = w.ws_steps;
     P.hint_noterm = (a.hints & DR_HINT_NO_EARLY_TERMINATION) ? 1 : 0;
     P.use_live = a.use_live; P.ctx = w.ctx; P.items = w.items; P.n_items = w.n_items;

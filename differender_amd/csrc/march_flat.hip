@@ -25,6 +25,7 @@ namespace dr {
 #ifndef DR_FNT_BWD
 #define DR_FNT_BWD 512
 #endif
+
 #ifndef DR_BWD_WAVES
 #define DR_BWD_WAVES 4
 #endif
@@ -673,7 +674,7 @@ __device__ __forceinline__ float wave_min_f(float v) {
 // inside the volume: the brick around the eye is a candidate of every pixel -- had the rest cut into items of ITEM_CAND
 // candidates by brick_ctx_kernel, which a second, small launch works off (brick_flat_items_kernel). Without that, the few
 // bricks next to the camera would each be one workgroup's job: 61 ms instead of 6 for a 512^2 view from inside a 512^3 volume.
-template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, bool ALPHA, int KF, bool HEAVY>
+template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, bool ALPHA, int KF, bool HEAVY, bool NARROW>
 __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsigned char *smem, const int slot, const int view,
                                                 const int c_lo, const int c_hi, bool &box_valid) {
     if (ALPHA && P.vflags[view] == 0u) return;  // uniform: no ray of this view can terminate early
@@ -950,9 +951,10 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                     Over2 ej = {0.f, 0.f};
                     if (vj) {
                         float dx, dy, dz;
-                        sm.I = sample_centre_lds(L.box, t);
+                        CentreLerps cl;
+                        sm.I = sample_centre_lds_keep(L.box, t, cl);
                         classify_from_I(L.tf, P.R, P.tf_len, P.inv_sr, sm);
-                        sample_normal_taps_lds(L.box, t, dx, dy, dz);
+                        sample_normal_taps_shared_lds<NARROW>(L.box, t, cl, dx, dy, dz);
                         shade_from_grad<true>(dx, dy, dz, light, vd, true, sm);
                         const float rd = go.x * sm.r + go.y * sm.g + go.z * sm.b;
                         kL[j] = sm.L; kop[j] = sm.op; krd[j] = rd; kfr[j] = sm.fr; ka[j] = sm.a; klo[j] = sm.lo; khi[j] = sm.hi;
@@ -1060,20 +1062,22 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
             // is (the nondiff path skips alpha <= 1e-3 by definition, VR.py:334). Lanes are consecutive samples of a
             // ray, so empty stretches of the transfer function are wave-uniform: skip the six normal taps (48 of the
             // 56 LDS reads) and the shading for the whole wave. The backward always needs L (d/d alpha).
+            CentreLerps cl;
+            cl.a0 = cl.b0 = cl.a1 = cl.b1 = cl.zl = cl.zh = 0.f;
             if (KS == 1) {
                 if (act) {
                     sample_pos_rcp(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, cam.x, cam.y, cam.z, s, sm.px, sm.py, sm.pz);
                     valid = BWD ? sample_coords_at(vol, c, sm, t) : sample_centre_coords_at(vol, c, sm, t);
                 }
                 if (valid) {
-                    sm.I = sample_centre_lds(L.box, t);
+                    sm.I = sample_centre_lds_keep(L.box, t, cl);
                     classify_from_I(L.tf, P.R, P.tf_len, P.inv_sr, sm);
                 }
                 const bool lit = !ALPHA && valid && (BWD || (MODE == DR_MODE_NONDIFF ? (sm.a > 1e-3f) : (sm.op != 0.0f)));
                 if (BWD || __any(lit)) {
                     if (lit) {
                         if (!BWD) sample_normal_coords_at(vol, c, sm, t);
-                        sample_normal_taps_lds(L.box, t, dx, dy, dz);
+                        sample_normal_taps_shared_lds<NARROW>(L.box, t, cl, dx, dy, dz);
                         shade_from_grad<true>(dx, dy, dz, light, vd, MODE == DR_MODE_DIFF, sm);
                     }
                     // Kinks of the lighting model: the adjoint switches on 1 < Lraw (the clamp of VR.py:298),
@@ -1102,7 +1106,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                         vj = sample_centre_coords_at(vol, c, sm, t);
                     }
                     if (vj) {
-                        sm.I = sample_centre_lds(L.box, t);
+                        sm.I = sample_centre_lds_keep(L.box, t, cl);
                         tf_lookup_from_I(L.tf, P.R, P.tf_len, sm);
                         if (MODE != DR_MODE_NONDIFF) sm.op = opacity_of_alpha(sm.a, P.inv_sr);
                     }
@@ -1112,7 +1116,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                         if (lit) {
                             if (MODE == DR_MODE_NONDIFF) sm.op = opacity_of_alpha(sm.a, P.inv_sr);  // (a power: only where lit)
                             sample_normal_coords_at(vol, c, sm, t);  // (not before: transparent stretches never need them)
-                            sample_normal_taps_lds(L.box, t, dx, dy, dz);
+                            sample_normal_taps_shared_lds<NARROW>(L.box, t, cl, dx, dy, dz);
                             shade_from_grad<true>(dx, dy, dz, light, vd, MODE == DR_MODE_DIFF, sm);
                             ej.c0 = sm.L * sm.r * sm.op; ej.c1 = sm.L * sm.g * sm.op; ej.c2 = sm.L * sm.b * sm.op; ej.a = sm.op;
                         }
@@ -1370,7 +1374,7 @@ constexpr int ITEM_GRID_FWD = DR_ITEM_GRID_FWD, ITEM_GRID_BWD = DR_ITEM_GRID_BWD
 #endif
 constexpr int ITEM_RUN = DR_ITEM_RUN;   // consecutive items a workgroup takes at a time
 
-template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, bool ALPHA = false, int KF = 1>
+template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, bool ALPHA = false, int KF = 1, bool NARROW = true>
 __global__ __launch_bounds__((FlatCfg<BWD, WANT_VOL>::FNT), (FlatCfg<BWD, WANT_VOL>::WAVES)) void brick_flat_kernel(BrickParams<VT> P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef DR_VIEW_FASTEST
@@ -1378,15 +1382,15 @@ __global__ __launch_bounds__((FlatCfg<BWD, WANT_VOL>::FNT), (FlatCfg<BWD, WANT_V
     // read -- 2 % slower with 8 views, 13 % on the demo loop)
     const int nv = P.n_views;
     bool bv = false;
-    brick_flat_body<VT, MODE, BWD, WANT_VOL, WANT_TF, ALPHA, KF, false>(P, smem, blockIdx.x / nv, blockIdx.x % nv, 0, MAIN_CAND, bv);
+    brick_flat_body<VT, MODE, BWD, WANT_VOL, WANT_TF, ALPHA, KF, false, NARROW>(P, smem, blockIdx.x / nv, blockIdx.x % nv, 0, MAIN_CAND, bv);
 #else
     bool bv = false;
-    brick_flat_body<VT, MODE, BWD, WANT_VOL, WANT_TF, ALPHA, KF, false>(P, smem, blockIdx.x, blockIdx.y,
-                                                                       0, MAIN_CAND, bv);
+    brick_flat_body<VT, MODE, BWD, WANT_VOL, WANT_TF, ALPHA, KF, false, NARROW>(P, smem, blockIdx.x, blockIdx.y,
+                                                                               0, MAIN_CAND, bv);
 #endif
 }
 // the overflow items of heavy bricks (all views), worked off by a fixed, small grid
-template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, bool ALPHA = false, int KF = 1>
+template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, bool ALPHA = false, int KF = 1, bool NARROW = true>
 __global__ __launch_bounds__((FlatCfg<BWD, WANT_VOL>::FNT), (FlatCfg<BWD, WANT_VOL>::WAVES)) void brick_flat_items_kernel(BrickParams<VT> P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (BWD && P.stats[ST_MARK] != P.mark) return;  // uniform over the grid: not this call's workspace, the item list is garbage
@@ -1411,7 +1415,7 @@ __global__ __launch_bounds__((FlatCfg<BWD, WANT_VOL>::FNT), (FlatCfg<BWD, WANT_V
         for (int it = first; it < min(first + ITEM_RUN, n_items); ++it) {
             const BrickItem item = P.items[it];
             if (item.view != pv || item.brick != ps) { box_valid = false; pv = item.view; ps = item.brick; }
-            brick_flat_body<VT, MODE, BWD, WANT_VOL, WANT_TF, ALPHA, KF, true>(P, smem, item.brick, item.view, item.c0, item.c1, box_valid);
+            brick_flat_body<VT, MODE, BWD, WANT_VOL, WANT_TF, ALPHA, KF, true, NARROW>(P, smem, item.brick, item.view, item.c0, item.c1, box_valid);
             __syncthreads();  // the next item reuses the LDS
         }
     }
@@ -1437,6 +1441,10 @@ bool brick_path_supported(int VX, int VY, int VZ, int R) {
     return flat_lds_bytes<true>(R, true, true) <= 160 * 1024;
 }
 
+static inline bool taps_narrow(const MarchArgs &a) {
+    const int m = a.VX > a.VY ? (a.VX > a.VZ ? a.VX : a.VZ) : (a.VY > a.VZ ? a.VY : a.VZ);
+    return m - 1 <= 990;   // delta = 1e-3 world units = 1e-3 * (m - 1) / 2 voxels <= 0.495
+}
 #ifdef DR_VIEW_FASTEST
 #define DR_GRID1 dim3(grid1.x * grid1.y)
 #else
@@ -1446,12 +1454,19 @@ bool brick_path_supported(int VX, int VY, int VZ, int R) {
 #ifndef DR_ABL_EXTRA_LDS_ALPHA
 #define DR_ABL_EXTRA_LDS_ALPHA 0   // what-if: bytes of unused LDS per workgroup of the alpha pre-pass (fewer workgroups per CU)
 #endif
+#define DR_LAUNCH_BOTH_N(MODE_, BWD_, VOL_, TF_, ALPHA_, K_, NT_, NARROW_)                                                             \
+    {                                                                                                                                 \
+        if ((e = allow_lds(brick_flat_kernel<VT, MODE_, BWD_, VOL_, TF_, ALPHA_, K_, NARROW_>, lds)) != hipSuccess) return (int)e;    \
+        if ((e = allow_lds(brick_flat_items_kernel<VT, MODE_, BWD_, VOL_, TF_, ALPHA_, K_, NARROW_>, align16(lds) + ITEM_EXTRA_LDS)) != hipSuccess) return (int)e; \
+        hipLaunchKernelGGL((brick_flat_kernel<VT, MODE_, BWD_, VOL_, TF_, ALPHA_, K_, NARROW_>), DR_GRID1, dim3(NT_), lds + ((ALPHA_) ? DR_ABL_EXTRA_LDS_ALPHA : 0), stream, P);         \
+        hipLaunchKernelGGL((brick_flat_items_kernel<VT, MODE_, BWD_, VOL_, TF_, ALPHA_, K_, NARROW_>), dim3(BWD_ ? (VOL_ ? ITEM_GRID_BWD : 2 * ITEM_GRID_BWD) : ITEM_GRID_FWD), dim3(NT_), align16(lds) + ITEM_EXTRA_LDS, stream, P); \
+    }
+// NARROW (delta below half a voxel: every edge <= 991 voxels) selects the cheaper shared-lerp taps (dr_brick_common.h); the alpha
+// pre-pass takes no normal taps and exists in one flavour
 #define DR_LAUNCH_BOTH(MODE_, BWD_, VOL_, TF_, ALPHA_, K_, NT_)                                                                       \
     {                                                                                                                                 \
-        if ((e = allow_lds(brick_flat_kernel<VT, MODE_, BWD_, VOL_, TF_, ALPHA_, K_>, lds)) != hipSuccess) return (int)e;             \
-        if ((e = allow_lds(brick_flat_items_kernel<VT, MODE_, BWD_, VOL_, TF_, ALPHA_, K_>, align16(lds) + ITEM_EXTRA_LDS)) != hipSuccess) return (int)e; \
-        hipLaunchKernelGGL((brick_flat_kernel<VT, MODE_, BWD_, VOL_, TF_, ALPHA_, K_>), DR_GRID1, dim3(NT_), lds + ((ALPHA_) ? DR_ABL_EXTRA_LDS_ALPHA : 0), stream, P);         \
-        hipLaunchKernelGGL((brick_flat_items_kernel<VT, MODE_, BWD_, VOL_, TF_, ALPHA_, K_>), dim3(BWD_ ? (VOL_ ? ITEM_GRID_BWD : 2 * ITEM_GRID_BWD) : ITEM_GRID_FWD), dim3(NT_), align16(lds) + ITEM_EXTRA_LDS, stream, P); \
+        if ((ALPHA_) || taps_narrow(a)) DR_LAUNCH_BOTH_N(MODE_, BWD_, VOL_, TF_, ALPHA_, K_, NT_, true)                              \
+        else DR_LAUNCH_BOTH_N(MODE_, BWD_, VOL_, TF_, ALPHA_, K_, NT_, false)                                                         \
     }
 
 template <typename VT>

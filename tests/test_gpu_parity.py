@@ -1031,3 +1031,38 @@ def test_object_in_air_with_odd_voxels(oracle, hiplib, poison):
     assert np.array_equal(np.isnan(got), np.isnan(ref))
     fin = ~np.isnan(ref)
     assert np.abs(got[fin] - ref[fin]).max() <= FWD_TOL
+
+
+@pytest.mark.parametrize("vshape,cam", [((1100, 20, 16), (0.4, 0.3, 2.4)), ((24, 1300, 20), (2.2, 0.2, 0.9)), ((16, 28, 1990), (1.9, 0.4, 1.6))],
+                         ids=["long-x", "long-y", "long-z"])
+def test_long_volume_both_normal_taps_leave_the_cell(oracle, hiplib, vshape, cam):
+    """Edges beyond 991 voxels: delta = 1e-3 world units exceeds half a voxel along the long axis, so the +delta AND the -delta tap
+    of one sample can both sit outside the centre's cell. The shared-lerp taps (dr_brick_common.h) then read both extra rows /
+    planes (template flavour NARROW = false; every other test of the suite runs NARROW = true). Forward and gradients against
+    the oracle, fast path and baseline kernels."""
+    from differender_amd import functional as Fn
+    rng = np.random.RandomState(8)
+    vol = (0.5 + 0.45 * np.sin(0.37 * np.arange(vshape[0]))[:, None, None] * np.cos(0.9 * np.arange(vshape[1]))[None, :, None]
+           * np.sin(0.5 + 0.21 * np.arange(vshape[2]))[None, None, :]).astype(np.float32)
+    vol += rng.uniform(-0.02, 0.02, size=vshape).astype(np.float32)
+    tf = oracle.bench_tf(32, 0.02); tf[:, 3] = np.linspace(0.004, 0.05, 32)
+    cam = np.array(cam, np.float32)
+    WH = (40, 32)
+    e0, x0, r0, n0 = oracle.ray_setup(cam, *WH, vshape)
+    ref, sref = oracle.march_fwd(vol, tf, cam, e0, x0, r0, n0, 1 << 20, 1.0, 0)
+    g = rng.randn(*WH, 4).astype(np.float32)
+    dv0, dt0 = oracle.march_bwd(vol, tf, cam, e0, x0, r0, n0, 1 << 20, 1.0, g)
+    vt, tt, ct = T(vol), T(tf), T(cam[None])
+    e, x, r, n = Fn.ray_setup(ct, WH, vshape, 1.0)
+    assert np.array_equal(n[0].cpu().numpy(), n0) and int(n0.max()) > 1000
+    ws = Fn.alloc_workspace(1, WH, vshape, 32, dev())
+    assert ws is not None
+    out, steps = Fn.march_fwd(vt, tt, ct, e, x, r, n, 1 << 20, 1.0, workspace=ws)
+    assert int(Fn.workspace_stats(ws)[0]) == 0
+    assert np.array_equal(steps[0].cpu().numpy(), sref)
+    assert np.abs(out[0].cpu().numpy() - ref).max() <= FWD_TOL
+    dv, dt = Fn.march_bwd(vt, tt, ct, e, x, r, n, 1 << 20, 1.0, T(g[None]), out, workspace=ws)
+    ok, err = grad_close(dv.cpu().numpy(), dv0); assert ok, f"d_vol rel err {err}"
+    ok, err = grad_close(dt.cpu().numpy(), dt0); assert ok, f"d_tf rel err {err}"
+    _, dt_only = Fn.march_bwd(vt, tt, ct, e, x, r, n, 1 << 20, 1.0, T(g[None]), out, want_vol=False, workspace=ws)
+    ok, err = grad_close(dt_only.cpu().numpy(), dt0); assert ok, f"d_tf (TF-only backward) rel err {err}"
