@@ -350,7 +350,18 @@ __device__ __forceinline__ void sample_normal_taps_shared_lds(const float *box, 
                                                               float &dx, float &dy, float &dz) {
     const int by = t.ly * BOX_SY, bz = t.lz, bx = t.lx * BOX_SX;
     // x: as before
+#ifdef DR_ABL_XREUSE
+    {   // what-if (WRONG results): both x taps from ONE set of eight voxels, no select -- the bound for reusing the centre's voxels
+        const int b0_ = bx + by + bz;
+        const float v000 = box[b0_], v100 = box[b0_ + BOX_SX], v010 = box[b0_ + BOX_SY], v110 = box[b0_ + BOX_SX + BOX_SY];
+        const float v001 = box[b0_ + 1], v101 = box[b0_ + BOX_SX + 1], v011 = box[b0_ + BOX_SY + 1], v111 = box[b0_ + BOX_SX + BOX_SY + 1];
+        const float p = mixf(mixf(mixf(v000, v100, t.fxp), mixf(v010, v110, t.fxp), t.fy), mixf(mixf(v001, v101, t.fxp), mixf(v011, v111, t.fxp), t.fy), t.fz);
+        const float m = mixf(mixf(mixf(v000, v100, t.fxm), mixf(v010, v110, t.fxm), t.fy), mixf(mixf(v001, v101, t.fxm), mixf(v011, v111, t.fxm), t.fy), t.fz);
+        dx = p - m;
+    }
+#else
     dx = tri_lds(box, t.lxp * BOX_SX + by + bz, t.fxp, t.fy, t.fz) - tri_lds(box, t.lxm * BOX_SX + by + bz, t.fxm, t.fy, t.fz);
+#endif
     {   // y: the x-lerps of row ly+2 (for a +delta tap in the cell above) and of row ly-1 (a -delta tap in the cell below)
         const bool up = t.lyp != t.ly, dn = t.lym != t.ly;
         const int ru = bx + (NARROW ? (up ? t.ly + 2 : t.ly - 1) : t.ly + 2) * BOX_SY + bz;
