@@ -35,8 +35,9 @@ def as_volume(vol):
 
 def bwd_is_sanitised(vol, tf, d_vol, workspace, n):
     """True if march_bwd(vol, tf, ..., n, ..., workspace=workspace) is served by the fast kernels, which sanitise their
-    gradients themselves (dr_march_bwd_variant -- the function dr_march_bwd_rows itself asks; residual overflow case: see
-    include/differender_hip.h); False for the plain kernels, which propagate NaN like the reference and want the
+    gradients themselves (dr_march_bwd_variant -- the function dr_march_bwd_rows itself asks; finite by construction, the float
+    atomics that combine bricks saturate at +-FLT_MAX: include/differender_hip.h) -- also when the per-ray second pass ends up
+    serving the whole call (a stale workspace, a repaired wrong hint): it sanitises whenever it runs for this path; False for the plain kernels, which propagate NaN like the reference and want the
     reference's nan_to_num. n: the (views, W, H) sample-count buffer of the call."""
     if workspace is None:
         return False
