@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Counterpart of the reference's examples/test_opt_tf.py (OPT.py:32-90) on synthetic data: reconstruct a
-volume from batched views with an MSE loss against non-differentiable ground-truth renders. Same call pattern
-(`raycast.raycast_nondiff(vol_gt, tf_gt, lf, sampling_rate=8.0)`, `raycast(vol, tf, lf)`, AdamW + OneCycle,
-clamp to [0,1]); the DSSIM term and the plotting need packages that are not installed here."""
+volume from batched views with the reference's DSSIM + MSE loss (OPT.py:70-72) against non-differentiable ground-truth
+renders. Same call pattern (`raycast.raycast_nondiff(vol_gt, tf_gt, lf, sampling_rate=8.0)`, `raycast(vol, tf, lf)`,
+AdamW + OneCycle, clamp to [0,1]); `ssim2d` is this repository's restatement of pytorch_msssim.ssim (not installed here,
+semantics from memory: differender_amd/utils/losses.py); the plotting needs packages that are not installed here."""
 import os
 import sys
 
@@ -12,6 +13,7 @@ import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from differender.utils import get_tf, in_circles, get_rand_pos  # noqa: E402
 from differender.volume_raycaster import Raycaster  # noqa: E402
+from differender_amd.utils import ssim2d  # noqa: E402  (stands in for `from pytorch_msssim import ssim as ssim2d`, OPT.py:14)
 from examples.render_nondiff_synthetic import synthetic_volume  # noqa: E402
 
 if __name__ == "__main__":
@@ -35,11 +37,13 @@ if __name__ == "__main__":
             gt = raycast.raycast_nondiff(vol_gt.detach(), tf_gt.detach(), lf.detach(), sampling_rate=8.0)
         opt.zero_grad()
         res = raycast(vol, tf, lf)
-        loss = F.mse_loss(res, gt)
+        dssim_loss = 1.0 - ssim2d(res, gt, data_range=1.0, size_average=True, nonnegative_ssim=True)   # OPT.py:70
+        mse_loss = F.mse_loss(res, gt)
+        loss = torch.nan_to_num(dssim_loss) + mse_loss
         loss.backward()
         if i % 10 == 0 or i == ITERATIONS - 1:
-            print(f"Step {i:03d}:   MSE: {loss.item():0.6f}   LR: {sched.get_last_lr()[0]:.1e}   "
-                  f"Vol Grad AbsMax: {vol.grad.abs().max():.1e}")
+            print(f"Step {i:03d}:   Loss: {loss.item():0.3f}   SSIM: {1.0 - dssim_loss.item():0.3f}   MSE: {mse_loss.item():0.5f}   "
+                  f"LR: {sched.get_last_lr()[0]:.1e}   Vol Grad AbsMax: {vol.grad.abs().max():.1e}")
         first = loss.item() if first is None else first
         last = loss.item()
         opt.step(); sched.step()

@@ -300,6 +300,33 @@ def test_optimisation_loop_reduces_loss(oracle, F):
     assert losses[-1] < 0.7 * losses[0], losses
 
 
+def test_optimisation_loop_with_the_reference_loss(oracle, F):
+    """The same loop with the loss of examples/test_opt_tf.py:70-72 -- nan_to_num(1 - ssim(res, gt)) + mse -- through the torch
+    restatement of pytorch_msssim.ssim (differender_amd/utils/losses.py): both terms must go down."""
+    from differender_amd.volume_raycaster import Raycaster
+    from differender_amd.utils import dssim_mse_loss
+    N = 32
+    vol_gt = T(oracle.synth_volume(N)).permute(1, 2, 0).contiguous()[None]
+    tf = T(oracle.peaks_tf(32)).t().contiguous()
+    rc = Raycaster((N, N, N), (48, 48), 32, jitter=True, max_samples=1024)
+    torch.manual_seed(1)
+    vol = (vol_gt + 0.15 * torch.randn_like(vol_gt)).clamp(0, 1).requires_grad_(True)
+    opt = torch.optim.Adam([vol], lr=2e-2)
+    cams = T(np.stack([oracle.in_circles(0.7 * v) for v in range(4)]))
+    with torch.no_grad():
+        gt = rc.raycast_nondiff(vol_gt, tf, cams, sampling_rate=2.0)
+    hist = []
+    for it in range(12):
+        opt.zero_grad()
+        loss, dssim, mse = dssim_mse_loss(rc(vol, tf, cams), gt)
+        loss.backward()
+        opt.step()
+        with torch.no_grad():
+            vol.clamp_(0.0, 1.0)
+        hist.append((float(loss.detach()), float(dssim.detach()), float(mse.detach())))
+    assert hist[-1][0] < 0.8 * hist[0][0] and hist[-1][1] < hist[0][1] and hist[-1][2] < hist[0][2], hist
+
+
 def test_loss_epilogue_and_momentum_step(oracle, hiplib):
     """dr_mse_loss_grad / dr_tf_momentum_step vs the oracle's statement of EX.py:368-381 (bit-exact
     elementwise results; the loss sum is carried in double on both sides)."""

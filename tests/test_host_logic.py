@@ -126,3 +126,32 @@ def test_work_balanced_row_bands():
     assert sum(nr for _, nr in (shard_rows(10, k, 4, weights=np.zeros(10)) for k in range(4))) == 10
     with pytest.raises(ValueError):
         shard_rows(10, 0, 2, weights=np.ones(9))
+
+
+def test_ssim2d_restatement_against_a_direct_evaluation():
+    """differender_amd.utils.ssim2d (restating pytorch_msssim.ssim as examples/test_opt_tf.py:70 calls it; [mem], unpinned) against a
+    direct float64 numpy evaluation of the same definition; identical images give 1, the loss is differentiable."""
+    import numpy as np
+    import torch
+    from differender_amd.utils import ssim2d, dssim_mse_loss
+    rng = np.random.default_rng(3)
+    X = rng.random((2, 3, 24, 20)); Y = np.clip(X + 0.1 * rng.standard_normal(X.shape), 0, 1)
+    k = np.arange(11) - 5.0
+    w = np.exp(-k * k / (2 * 1.5 ** 2)); w /= w.sum()
+
+    def filt(a):   # valid separable convolution
+        a = np.stack([np.tensordot(w, a[:, :, i:i + 11, :], axes=(0, 2)) for i in range(a.shape[2] - 10)], axis=2)
+        return np.stack([np.tensordot(a[:, :, :, j:j + 11], w, axes=(3, 0)) for j in range(a.shape[3] - 10)], axis=3)
+
+    mu1, mu2 = filt(X), filt(Y)
+    s1, s2, s12 = filt(X * X) - mu1 ** 2, filt(Y * Y) - mu2 ** 2, filt(X * Y) - mu1 * mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    m = ((2 * mu1 * mu2 + C1) / (mu1 ** 2 + mu2 ** 2 + C1)) * ((2 * s12 + C2) / (s1 + s2 + C2))
+    want = np.maximum(m.reshape(2, 3, -1).mean(-1), 0.0).mean()
+    got = ssim2d(torch.from_numpy(X), torch.from_numpy(Y), data_range=1.0, size_average=True, nonnegative_ssim=True)
+    assert abs(float(got) - want) < 1e-12
+    assert abs(float(ssim2d(torch.from_numpy(X), torch.from_numpy(X), data_range=1.0)) - 1.0) < 1e-12
+    xt = torch.from_numpy(X).float().requires_grad_(True)
+    loss, dssim, mse = dssim_mse_loss(xt, torch.from_numpy(Y).float())
+    loss.backward()
+    assert torch.isfinite(xt.grad).all() and float(xt.grad.abs().max()) > 0 and 0 < float(dssim.detach()) < 1
