@@ -8,7 +8,7 @@ import math
 import torch
 import torch.nn.functional as F
 
-__all__ = ["get_tf", "in_circles", "get_rand_pos", "tex_from_pts"]
+__all__ = ["get_tf", "in_circles", "get_rand_pos", "tex_from_pts", "TFGenerator"]
 
 
 def tex_from_pts(pts, res):
@@ -55,6 +55,37 @@ _PRESETS = {
 }
 
 
+class TFGenerator:
+    """Stand-in for torchvtk.utils.TFGenerator as UT.py:67-70 uses it (`TFGenerator(peakgen_kwargs={'max_num_peaks': 2}).generate()`
+    -> control points for tex_from_pts): torchvtk is neither vendored by the reference nor installed here, so only the call's
+    CONTRACT is restated -- random control points (x, r, g, b, a) of 1 .. max_num_peaks trapezoid opacity peaks in the presets'
+    own format (x ascending in [0, 1], transparent between the peaks, one random colour per peak) -- not its random stream or its
+    parameter distributions [mem: unpinned; a random TF has no reference value to match]. Drawn from torch's global generator."""
+
+    def __init__(self, peakgen_kwargs=None, **_ignored):
+        kw = dict(peakgen_kwargs or {})
+        self.max_num_peaks = int(kw.get("max_num_peaks", 5))
+        self.height_range = tuple(kw.get("height_range", (0.1, 0.9)))
+        self.width_range = tuple(kw.get("width_range", (0.02, 0.2)))
+
+    def generate(self):
+        n = int(torch.randint(1, self.max_num_peaks + 1, (1,)))
+        slot = 1.0 / n                                                   # one peak per equal slice of [0, 1]: ascending x, no overlap
+        pts = [[0.0, 0.0, 0.0, 0.0, 0.0]]
+        for k in range(n):
+            w = float(torch.empty(1).uniform_(*self.width_range).clamp(max=0.8 * slot))
+            c = k * slot + 0.1 * slot + float(torch.rand(1)) * (0.8 * slot - w) + 0.5 * w
+            ramp = 0.1 * w + 1e-3
+            h = float(torch.empty(1).uniform_(*self.height_range))
+            r, g, b = (float(v) for v in torch.rand(3))
+            x0, x1 = max(c - 0.5 * w, 1e-3), min(c + 0.5 * w, 1.0 - 1e-3)
+            pts += [[x0, r, g, b, 0.0], [x0 + ramp, r, g, b, h], [max(x1 - ramp, x0 + ramp), r, g, b, h], [x1, r, g, b, 0.0]]
+        pts.append([1.0, 0.0, 0.0, 0.0, 0.0])
+        t = torch.tensor(pts, dtype=torch.float32)
+        t[:, 0] = torch.cummax(t[:, 0], 0).values                          # (guards x ascending against rounding)
+        return t
+
+
 def get_tf(id, res):
     """UT.py:7-79: (4, res) transfer-function texture for a preset name."""
     if id in _PRESETS:
@@ -67,8 +98,9 @@ def get_tf(id, res):
         return tf
     if id == "rand":
         return torch.rand(4, res)
-    if id == "generate":
-        raise NotImplementedError("'generate' needs torchvtk.utils.TFGenerator, which is out of scope (SURVEY 8(f)-2)")
+    if id == "generate":   # UT.py:67-70
+        tfgen = TFGenerator(peakgen_kwargs={"max_num_peaks": 2})
+        return tex_from_pts(tfgen.generate(), res)
     raise Exception(f"Invalid Transfer function identifier given ({id}).")
 
 

@@ -155,3 +155,23 @@ def test_ssim2d_restatement_against_a_direct_evaluation():
     loss, dssim, mse = dssim_mse_loss(xt, torch.from_numpy(Y).float())
     loss.backward()
     assert torch.isfinite(xt.grad).all() and float(xt.grad.abs().max()) > 0 and 0 < float(dssim.detach()) < 1
+
+
+def test_get_tf_generate_returns_a_random_peaked_tf():
+    """UT.py:67-70: get_tf('generate', res) = tex_from_pts(TFGenerator(max_num_peaks=2).generate(), res). torchvtk's generator is
+    not available; the stand-in keeps the contract (control points in the presets' format, 1-2 opacity peaks, values in [0, 1])."""
+    from differender_amd.utils import get_tf
+    from differender_amd.utils.utils import TFGenerator
+    torch.manual_seed(5)
+    seen = set()
+    for _ in range(20):
+        pts = TFGenerator(peakgen_kwargs={"max_num_peaks": 2}).generate()
+        assert pts.shape[1] == 5 and float(pts[0, 0]) == 0.0 and float(pts[-1, 0]) == 1.0
+        assert bool((pts[1:, 0] >= pts[:-1, 0]).all()) and float(pts.min()) >= 0.0 and float(pts.max()) <= 1.0
+        seen.add((pts.shape[0] - 2) // 4)
+        tf = get_tf("generate", 128)
+        assert tf.shape == (4, 128) and tf.dtype == torch.float32 and 0.0 < float(tf[3].max()) <= 0.9
+        assert float(tf[3, 0]) == 0.0 and float(tf[3, -1]) == 0.0
+    assert seen == {1, 2}
+    with pytest.raises(Exception, match="Invalid Transfer function identifier"):
+        get_tf("nope", 16)
