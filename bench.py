@@ -114,8 +114,11 @@ def parse_args(argv=None):
     ap.add_argument("--hints", default="auto", choices=["auto", "off"],
                     help="caller hints of dr_march_fwd (DR_HINT_*): 'auto' = derived from the TF's largest alpha once it is "
                          "known (functional._TerminationHints, no host sync); 'off' = never")
-    ap.add_argument("--no-dssim", action="store_true",
-                    help="opt workload: MSE only (rounds 1-3; the reference's loss is DSSIM + MSE, examples/test_opt_tf.py:70-72: the default)")
+    ap.add_argument("--dssim", action="store_true",
+                    help="opt workload: the reference's full loss, DSSIM + MSE (examples/test_opt_tf.py:70-72), through the torch "
+                         "restatement of pytorch_msssim.ssim (differender_amd/utils/losses.py): +2.7 ms per iteration of torch "
+                         "convolutions outside the raycasting path. Default: MSE only, as every round measured the loop")
+    ap.add_argument("--no-dssim", action="store_true", help="(default; kept for tools/abn_opt.sh)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-img", type=int, default=None,
                     help="image edge of the CPU-baseline sample (default: the whole view, capped at 512: ~20 s on 16 cores)")
@@ -643,9 +646,9 @@ def main():
 # ------------------------------------------------------------------------------------------------ the demo loop
 def main_opt(args):
     """examples/test_opt_tf.py:33-88 on synthetic data, through the drop-in module: per iteration 8 camera positions, a
-    non-differentiable ground-truth render at sampling rate 8, the jittered differentiable render, DSSIM + MSE loss
-    (OPT.py:70-72; the SSIM is this repository's torch restatement of pytorch_msssim.ssim, which is not installed here;
-    --no-dssim: MSE only, as rounds 1-3 measured it), backward to volume and TF, AdamW + OneCycle step, clamp. This is what dropping the library into the reference's script costs end to end, host glue included."""
+    non-differentiable ground-truth render at sampling rate 8, the jittered differentiable render, MSE loss (--dssim: the
+    reference's DSSIM + MSE, OPT.py:70-72, through this repository's torch restatement of pytorch_msssim.ssim, which is
+    not installed here: +2.7 ms of torch convolutions per iteration), backward to volume and TF, AdamW + OneCycle step, clamp. This is what dropping the library into the reference's script costs end to end, host glue included."""
     N = args.vol or 256
     IMG = args.img or 256
     R = args.tf_res or 128
@@ -688,7 +691,7 @@ def main_opt(args):
         res = raycast(vol, tf, lf)
         fw_steps = raycast.vr._steps.sum()
         t2 = mark()
-        if args.no_dssim:
+        if not args.dssim:
             loss = torch.nn.functional.mse_loss(res, gt)
         else:   # OPT.py:70-72 (ssim2d: this repository's restatement of pytorch_msssim.ssim, differender_amd/utils/losses.py)
             loss = dssim_mse_loss(res, gt)[0]
@@ -741,7 +744,7 @@ def main_opt(args):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"OPT demo: {N}^3 f32 volume (5 % voxels randomised), {IMG}^2 image, {BS} views per iteration "
                                f"(1 orbit + {BS - 1} random, r=2.7), tf1 with {R} entries, max_samples=1024, jitter on; per "
-                               "iteration: nondiff GT render at sr 8, differentiable render at sr 1, " + ("MSE" if args.no_dssim else "DSSIM + MSE") + ", backward to volume "
+                               "iteration: nondiff GT render at sr 8, differentiable render at sr 1, " + ("DSSIM + MSE" if args.dssim else "MSE") + ", backward to volume "
                                "and TF, AdamW + OneCycleLR step, clamp",
                    "volume": N, "image": IMG, "tf_res": R, "views": BS},
         "mvoxel_steps_per_s": round(int(nsteps.item()) / elapsed / 1e6, 1),

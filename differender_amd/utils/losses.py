@@ -32,11 +32,14 @@ def ssim2d(X, Y, data_range=255.0, size_average=True, win_size=11, win_sigma=1.5
         raise ValueError("ssim2d expects two (N, C, H, W) tensors of the same shape")
     win = _gauss_window(win_size, win_sigma, X.dtype, X.device)
     C1, C2 = (K[0] * data_range) ** 2, (K[1] * data_range) ** 2
-    mu1, mu2 = _filter(X, win), _filter(Y, win)
+    c = X.shape[1]
+    # the five windowed moments in ONE pair of grouped convolutions (channels stacked): two launches forward, two backward
+    m = _filter(torch.cat([X, Y, X * X, Y * Y, X * Y], dim=1), win)
+    mu1, mu2 = m[:, :c], m[:, c:2 * c]
     mu1_sq, mu2_sq, mu12 = mu1 * mu1, mu2 * mu2, mu1 * mu2
-    s1 = _filter(X * X, win) - mu1_sq
-    s2 = _filter(Y * Y, win) - mu2_sq
-    s12 = _filter(X * Y, win) - mu12
+    s1 = m[:, 2 * c:3 * c] - mu1_sq
+    s2 = m[:, 3 * c:4 * c] - mu2_sq
+    s12 = m[:, 4 * c:] - mu12
     cs = (2.0 * s12 + C2) / (s1 + s2 + C2)
     ssim_map = ((2.0 * mu12 + C1) / (mu1_sq + mu2_sq + C1)) * cs
     per_channel = ssim_map.flatten(2).mean(-1)
