@@ -272,11 +272,14 @@ def _dominant_kernel(pm, want_bwd_kernel):
     return None, None
 
 
-# Issue cost of a VALU wave-instruction on gfx950 with four waves on the SIMD (tools/microbench/oprate_bench,
-# profiles/r02_microbench_oprate.txt): f32 add / mul / fma, v_mov, v_add_u32, v_ashrrev 2.6 cycles; every other class (min / max,
-# compares, conversions, v_fract, v_cndmask, DPP, shifts, 3-operand integer ops) 4.5. Share of the first class in the hot loops,
-# from the listings (tools/isa_hist.py, blocks of the per-sample loop + the per-pass scan): forward 0.70, backward 0.43.
-VALU_COST_FAST, VALU_COST_SLOW = 2.6, 4.5
+# Issue cost of a VALU wave-instruction on gfx950, in SHADER CLOCKS (what GRBM_GUI_ACTIVE counts). tools/microbench/oprate_bench
+# (profiles/r02_microbench_oprate.txt, four waves per SIMD) reports 2.6-3.0 "cycles" for f32 add / mul / fma, v_mov, v_add_u32,
+# v_ashrrev and 4.3-4.7 for every other class (min / max, compares, conversions, v_fract, v_cndmask, DPP, shifts, 3-operand integer
+# ops) -- in units of the NOMINAL 2.4 GHz clock. A 64-lane instruction of the second class occupies a 16-lane SIMD for exactly
+# 4 clocks, so the chip ran that benchmark at 2.4 x 4 / 4.5 = 2.13 GHz (the counters put these kernels at 2.1-2.2 GHz too) and the
+# costs in real clocks are 4.0 and 2.3-2.7 (2.4 for the kernels' mix of mov / add / mul / fma). Share of the first class in the
+# hot loops, from the listings (tools/isa_hist.py, blocks of the per-sample loop + the per-pass scan): forward 0.70, backward 0.43.
+VALU_COST_FAST, VALU_COST_SLOW = 2.4, 4.0
 VALU_FAST_SHARE = {False: 0.70, True: 0.43}
 N_SIMD, N_CU, N_XCD = 1024, 256, 8
 
@@ -307,9 +310,10 @@ def valu_roofline(pm, want_bwd_kernel, steps_per_launch):
             "waves_per_simd": round(4.0 * wc / N_SIMD / clocks, 2),
             "wave_time_split": {"parked_waitcnt_or_barrier": round(v.get("SQ_WAIT_ANY", 0.0) / wc, 3),
                                 "issue_stalled": round(v.get("SQ_WAIT_INST_ANY", 0.0) / wc, 3)},
-            "note": "issue_slot_utilisation = (share of full-rate VALU x 2.6 + rest x 4.5 clocks, measured issue costs and the "
-                    "static mix of the hot loop) / observed clocks per VALU wave-instruction per SIMD; the HBM fractions in "
-                    "`roofline` price a kernel that is bound HERE"}
+            "note": "issue_slot_utilisation = (share of full-rate VALU x 2.4 + rest x 4.0 shader clocks: measured issue costs and "
+                    "the static mix of the hot loop) / observed clocks per VALU wave-instruction per SIMD, capped at 1; "
+                    "issue_slot_utilisation_if_all_full_rate is the floor no mix can go below; the HBM fractions in `roofline` "
+                    "price a kernel that is bound HERE (and, in the backward, by its LDS atomics)"}
 
 
 def traffic_bytes(pm, want_bwd_kernel):
