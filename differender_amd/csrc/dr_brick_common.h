@@ -309,19 +309,10 @@ struct TapCoords {
     float fxp, fxm, fyp, fym, fzp, fzm;
 };
 
-// Centre tap and the six normal taps from the LDS box (two halves, so that the normal taps can be skipped when no
-// lane needs the lighting term).
-__device__ __forceinline__ float sample_centre_lds(const float *box, const TapCoords &t) {
-    return tri_lds(box, t.lx * BOX_SX + t.ly * BOX_SY + t.lz, t.fx, t.fy, t.fz);
-}
-__device__ __forceinline__ void sample_normal_taps_lds(const float *box, const TapCoords &t, float &dx, float &dy, float &dz) {
-    const int by = t.ly * BOX_SY, bz = t.lz, bx = t.lx * BOX_SX;
-    dx = tri_lds(box, t.lxp * BOX_SX + by + bz, t.fxp, t.fy, t.fz) - tri_lds(box, t.lxm * BOX_SX + by + bz, t.fxm, t.fy, t.fz);
-    dy = tri_lds(box, bx + t.lyp * BOX_SY + bz, t.fx, t.fyp, t.fz) - tri_lds(box, bx + t.lym * BOX_SY + bz, t.fx, t.fym, t.fz);
-    dz = tri_lds(box, bx + by + t.lzp, t.fx, t.fy, t.fzp) - tri_lds(box, bx + by + t.lzm, t.fx, t.fy, t.fzm);
-}
-
-// ---- The same seven taps with SHARED partial lerps (round 4) ------------------------------------------------------------
+// Centre tap and the six normal taps from the LDS box, in two halves (the normal taps are skipped when no lane needs the
+// lighting term). Until round 4 these were seven independent tri_lds() calls -- 56 LDS words and 49 lerps per sample; the
+// arithmetic of each tap is unchanged below, the taps now share what they have in common.
+// ---- Seven taps with SHARED partial lerps (round 4) -----------------------------------------------------------------------
 // The reference interpolates x -> y -> z (VR.py:173-189). The +-delta taps along y keep the centre tap's x cell and x
 // fraction, so their four x-lerps are -- bit for bit -- the centre's own (rows ly, ly+1) plus, when the tap has crossed into the
 // neighbouring cell, ONE more row (ly+2 or ly-1); the taps along z keep x and y, so their two bilinear planes are the centre's
