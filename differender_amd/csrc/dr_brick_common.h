@@ -339,28 +339,30 @@ __device__ __forceinline__ float sample_centre_lds_keep(const float *box, const 
 template <bool NARROW>
 __device__ __forceinline__ void sample_normal_taps_shared_lds(const float *box, const TapCoords &t, const CentreLerps &c,
                                                               float &dx, float &dy, float &dz) {
-    const int by = t.ly * BOX_SY, bz = t.lz, bx = t.lx * BOX_SX;
-    // x: as before
+    // every address is the centre's plus a per-lane constant: the taps sit in the centre's cell or in the one next to it
+    // (delta < 1 voxel), so a select + an add replaces the multiply-add chain per tap
+    const int base = t.lx * BOX_SX + t.ly * BOX_SY + t.lz;
+    {   // x: two whole taps (their first lerp has its own fraction: nothing of the centre's is reusable but the voxels)
 #ifdef DR_ABL_XREUSE
-    {   // what-if (WRONG results): both x taps from ONE set of eight voxels, no select -- the bound for reusing the centre's voxels
-        const int b0_ = bx + by + bz;
-        const float v000 = box[b0_], v100 = box[b0_ + BOX_SX], v010 = box[b0_ + BOX_SY], v110 = box[b0_ + BOX_SX + BOX_SY];
-        const float v001 = box[b0_ + 1], v101 = box[b0_ + BOX_SX + 1], v011 = box[b0_ + BOX_SY + 1], v111 = box[b0_ + BOX_SX + BOX_SY + 1];
+        // what-if (WRONG results): both x taps from ONE set of eight voxels, no select -- the bound for reusing the centre's voxels
+        const float v000 = box[base], v100 = box[base + BOX_SX], v010 = box[base + BOX_SY], v110 = box[base + BOX_SX + BOX_SY];
+        const float v001 = box[base + 1], v101 = box[base + BOX_SX + 1], v011 = box[base + BOX_SY + 1], v111 = box[base + BOX_SX + BOX_SY + 1];
         const float p = mixf(mixf(mixf(v000, v100, t.fxp), mixf(v010, v110, t.fxp), t.fy), mixf(mixf(v001, v101, t.fxp), mixf(v011, v111, t.fxp), t.fy), t.fz);
         const float m = mixf(mixf(mixf(v000, v100, t.fxm), mixf(v010, v110, t.fxm), t.fy), mixf(mixf(v001, v101, t.fxm), mixf(v011, v111, t.fxm), t.fy), t.fz);
         dx = p - m;
-    }
 #else
-    dx = tri_lds(box, t.lxp * BOX_SX + by + bz, t.fxp, t.fy, t.fz) - tri_lds(box, t.lxm * BOX_SX + by + bz, t.fxm, t.fy, t.fz);
+        const int ip = base + ((t.lxp != t.lx) ? BOX_SX : 0), im = base - ((t.lxm != t.lx) ? BOX_SX : 0);
+        dx = tri_lds(box, ip, t.fxp, t.fy, t.fz) - tri_lds(box, im, t.fxm, t.fy, t.fz);
 #endif
+    }
     {   // y: the x-lerps of row ly+2 (for a +delta tap in the cell above) and of row ly-1 (a -delta tap in the cell below)
         const bool up = t.lyp != t.ly, dn = t.lym != t.ly;
-        const int ru = bx + (NARROW ? (up ? t.ly + 2 : t.ly - 1) : t.ly + 2) * BOX_SY + bz;
+        const int ru = base + (NARROW ? (up ? 2 * BOX_SY : -BOX_SY) : 2 * BOX_SY);
         const float u0 = mixf(box[ru], box[ru + BOX_SX], t.fx);
         const float u1 = mixf(box[ru + 1], box[ru + BOX_SX + 1], t.fx);
         float d0 = u0, d1 = u1;
         if (!NARROW) {
-            const int rd = bx + (t.ly - 1) * BOX_SY + bz;
+            const int rd = base - BOX_SY;
             d0 = mixf(box[rd], box[rd + BOX_SX], t.fx);
             d1 = mixf(box[rd + 1], box[rd + BOX_SX + 1], t.fx);
         }
@@ -370,11 +372,11 @@ __device__ __forceinline__ void sample_normal_taps_shared_lds(const float *box, 
     }
     {   // z: the bilinear planes lz+2 and lz-1
         const bool up = t.lzp != t.lz, dn = t.lzm != t.lz;
-        const int pu = bx + by + (NARROW ? (up ? t.lz + 2 : t.lz - 1) : t.lz + 2);
+        const int pu = base + (NARROW ? (up ? 2 : -1) : 2);
         const float zu = mixf(mixf(box[pu], box[pu + BOX_SX], t.fx), mixf(box[pu + BOX_SY], box[pu + BOX_SX + BOX_SY], t.fx), t.fy);
         float zd = zu;
         if (!NARROW) {
-            const int pd = bx + by + t.lz - 1;
+            const int pd = base - 1;
             zd = mixf(mixf(box[pd], box[pd + BOX_SX], t.fx), mixf(box[pd + BOX_SY], box[pd + BOX_SX + BOX_SY], t.fx), t.fy);
         }
         const float p = mixf(up ? c.zh : c.zl, up ? zu : c.zh, t.fzp);
