@@ -113,8 +113,13 @@ def test_whole_view_parity_with_oracle(scene, oracle, tfname):
     dv_h = dv.cpu().numpy(); del dv
     err_v = np.abs(dv_h - dv_ref).max() / np.abs(dv_ref).max()
     err_t = np.abs(dt.cpu().numpy() - dt_ref).max() / np.abs(dt_ref).max()
-    print(f"whole view [{tfname}]: {int(st.sum())} voxel-steps, d_vol rel err {err_v:.2e} over {dv_ref.size} voxels, d_tf rel err {err_t:.2e}")
-    assert err_v <= 1e-4 and err_t <= 1e-4
+    # config C3's kernel (the backward w.r.t. the TF alone: no gradient box, two samples per lane) on the same whole view
+    _, dt_only = F.march_bwd(scene["vol"], tf, scene["cam"], *scene["rays"], 1 << 20, 1.0, g.to(scene["dev"]), out,
+                             want_vol=False, want_tf=True, workspace=ws)
+    err_t_only = np.abs(dt_only.cpu().numpy() - dt_ref).max() / np.abs(dt_ref).max()
+    print(f"whole view [{tfname}]: {int(st.sum())} voxel-steps, d_vol rel err {err_v:.2e} over {dv_ref.size} voxels, d_tf rel err {err_t:.2e}"
+          f" (TF-only backward {err_t_only:.2e})")
+    assert err_v <= 1e-4 and err_t <= 1e-4 and err_t_only <= 1e-4
 
 
 @pytest.mark.parametrize("tfname", ["bench", "tf1"])
