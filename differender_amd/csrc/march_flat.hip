@@ -1426,6 +1426,12 @@ __global__ __launch_bounds__((FlatCfg<BWD, WANT_VOL>::FNT), (FlatCfg<BWD, WANT_V
 }
 
 // ------------------------------------------------------------------------------------------------ host
+// This file is compiled TWICE (Makefile): as march_flat.o -- everything but the backward with a gradient box -- and, through
+// march_flat_bwdvol.hip (which defines DR_FLAT_TU_BWDVOL and includes it), as the translation unit of that one kernel family,
+// B1, built with -mllvm -amdgpu-sched-strategy=iterative-minreg: the scheduler strategy is a per-compilation switch, B1
+// (128 VGPRs, its waves parked 40 % of their lifetime) gains 2.5 % from it, the forward and the TF-only backward lose 2-4 %
+// (profiles/r04_ab_experiments.txt). Kernel templates are instantiated where they are launched, so each object holds its own.
+#ifndef DR_FLAT_TU_BWDVOL
 // in-box element offsets are computed in 32 bits: 3 * (BOX-1) * max|stride| must stay below 2^31
 bool flat_strides_ok(int64_t sx, int64_t sy, int64_t sz) {
     const int64_t lim = ((int64_t)1 << 31) / (3 * BOX);
@@ -1440,6 +1446,8 @@ bool brick_path_supported(int VX, int VY, int VZ, int R) {
     if (m - 1 >= 2000) return false;       // normal taps must stay within one voxel of the centre cell
     return flat_lds_bytes<true>(R, true, true) <= 160 * 1024;
 }
+
+#endif  // !DR_FLAT_TU_BWDVOL
 
 static inline bool taps_narrow(const MarchArgs &a) {
     const int m = a.VX > a.VY ? (a.VX > a.VZ ? a.VX : a.VZ) : (a.VY > a.VZ ? a.VY : a.VZ);
@@ -1468,6 +1476,22 @@ static inline bool taps_narrow(const MarchArgs &a) {
         if ((ALPHA_) || taps_narrow(a)) DR_LAUNCH_BOTH_N(MODE_, BWD_, VOL_, TF_, ALPHA_, K_, NT_, true)                              \
         else DR_LAUNCH_BOTH_N(MODE_, BWD_, VOL_, TF_, ALPHA_, K_, NT_, false)                                                         \
     }
+
+// B1 (the backward with a gradient box), launched from its own translation unit
+template <typename VT>
+int flat_bwd_vol_launch(const MarchArgs &a, BrickParams<VT> P, dim3 grid1, size_t lds, bool want_tf, hipStream_t stream);
+
+#ifdef DR_FLAT_TU_BWDVOL
+template <typename VT>
+int flat_bwd_vol_launch(const MarchArgs &a, BrickParams<VT> P, dim3 grid1, size_t lds, bool want_tf, hipStream_t stream) {
+    hipError_t e = hipSuccess;
+    if (want_tf) DR_LAUNCH_BOTH(DR_MODE_DIFF, true, true, true, false, 1, (FlatCfg<true, true>::FNT))
+    else DR_LAUNCH_BOTH(DR_MODE_DIFF, true, true, false, false, 1, (FlatCfg<true, true>::FNT))
+    return (int)hipGetLastError();
+}
+template int flat_bwd_vol_launch<float>(const MarchArgs &, BrickParams<float>, dim3, size_t, bool, hipStream_t);
+template int flat_bwd_vol_launch<__half>(const MarchArgs &, BrickParams<__half>, dim3, size_t, bool, hipStream_t);
+#else
 
 template <typename VT>
 static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
@@ -1569,9 +1593,10 @@ static int flat_bwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     const dim3 grid1(g.NBx * g.NBy * g.NBz, a.n_views);
     hipError_t e = hipSuccess;
     // (the brick records, live flags and work items are the forward's: same inputs, same workspace)
-    if (wv && wt) DR_LAUNCH_BOTH(DR_MODE_DIFF, true, true, true, false, 1, (FlatCfg<true, true>::FNT))
-    else if (wv) DR_LAUNCH_BOTH(DR_MODE_DIFF, true, true, false, false, 1, (FlatCfg<true, true>::FNT))
-    else DR_LAUNCH_BOTH(DR_MODE_DIFF, true, false, true, false, 1, (FlatCfg<true, false>::FNT))
+    if (wv) {   // B1: march_flat_bwdvol.o
+        const int rc = flat_bwd_vol_launch<VT>(a, P, grid1, lds, wt, stream);
+        if (rc) return rc;
+    } else DR_LAUNCH_BOTH(DR_MODE_DIFF, true, false, true, false, 1, (FlatCfg<true, false>::FNT))
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
     MarchArgs b = a;
     b.only_flagged = w.rayflag;  // B2: irregular rays through the baseline backward (every ray, if the workspace is not this call's)
@@ -1582,5 +1607,6 @@ static int flat_bwd_dispatch(const MarchArgs &a, hipStream_t stream) {
 int launch_march_bwd_flat(const MarchArgs &a, hipStream_t stream) {
     return a.vol_dtype == DR_F16 ? flat_bwd_dispatch<__half>(a, stream) : flat_bwd_dispatch<float>(a, stream);
 }
+#endif  // DR_FLAT_TU_BWDVOL
 
 }  // namespace dr
