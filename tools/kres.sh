@@ -3,7 +3,7 @@
 #   usage: tools/kres.sh march_flat [extra hipcc flags...]
 F=$1; shift
 cd "$(dirname "$0")/../differender_amd/csrc"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -munsafe-fp-atomics -ffp-contract=off -fno-slp-vectorize "$@" \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -munsafe-fp-atomics -ffp-contract=off -fno-slp-vectorize -mllvm -disable-machine-licm "$@" \
   -Rpass-analysis=kernel-resource-usage -c $F.hip -o /dev/null 2>&1 | python3 -c "
 import re, sys
 cur = {}

@@ -5,7 +5,7 @@ set -e
 name=$1; shift
 src=differender_amd/csrc; out=ab_libs/obj_$name
 mkdir -p $out
-COMMON="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -munsafe-fp-atomics -ffp-contract=off -fno-slp-vectorize"
+COMMON="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -munsafe-fp-atomics -ffp-contract=off -fno-slp-vectorize ${NO_LICM_FLAG--mllvm -disable-machine-licm}"
 pids=()
 for f in capi ray_setup march_baseline ray_passes march_flat epilogue collective; do
   /opt/rocm/bin/hipcc $COMMON "$@" -c $src/$f.hip -o $out/$f.o & pids+=($!)
