@@ -10,9 +10,10 @@ pids=()
 for f in capi ray_setup march_baseline ray_passes march_flat epilogue collective; do
   /opt/rocm/bin/hipcc $COMMON "$@" -c $src/$f.hip -o $out/$f.o & pids+=($!)
 done
-# B1 in its own translation unit, with its own scheduler strategy (Makefile); BWDVOL_SCHED=default builds it like the rest
+# B1 in its own translation unit, with its own scheduler strategy (Makefile); BWDVOL_SCHED=default builds it like the rest;
+# BWDVOL_EXTRA="-D..." adds switches to that translation unit only
 if [ "${BWDVOL_SCHED:-iterative-minreg}" = default ]; then SCHED=""; else SCHED="-mllvm -amdgpu-sched-strategy=${BWDVOL_SCHED:-iterative-minreg}"; fi
-/opt/rocm/bin/hipcc $COMMON $SCHED "$@" -c $src/march_flat_bwdvol.hip -o $out/march_flat_bwdvol.o & pids+=($!)
+/opt/rocm/bin/hipcc $COMMON $SCHED "$@" $BWDVOL_EXTRA -c $src/march_flat_bwdvol.hip -o $out/march_flat_bwdvol.o & pids+=($!)
 for p in "${pids[@]}"; do wait $p; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ab_libs/$name.so $out/*.o -ldl
 rm -rf $out
