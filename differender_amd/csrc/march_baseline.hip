@@ -87,14 +87,15 @@ __device__ __forceinline__ float finite_or_zero(float x) { return (x == x) ? fmi
 
 template <typename VT>
 __global__ __launch_bounds__(256) void march_bwd_baseline_kernel(MarchParams<VT> P) {
-    extern __shared__ __attribute__((aligned(16))) float4 lds_tf[];  // [R] TF, then [R] dTF accumulators
+    // [R] TF, then [R][4] dTF accumulators in DOUBLE: thousands of samples of a workgroup land on a few texels (all of them on
+    // one when R = 1), and f32 atomics in thread order put 1e-3 of summation noise on d_tf at sampling rate 16 (fuzz seed 603239,
+    // round 4); the oracle sums d_tf in double for the same reason (oracle/dr_oracle_impl.inc), so this keeps the twin a twin
+    extern __shared__ __attribute__((aligned(16))) float4 lds_tf[];
     const int view = blockIdx.y;
     const float4 *tfg = P.tf + view * P.tf_vs;
-    float *lds_dtf = reinterpret_cast<float *>(lds_tf + P.R);
-    for (int k = threadIdx.x; k < P.R; k += 256) {
-        lds_tf[k] = tfg[k];
-        lds_tf[P.R + k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    double *lds_dtf = reinterpret_cast<double *>(lds_tf + P.R);
+    for (int k = threadIdx.x; k < P.R; k += 256) lds_tf[k] = tfg[k];
+    for (int k = threadIdx.x; k < 4 * P.R; k += 256) lds_dtf[k] = 0.0;
     __syncthreads();
 
     int i, j;
@@ -156,11 +157,11 @@ __global__ __launch_bounds__(256) void march_bwd_baseline_kernel(MarchParams<VT>
 
             if (want_tf) {
                 const float w0 = 1.0f - sm.fr, w1 = sm.fr;
-                float *d0 = lds_dtf + 4 * sm.lo, *d1 = lds_dtf + 4 * sm.hi;
-                atomicAdd(d0 + 0, w0 * ad.r_bar); atomicAdd(d0 + 1, w0 * ad.g_bar);
-                atomicAdd(d0 + 2, w0 * ad.b_bar); atomicAdd(d0 + 3, w0 * ad.a_bar);
-                atomicAdd(d1 + 0, w1 * ad.r_bar); atomicAdd(d1 + 1, w1 * ad.g_bar);
-                atomicAdd(d1 + 2, w1 * ad.b_bar); atomicAdd(d1 + 3, w1 * ad.a_bar);
+                double *d0 = lds_dtf + 4 * sm.lo, *d1 = lds_dtf + 4 * sm.hi;   // (the products are f32, as in the oracle)
+                atomicAdd(d0 + 0, (double)(w0 * ad.r_bar)); atomicAdd(d0 + 1, (double)(w0 * ad.g_bar));
+                atomicAdd(d0 + 2, (double)(w0 * ad.b_bar)); atomicAdd(d0 + 3, (double)(w0 * ad.a_bar));
+                atomicAdd(d1 + 0, (double)(w1 * ad.r_bar)); atomicAdd(d1 + 1, (double)(w1 * ad.g_bar));
+                atomicAdd(d1 + 2, (double)(w1 * ad.b_bar)); atomicAdd(d1 + 3, (double)(w1 * ad.a_bar));
             }
             if (want_vol) {
                 tri_scatter_global(vol, dv, sm.px, sm.py, sm.pz, I_bar);
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(256) void march_bwd_baseline_kernel(MarchParams<VT>
         __syncthreads();
         float *dtf = P.d_tf + view * P.dtf_vs * 4;
         for (int k = threadIdx.x; k < 4 * P.R; k += 256) {
-            const float v = lds_dtf[k];
+            const float v = (float)lds_dtf[k];
             if (v == 0.0f) continue;
             if (P.only_flagged) atomic_add_sat(dtf + k, v);  // second pass of the sanitising backward: the sum stays finite
             else unsafeAtomicAdd(dtf + k, v);
@@ -242,8 +243,8 @@ int launch_march_fwd_baseline(const MarchArgs &a, hipStream_t stream) {
 
 template <typename VT>
 static int bwd_dispatch(const MarchArgs &a, hipStream_t stream) {
-    const size_t lds = 2 * (size_t)a.R * sizeof(float4);
-    if (lds > 160 * 1024) return DR_EUNSUPPORTED;  // TF + its gradient table in LDS (R <= 5120)
+    const size_t lds = (size_t)a.R * (sizeof(float4) + 4 * sizeof(double));
+    if (lds > 160 * 1024) return DR_EUNSUPPORTED;  // TF + its double-precision gradient table in LDS (R <= 3413)
     MarchParams<VT> P = make_params<VT>(a);
     if (big_lds(march_bwd_baseline_kernel<VT>, lds) != hipSuccess) return DR_EUNSUPPORTED;
     hipLaunchKernelGGL((march_bwd_baseline_kernel<VT>), tile_grid(a), dim3(256), lds, stream, P);

@@ -142,7 +142,7 @@ def test_whole_gradient_tensor_matches_sequential_kernels(scene, tfname):
     db, dtb = F.march_bwd(scene["vol"], tf, scene["cam"], *scene["rays"], 1 << 20, 1.0, g, outb, variant=1)
     sv, st = float(db.abs().max()), float(dtb.abs().max())
     assert float((dv - db).abs().max()) <= 2e-5 * sv
-    assert float((dt - dtb).abs().max()) <= 1e-4 * st     # (the sequential kernels add d_tf with float atomics: their noise)
+    assert float((dt - dtb).abs().max()) <= 2e-5 * st     # (both accumulate d_tf in double; what is left is the float atomics across workgroups)
 
 
 def test_backward_linearity_and_stability(scene):
@@ -357,7 +357,7 @@ def test_ct_like_scene_needs_no_repairs(scene):
     dv, dt = F.march_bwd(vol, tf, scene["cam"], *scene["rays"], 1 << 20, 1.0, g, out, workspace=ws)
     db, dtb = F.march_bwd(vol, tf, scene["cam"], *scene["rays"], 1 << 20, 1.0, g, outb, variant=1)
     assert float((dv - db).abs().max()) <= 2e-5 * float(db.abs().max())
-    # d_tf: texel 0 collects the alpha adjoints of every sample in the air (intensity exactly 0: 1e8 contributions of either sign);
-    # the sequential kernels sum them with float atomics -- 1e-3 of rounding noise there -- the fast path in double
-    assert float((dt - dtb)[1:].abs().max()) <= 1e-4 * float(dtb[1:].abs().max())
-    assert float((dt - dtb)[0].abs().max()) <= 3e-3 * float(dtb[0].abs().max())
+    # d_tf: texel 0 collects the alpha adjoints of every sample in the air (intensity exactly 0: 1e8 contributions of either sign).
+    # (Until round 4 the sequential kernels summed d_tf with f32 LDS atomics and carried 1e-3 of rounding noise on that texel;
+    # they accumulate in double now, like the oracle and the fast path.)
+    assert float((dt - dtb).abs().max()) <= 2e-5 * float(dtb.abs().max())

@@ -11,6 +11,8 @@ What the listed seeds pinned down ("What the fuzzer found"):
   20228, 23671, 26708  a sample on a kink of the lighting model (Lraw within 1e-5 of the clamp at 1): D7
   1108, 1116, 2440     a ray parallel to a slab it lies outside of: NaN sample count, defined as 0
   56, 90, 3255         alpha == 1 at a sampling rate != 1: infinite reference gradient, kernels stay finite
+  603239               (round 4) one TF texel, sampling rate 16, the SEQUENTIAL kernels: their f32 LDS atomics put 1e-3 of summation noise on
+                       d_tf (the oracle sums d_tf in double); they accumulate in double now
 """
 import importlib.util
 import os
@@ -22,7 +24,7 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REGRESSION_SEEDS = [1, 28, 56, 90, 113, 177, 603, 759, 826, 1108, 1116, 1246, 1310, 2430, 2440, 2552, 2571, 3255,
-                    20228, 21150, 23557, 23646, 23671, 26708]
+                    20228, 21150, 23557, 23646, 23671, 26708, 603239]
 
 
 @pytest.fixture(scope="module")
