@@ -1,6 +1,7 @@
-"""BASELINE.json's full size (512^3 f32 volume, 512^2 image, 256-entry TF) on the GPU: oracle parity on
-pixel patches (the oracle is too slow for the whole image) plus size-independent properties: sample-count
-conservation, agreement of independent kernel variants, linearity of the backward, run-to-run stability."""
+"""BASELINE.json's full sizes on the GPU. The 512^3 / 512^2 configurations (C2, C3, C4) are compared with the OpenMP oracle on
+the WHOLE view (every ray, every voxel; ~16 s per view on the box's cores); the 1024^3 f16 configuration (C5) on a centred
+256x256 crop of its 1024^2 view. On top: size-independent properties - sample-count conservation, agreement of independent
+kernel variants, linearity of the backward, run-to-run stability."""
 import os
 import sys
 
