@@ -316,6 +316,21 @@ def valu_roofline(pm, want_bwd_kernel, steps_per_launch):
                     "price a kernel that is bound HERE (and, in the backward, by its LDS atomics)"}
 
 
+def observed_bound(vr, hbm_frac_measured):
+    """Name of what limits a brick kernel according to ITS counters (roofline_valu block vr): VALU issue slots (>= 80 % full
+    against the two-class issue-cost model), the LDS (array >= 45 % busy: in the backward that is its atomics), HBM only if the
+    memory side is the busiest of the three. The HBM *model* fraction stays in `frac`."""
+    parts = []
+    if vr["issue_slot_utilisation"] >= 0.8:
+        parts.append("valu-issue")
+    if vr["lds_array_busy"] >= 0.45:
+        targs = [t.strip(" >") for t in vr["kernel"].split("<")[1].split(",")]  # <VT, MODE, BWD, VOL, TF, ALPHA, K, NARROW>
+        parts.append("lds-atomics" if len(targs) > 2 and targs[2] == "true" else "lds")
+    if hbm_frac_measured is not None and hbm_frac_measured >= max(0.6, vr["issue_slot_utilisation"]):
+        parts = ["hbm"]
+    return "+".join(parts) if parts else "latency (no unit above 80 % / 45 % busy)"
+
+
 def traffic_bytes(pm, want_bwd_kernel):
     """HBM-side bytes per launch of the forward / backward brick kernel from a per-launch counter table.
     FETCH_SIZE counts 128-B fabric requests at 64 B on gfx950: doubled, as the MI355X guide prescribes (calibrated on
@@ -571,8 +586,12 @@ def main():
 
     def roof(name, ms, bytes_per_step):
         ach = steps_per_launch * bytes_per_step / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        return {"kernel": name, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "hbm_gbs_measured": None, "hbm_frac_measured": None,
+        # `bound` is what the counters show once they are in (set below from roofline_valu); `frac` stays the MODEL fraction
+        # north_star prices this path with (algorithmic bytes / time / HBM peak) and says so in `frac_kind`
+        return {"kernel": name, "bound": "valu-issue (as profiled in profiles/; not re-measured in this run)", "model_bound": "hbm",
+                "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 5), "frac_kind": "model: algorithmic bytes / time / HBM peak",
+                "traffic": None, "hbm_gbs_measured": None, "hbm_frac_measured": None,
                 "avg_launch_ms": round(ms, 4), "bytes_per_voxel_step": bytes_per_step,
                 "voxel_steps_per_launch": int(steps_per_launch),
                 "note": "achieved/frac price the ALGORITHMIC bytes (model); hbm_gbs_measured = traffic / avg_launch is what "
@@ -604,6 +623,9 @@ def main():
     dominant = roof_bwd if (roof_bwd and bwd_ms >= fwd_ms) else roof_fwd
     valu_fwd = valu_roofline(pm, False, steps_per_launch) if pm else None
     valu_bwd = valu_roofline(pm, True, steps_per_launch) if (pm and want_bwd) else None
+    for rf, vr in ((roof_fwd, valu_fwd), (roof_bwd, valu_bwd)):
+        if rf is not None and vr is not None:
+            rf["bound"] = observed_bound(vr, rf.get("hbm_frac_measured"))
 
     cpu_baseline = None
     if world == 1 and not args.no_cpu_baseline:
@@ -619,7 +641,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4),
         "higher_is_better": True, "scaling": "strong" if bands else "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32" if args.vol_dtype == "f32" else "f32 arithmetic, f16 volume storage", "data": "synthetic",
         "config": {"workload": f"{workload}; {N}^3 {args.vol_dtype} volume, {IMG}^2 image, {R}-entry TF, sr=1.0, "
                                f"{V} view(s) per rank per step, {cams}, jitter {'on' if args.jitter else 'off'}",
                    "volume": N, "image": IMG, "tf_res": R, "views_per_rank_per_step": V,

@@ -6,9 +6,12 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# DIFFERENDER_HIP_LIB lets tools/ab.sh time two builds of the library in one job (A/B on the same device)
+# DIFFERENDER_HIP_LIB lets tools/ab.sh time two builds of the library in one job (A/B on the same device). A what-if build
+# (kernels that compute wrong results on purpose, csrc/dr_experiment.h) is refused unless DIFFERENDER_ALLOW_EXPERIMENT=1.
 LIB_PATH = os.environ.get("DIFFERENDER_HIP_LIB") or os.path.join(_HERE, "libdifferender_hip.so")
 
+ABI_VERSION = 8
+BUILD_WRONG_RESULTS, BUILD_DIAGNOSTIC = 1, 2   # dr_build_flags()
 DR_F32, DR_F16 = 0, 1
 DR_MODE_DIFF, DR_MODE_NONDIFF = 0, 1
 DR_VARIANT_AUTO, DR_VARIANT_BASELINE = 0, 1
@@ -20,6 +23,7 @@ _P, _I, _L, _F, _D, _U, _Z = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c
 # name -> (restype, argtypes); must list every symbol the header declares (tests/test_abi.py checks)
 SIGNATURES = {
     "dr_abi_version": (_I, []),
+    "dr_build_flags": (_I, []),
     "dr_error_string": (_c.c_char_p, [_I]),
     "dr_ray_setup": (_I, [_P, _I, _I, _I, _I, _I, _I, _D, _D, _F, _U, _U, _P, _P, _P, _P, _P]),
     "dr_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I, _I]),
@@ -59,8 +63,16 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.dr_abi_version() != 7:
-            raise ImportError("libdifferender_hip.so ABI version mismatch; rebuild it")
+        version, flags = handle.dr_abi_version(), handle.dr_build_flags()
+        if (version < 0 or flags & BUILD_WRONG_RESULTS) and os.environ.get("DIFFERENDER_ALLOW_EXPERIMENT") != "1":
+            raise ImportError(
+                f"{LIB_PATH} is a what-if build whose kernels compute WRONG results on purpose (dr_build_flags() = {flags}); "
+                "it is for timing experiments only. Set DIFFERENDER_ALLOW_EXPERIMENT=1 to load it anyway.")
+        if abs(version) != ABI_VERSION:
+            raise ImportError(f"{LIB_PATH}: ABI version {version}, expected {ABI_VERSION}; rebuild it")
+        if flags & BUILD_WRONG_RESULTS:
+            import warnings
+            warnings.warn(f"{LIB_PATH}: what-if build, results are WRONG by construction", RuntimeWarning)
         _lib = handle
     return _lib
 

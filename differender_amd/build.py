@@ -5,12 +5,15 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdifferender_hip.so")
 # compiler and target of every native piece (the Makefile reads the same variables from the environment)
-HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-ARCH = os.environ.get("ARCH", "gfx950")
+# (DR_HIPCC / DR_ARCH, not HIPCC / ARCH: many build environments export ARCH=x86_64)
+HIPCC = os.environ.get("DR_HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = os.environ.get("DR_ARCH", "gfx950")
+if not ARCH.startswith("gfx"):
+    raise RuntimeError(f"DR_ARCH must name an AMD GPU target (gfx950), got {ARCH!r}")
 
 
 def build(force=False, verbose=False):
-    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j4", f"HIPCC={HIPCC}", f"ARCH={ARCH}"]
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j4", f"DR_HIPCC={HIPCC}", f"DR_ARCH={ARCH}"]
     if force:
         cmd.append("-B")
     subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)

@@ -46,7 +46,12 @@ struct DeviceOf {
 
 extern "C" {
 
-int dr_abi_version(void) { return DR_ABI_VERSION; }
+// OR-ed at load time by every translation unit that was compiled with a what-if or diagnostic switch (dr_experiment.h)
+int dr_experiment_flags_ = 0;
+
+int dr_build_flags(void) { return dr_experiment_flags_; }
+// a library that computes wrong results on purpose does not answer with the ABI version a loader expects
+int dr_abi_version(void) { return (dr_experiment_flags_ & DR_BUILD_WRONG_RESULTS) ? -DR_ABI_VERSION : DR_ABI_VERSION; }
 
 const char *dr_error_string(int code) {
     switch (code) {

@@ -89,7 +89,7 @@ template <typename VT>
 __global__ __launch_bounds__(256) void march_bwd_baseline_kernel(MarchParams<VT> P) {
     // [R] TF, then [R][4] dTF accumulators in DOUBLE: thousands of samples of a workgroup land on a few texels (all of them on
     // one when R = 1), and f32 atomics in thread order put 1e-3 of summation noise on d_tf at sampling rate 16 (fuzz seed 603239,
-    // round 4); the oracle sums d_tf in double for the same reason (oracle/dr_oracle_impl.inc), so this keeps the twin a twin
+    // round 4); the oracle sums d_tf in double for the same reason (its d_tf accumulators), so this keeps the twin a twin
     extern __shared__ __attribute__((aligned(16))) float4 lds_tf[];
     const int view = blockIdx.y;
     const float4 *tfg = P.tf + view * P.tf_vs;

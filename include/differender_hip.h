@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DR_ABI_VERSION 7
+#define DR_ABI_VERSION 8
 
 enum { DR_F32 = 0, DR_F16 = 1 };
 enum { DR_MODE_DIFF = 0, DR_MODE_NONDIFF = 1 };
@@ -58,7 +58,13 @@ enum {
     DR_ECOLLECTIVE = -3   /* RCCL reported an error */
 };
 
+/* DR_ABI_VERSION for the shipped kernels. A library in which any translation unit was compiled with a timing-only what-if
+ * switch (kernels that compute WRONG results on purpose: tools/README.md, csrc/dr_experiment.h) answers -DR_ABI_VERSION, so a
+ * loader that checks the version cannot take it for the product by accident. */
 int dr_abi_version(void);
+/* Bit mask of how this library was built: 0 = the shipped kernels; 1 = a what-if build with wrong results;
+ * 2 = diagnostic instrumentation (per-phase clocks / counters in the workspace header; results unchanged, slower). */
+int dr_build_flags(void);
 const char *dr_error_string(int code);
 
 /* Ray generation + box clipping + sample count + jitter.

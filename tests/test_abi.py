@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(hiplib):
     for s in _declared_symbols():
         assert hasattr(raw, s), f"{s} declared in include/differender_hip.h but not exported"
         assert s in N.SIGNATURES, f"{s} has no ctypes signature in differender_amd/_native.py"
-    assert hiplib.dr_abi_version() == 7
+    assert hiplib.dr_abi_version() == 8 and hiplib.dr_build_flags() == 0
     assert b"invalid" in hiplib.dr_error_string(-1)
 
 
@@ -125,3 +125,31 @@ def test_product_does_not_reference_oracle():
                 if f.endswith(".so"):
                     syms = os.popen(f"nm -D --defined-only {os.path.join(d, f)!r} 2>/dev/null").read()
                     assert "dro_" not in syms, (d, f)
+
+
+def test_what_if_build_is_refused_by_the_loader(hiplib, tmp_path):
+    """A library in which ANY translation unit was compiled with a wrong-result what-if switch (csrc/dr_experiment.h) answers a
+    negative ABI version and dr_build_flags() & 1, and differender_amd._native refuses it unless DIFFERENDER_ALLOW_EXPERIMENT=1
+    (VERDICT r04 item 5). Built here: the shipped objects with ONE small unit recompiled under -DDR_ABL_NOFLUSH."""
+    import subprocess
+    import sys
+    csrc = os.path.join(ROOT, "differender_amd", "csrc")
+    flags = subprocess.check_output(["make", "-s", "-C", csrc, "print-common"], text=True).split()
+    obj = str(tmp_path / "epilogue_whatif.o")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", *flags, "-DDR_ABL_NOFLUSH", "-c", os.path.join(csrc, "epilogue.hip"), "-o", obj])
+    others = [os.path.join(csrc, f) for f in ("capi.o", "ray_setup.o", "march_baseline.o", "ray_passes.o", "march_flat.o",
+                                               "march_flat_bwdvol.o", "collective.o")]
+    so = str(tmp_path / "libwhatif.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so, obj, *others, "-ldl"])
+    raw = ctypes.CDLL(so)
+    assert raw.dr_abi_version() == -8 and raw.dr_build_flags() & 1
+    probe = "from differender_amd import _native as N; N.lib(); print('loaded', N.lib().dr_build_flags())"
+    env = dict(os.environ, DIFFERENDER_HIP_LIB=so, PYTHONPATH=ROOT)
+    env.pop("DIFFERENDER_ALLOW_EXPERIMENT", None)
+    r = subprocess.run([sys.executable, "-W", "ignore", "-c", probe], env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and "what-if build" in r.stderr and "loaded" not in r.stdout
+    r = subprocess.run([sys.executable, "-W", "ignore", "-c", probe], env=dict(env, DIFFERENDER_ALLOW_EXPERIMENT="1"),
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and "loaded 1" in r.stdout, r.stderr
+    # the shipped library is clean
+    assert hiplib.dr_abi_version() == 8 and hiplib.dr_build_flags() == 0

@@ -70,3 +70,16 @@ def test_valu_roofline_from_the_committed_counters():
     assert 4.0 < f["waves_per_simd"] <= 5.0 and 3.0 < b["waves_per_simd"] <= 4.0
     assert B.traffic_bytes(pm, False) == int((2 * pm[f["kernel"]]["FETCH_SIZE"] + pm[f["kernel"]]["WRITE_SIZE"]) * 1024)
     assert B.valu_roofline({}, False, steps) is None
+
+
+def test_roofline_bound_is_named_from_the_counters():
+    """`roofline.bound` says what the SQ counters show, not what the byte model prices: on the committed
+    round-4 counters the forward is VALU-issue + LDS bound, the backward VALU-issue + LDS-atomics; HBM only if the memory side is
+    the busiest unit."""
+    import json
+    B = _bench()
+    d = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_line_headline.json")))
+    assert B.observed_bound(d["roofline_valu_fwd"], d["roofline_fwd"]["hbm_frac_measured"]) == "valu-issue+lds"
+    assert B.observed_bound(d["roofline_valu_bwd"], d["roofline_bwd"]["hbm_frac_measured"]) == "valu-issue+lds-atomics"
+    idle = dict(d["roofline_valu_fwd"], issue_slot_utilisation=0.3, lds_array_busy=0.1)
+    assert B.observed_bound(idle, 0.85) == "hbm" and B.observed_bound(idle, 0.2).startswith("latency")

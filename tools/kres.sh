@@ -3,7 +3,8 @@
 #   usage: tools/kres.sh march_flat [extra hipcc flags...]
 F=$1; shift
 cd "$(dirname "$0")/../differender_amd/csrc"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -munsafe-fp-atomics -ffp-contract=off -fno-slp-vectorize -mllvm -disable-machine-licm "$@" \
+# (the flag list is the Makefile's; for B1's own unit: tools/kres.sh march_flat_bwdvol -mllvm -amdgpu-sched-strategy=iterative-minreg)
+/opt/rocm/bin/hipcc $(make -s print-common) -Wno-everything "$@" \
   -Rpass-analysis=kernel-resource-usage -c $F.hip -o /dev/null 2>&1 | python3 -c "
 import re, sys
 cur = {}

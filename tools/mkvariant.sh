@@ -1,11 +1,14 @@
 #!/bin/bash
-# Build a variant of libdifferender_hip.so into ab_libs/<name>.so with extra compiler flags (for tools/ab.sh).
+# Build a variant of libdifferender_hip.so into ab_libs/<name>.so with extra compiler flags (for tools/ab.sh / abn.sh).
 #   usage: tools/mkvariant.sh name [extra hipcc flags...]
+# The flag list is the Makefile's (make print-common / print-bwdvol): one definition. A variant built with a what-if switch
+# (csrc/dr_experiment.h) marks itself: the Python loader refuses it unless DIFFERENDER_ALLOW_EXPERIMENT=1 (tools/abn.sh sets it).
 set -e
 name=$1; shift
 src=differender_amd/csrc; out=ab_libs/obj_$name
 mkdir -p $out
-COMMON="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -munsafe-fp-atomics -ffp-contract=off -fno-slp-vectorize ${NO_LICM_FLAG--mllvm -disable-machine-licm}"
+COMMON="$(make -s -C $src print-common)"
+if [ -n "${NO_LICM_FLAG+x}" ]; then COMMON="${COMMON//-mllvm -disable-machine-licm/}"; fi
 pids=()
 for f in capi ray_setup march_baseline ray_passes march_flat epilogue collective; do
   /opt/rocm/bin/hipcc $COMMON "$@" -c $src/$f.hip -o $out/$f.o & pids+=($!)

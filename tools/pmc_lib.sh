@@ -2,7 +2,7 @@
 # usage: tools/pmc_lib.sh <outdir> <lib.so> <counters...>   -- PMC pass over bench.py (fwd only) with a given library build
 out=$1; lib=$2; shift 2
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-export DIFFERENDER_HIP_LIB=$PWD/$lib
+export DIFFERENDER_ALLOW_EXPERIMENT=1 DIFFERENDER_HIP_LIB=$PWD/$lib
 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d gpurun_out/$out -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --pmc off > gpurun_out/$out.log 2>&1
 f=$(find gpurun_out/$out -name "*counter_collection.csv" | head -1)
 python - <<PY

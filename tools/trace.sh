@@ -3,7 +3,7 @@
 lib=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/trace_tmp
-DIFFERENDER_HIP_LIB=$PWD/$lib rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/trace_tmp -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --pmc off "$@" > gpurun_out/trace_tmp.log 2>&1
+DIFFERENDER_ALLOW_EXPERIMENT=1 DIFFERENDER_HIP_LIB=$PWD/$lib rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/trace_tmp -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --pmc off "$@" > gpurun_out/trace_tmp.log 2>&1
 python - <<PY
 import csv,glob
 f=glob.glob("gpurun_out/trace_tmp/**/*kernel_stats.csv", recursive=True)[0]
