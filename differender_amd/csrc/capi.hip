@@ -37,6 +37,9 @@ struct DeviceOf {
         hipPointerAttribute_t attr;
         if (hipPointerGetAttributes(&attr, device_ptr) != hipSuccess) { (void)hipGetLastError(); return; }  // not a device pointer we know: leave as is
         dev = attr.device;
+        // (a launch error somebody else left behind -- an earlier failed call of ours, another library -- must not be taken for
+        // this call's: the launch functions read hipGetLastError() after their launches)
+        (void)hipGetLastError();
         if (hipGetDevice(&prev) != hipSuccess) { prev = -1; return; }
         if (prev != dev) err = hipSetDevice(dev); else prev = -1;
     }

@@ -8,7 +8,7 @@
 
 // ---- what-ifs with WRONG results (tools/README.md; findings in profiles/r0N_ab_experiments.txt) ----
 #if defined(DR_ABL_NOSCATTER) || defined(DR_ABL_NOATOMIC) || defined(DR_ABL_NOFLUSH) || defined(DR_ABL_NOBARRIER) || \
-    defined(DR_ABL_HALFREADS) || defined(DR_ABL_XREUSE) || defined(DR_ABL_SMALLBOX) || defined(DR_ABL_ALPHA13) || \
+    defined(DR_ABL_HALFREADS) || defined(DR_ABL_XREUSE) || defined(DR_ABL_SMALLBOX) || defined(DR_ABL_ALPHA13) || defined(DR_ABL_NOMEMSET) || defined(DR_ABL_NOITEMS) || \
     defined(DR_CROSS_NORESTART) || defined(DR_ABL_WRONG)
 #define DR_EXPERIMENT_WRONG 1
 #else

@@ -37,13 +37,18 @@ __device__ __forceinline__ bool tile_pixel(int W, int H, int &i, int &j) {
     return i < W && j < H;
 }
 
-template <typename VT, int MODE>
+// TF_LDS: the transfer function is staged in LDS (R <= 10240 entries = 160 KiB); a larger one is read where it lies, through the
+// caches -- the reference has no limit on the TF resolution, and neither have the plain kernels.
+template <typename VT, int MODE, bool TF_LDS>
 __global__ __launch_bounds__(256) void march_fwd_baseline_kernel(MarchParams<VT> P) {
-    extern __shared__ __attribute__((aligned(16))) float4 lds_tf[];
+    extern __shared__ __attribute__((aligned(16))) float4 lds_tf_[];
     const int view = blockIdx.y;
     const float4 *tfg = P.tf + view * P.tf_vs;
-    for (int k = threadIdx.x; k < P.R; k += 256) lds_tf[k] = tfg[k];
-    __syncthreads();
+    if (TF_LDS) {
+        for (int k = threadIdx.x; k < P.R; k += 256) lds_tf_[k] = tfg[k];
+        __syncthreads();
+    }
+    const float4 *lds_tf = TF_LDS ? lds_tf_ : tfg;
 
     int i, j;
     if (!tile_pixel(P.W, P.H, i, j)) return;
@@ -85,18 +90,26 @@ __global__ __launch_bounds__(256) void march_fwd_baseline_kernel(MarchParams<VT>
 
 __device__ __forceinline__ float finite_or_zero(float x) { return (x == x) ? fminf(fmaxf(x, -1.0e30f), 1.0e30f) : 0.0f; }
 
-template <typename VT>
+// TABLES: what the workgroup keeps in LDS --
+//   2: [R] TF + [R][4] d_tf accumulators in double (48 R bytes: R <= 3413);
+//   1: the TF only; d_tf contributions go straight to the caller's tensor with float atomics (16 R bytes: R <= 10240; at such
+//      resolutions a texel collects few samples of a workgroup, so the summation noise the double table exists for -- below -- is
+//      not a concern);
+//   0: nothing: the TF is read where it lies (any R; the reference has no limit on the TF resolution).
+template <typename VT, int TABLES>
 __global__ __launch_bounds__(256) void march_bwd_baseline_kernel(MarchParams<VT> P) {
-    // [R] TF, then [R][4] dTF accumulators in DOUBLE: thousands of samples of a workgroup land on a few texels (all of them on
+    // TABLES == 2: [R] TF, then [R][4] dTF accumulators in DOUBLE: thousands of samples of a workgroup land on a few texels (all of them on
     // one when R = 1), and f32 atomics in thread order put 1e-3 of summation noise on d_tf at sampling rate 16 (fuzz seed 603239,
     // round 4); the oracle sums d_tf in double for the same reason (its d_tf accumulators), so this keeps the twin a twin
-    extern __shared__ __attribute__((aligned(16))) float4 lds_tf[];
+    extern __shared__ __attribute__((aligned(16))) float4 lds_tf_[];
     const int view = blockIdx.y;
     const float4 *tfg = P.tf + view * P.tf_vs;
-    double *lds_dtf = reinterpret_cast<double *>(lds_tf + P.R);
-    for (int k = threadIdx.x; k < P.R; k += 256) lds_tf[k] = tfg[k];
-    for (int k = threadIdx.x; k < 4 * P.R; k += 256) lds_dtf[k] = 0.0;
-    __syncthreads();
+    double *lds_dtf = reinterpret_cast<double *>(lds_tf_ + P.R);
+    if (TABLES >= 1) for (int k = threadIdx.x; k < P.R; k += 256) lds_tf_[k] = tfg[k];
+    if (TABLES == 2) for (int k = threadIdx.x; k < 4 * P.R; k += 256) lds_dtf[k] = 0.0;
+    if (TABLES >= 1) __syncthreads();
+    const float4 *lds_tf = TABLES >= 1 ? lds_tf_ : tfg;
+    float *dtf_g = P.d_tf ? P.d_tf + view * P.dtf_vs * 4 : nullptr;
 
     int i, j;
     bool active = tile_pixel(P.W, P.H, i, j);
@@ -155,7 +168,16 @@ __global__ __launch_bounds__(256) void march_bwd_baseline_kernel(MarchParams<VT>
                 ad.gz = finite_or_zero(ad.gz); I_bar = finite_or_zero(I_bar);
             }
 
-            if (want_tf) {
+            if (want_tf && TABLES < 2) {
+                const float w0 = 1.0f - sm.fr, w1 = sm.fr;
+                float *d0 = dtf_g + 4 * sm.lo, *d1 = dtf_g + 4 * sm.hi;
+                const float v8[8] = {w0 * ad.r_bar, w0 * ad.g_bar, w0 * ad.b_bar, w0 * ad.a_bar, w1 * ad.r_bar, w1 * ad.g_bar, w1 * ad.b_bar, w1 * ad.a_bar};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (P.only_flagged) { atomic_add_sat(d0 + q, v8[q]); atomic_add_sat(d1 + q, v8[4 + q]); }
+                    else { unsafeAtomicAdd(d0 + q, v8[q]); unsafeAtomicAdd(d1 + q, v8[4 + q]); }
+                }
+            } else if (want_tf) {
                 const float w0 = 1.0f - sm.fr, w1 = sm.fr;
                 double *d0 = lds_dtf + 4 * sm.lo, *d1 = lds_dtf + 4 * sm.hi;   // (the products are f32, as in the oracle)
                 atomicAdd(d0 + 0, (double)(w0 * ad.r_bar)); atomicAdd(d0 + 1, (double)(w0 * ad.g_bar));
@@ -176,9 +198,9 @@ __global__ __launch_bounds__(256) void march_bwd_baseline_kernel(MarchParams<VT>
             }
         }
     }
-    if (P.d_tf) {
+    if (P.d_tf && TABLES == 2) {
         __syncthreads();
-        float *dtf = P.d_tf + view * P.dtf_vs * 4;
+        float *dtf = dtf_g;
         for (int k = threadIdx.x; k < 4 * P.R; k += 256) {
             const float v = (float)lds_dtf[k];
             if (v == 0.0f) continue;
@@ -217,6 +239,7 @@ static hipError_t big_lds(K kernel, size_t bytes) {  // dynamic LDS above 64 KB 
     return allow_lds_impl(reinterpret_cast<const void *>(kernel), bytes);
 }
 
+constexpr size_t LDS_PER_CU = 160 * 1024;
 static dim3 tile_grid(const MarchArgs &a) {
     const int tiles = ((a.W + 7) / 8) * ((a.H + 7) / 8);
     return dim3((tiles + 3) / 4, a.n_views);
@@ -224,16 +247,18 @@ static dim3 tile_grid(const MarchArgs &a) {
 
 template <typename VT>
 static int fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
-    const size_t lds = (size_t)a.R * sizeof(float4);
-    if (lds > 160 * 1024) return DR_EUNSUPPORTED;  // TF table must fit the CU's LDS (R <= 10240)
+    size_t lds = (size_t)a.R * sizeof(float4);
+    const bool tf_lds = lds <= LDS_PER_CU;   // (R <= 10240; a larger TF is read from global memory)
+    if (!tf_lds) lds = 0;
     MarchParams<VT> P = make_params<VT>(a);
-    if (a.mode == DR_MODE_DIFF) {
-        if (big_lds(march_fwd_baseline_kernel<VT, DR_MODE_DIFF>, lds) != hipSuccess) return DR_EUNSUPPORTED;
-        hipLaunchKernelGGL((march_fwd_baseline_kernel<VT, DR_MODE_DIFF>), tile_grid(a), dim3(256), lds, stream, P);
-    } else {
-        if (big_lds(march_fwd_baseline_kernel<VT, DR_MODE_NONDIFF>, lds) != hipSuccess) return DR_EUNSUPPORTED;
-        hipLaunchKernelGGL((march_fwd_baseline_kernel<VT, DR_MODE_NONDIFF>), tile_grid(a), dim3(256), lds, stream, P);
+#define DR_FWD_BASE(MODE_, LDS_)                                                                                             \
+    {                                                                                                                        \
+        if (big_lds(march_fwd_baseline_kernel<VT, MODE_, LDS_>, lds) != hipSuccess) return DR_EUNSUPPORTED;                  \
+        hipLaunchKernelGGL((march_fwd_baseline_kernel<VT, MODE_, LDS_>), tile_grid(a), dim3(256), lds, stream, P);           \
     }
+    if (a.mode == DR_MODE_DIFF) { if (tf_lds) DR_FWD_BASE(DR_MODE_DIFF, true) else DR_FWD_BASE(DR_MODE_DIFF, false) }
+    else { if (tf_lds) DR_FWD_BASE(DR_MODE_NONDIFF, true) else DR_FWD_BASE(DR_MODE_NONDIFF, false) }
+#undef DR_FWD_BASE
     return (int)hipGetLastError();
 }
 
@@ -243,11 +268,18 @@ int launch_march_fwd_baseline(const MarchArgs &a, hipStream_t stream) {
 
 template <typename VT>
 static int bwd_dispatch(const MarchArgs &a, hipStream_t stream) {
-    const size_t lds = (size_t)a.R * (sizeof(float4) + 4 * sizeof(double));
-    if (lds > 160 * 1024) return DR_EUNSUPPORTED;  // TF + its double-precision gradient table in LDS (R <= 3413)
+    // TF + its double-precision gradient table in LDS while they fit (R <= 3413), then the TF alone (R <= 10240), then nothing
+    const size_t lds2 = (size_t)a.R * (sizeof(float4) + 4 * sizeof(double)), lds1 = (size_t)a.R * sizeof(float4);
+    const int tables = lds2 <= LDS_PER_CU ? 2 : (lds1 <= LDS_PER_CU ? 1 : 0);
+    const size_t lds = tables == 2 ? lds2 : (tables == 1 ? lds1 : 0);
     MarchParams<VT> P = make_params<VT>(a);
-    if (big_lds(march_bwd_baseline_kernel<VT>, lds) != hipSuccess) return DR_EUNSUPPORTED;
-    hipLaunchKernelGGL((march_bwd_baseline_kernel<VT>), tile_grid(a), dim3(256), lds, stream, P);
+#define DR_BWD_BASE(T_)                                                                                          \
+    {                                                                                                            \
+        if (big_lds(march_bwd_baseline_kernel<VT, T_>, lds) != hipSuccess) return DR_EUNSUPPORTED;               \
+        hipLaunchKernelGGL((march_bwd_baseline_kernel<VT, T_>), tile_grid(a), dim3(256), lds, stream, P);        \
+    }
+    if (tables == 2) DR_BWD_BASE(2) else if (tables == 1) DR_BWD_BASE(1) else DR_BWD_BASE(0)
+#undef DR_BWD_BASE
     return (int)hipGetLastError();
 }
 

@@ -22,8 +22,33 @@
 
 namespace dr {
 
+// What-if (WRONG results, timing only): B1 as FOUR-wave workgroups, four per CU -- the shape that was worth 15 %
+// to the TF-only backward -- with the per-brick work unchanged. The LDS it would need (<= 40 KB) is faked: the gradient box is
+// aliased into 8 KB and the d_tf table into 2 KB (addresses masked; same instructions, same number of atomics, same flush
+// traffic). An upper bound for any real small-box design, which pays for its extra bricks / passes on top.
+#ifdef DR_ABL_SMALLBOX
+#define DR_FNT_BWD 256
+#define DR_FEC_BWD 128
+#define DR_BWD_UNEVEN 0
+#define DR_DBOX_WORDS 1024
+#define DR_DBOX_IDX(i) (256 + ((i) & 255))
+#define DR_DBOX_FLUSH_IDX(i) ((i) & 1023)
+#define DR_DTF_TEXEL(t) ((t) & 63)
+#define DR_DTF_BYTES(R) ((size_t)64 * 32)
+#define DR_DTF_FLUSH_IDX(k) ((k) & 255)
+#else
+#define DR_DBOX_WORDS BOX_LDS
+#define DR_DBOX_IDX(i) (i)
+#define DR_DBOX_FLUSH_IDX(i) (i)
+#define DR_DTF_TEXEL(t) (t)
+#define DR_DTF_BYTES(R) ((size_t)(R) * 32)
+#define DR_DTF_FLUSH_IDX(k) (k)
+#endif
 #ifndef DR_FNT_BWD
 #define DR_FNT_BWD 512
+#endif
+#ifndef DR_ABL_EXTRA_LDS_BWD
+#define DR_ABL_EXTRA_LDS_BWD 0   // what-if: bytes of unused LDS per backward workgroup (fewer workgroups per CU)
 #endif
 
 #ifndef DR_BWD_WAVES
@@ -110,7 +135,7 @@ template <bool BWD>
 __host__ __device__ constexpr size_t flat_fixed_bytes(bool want_vol) {
     const int EC = want_vol ? FlatCfg<BWD, true>::EC : FlatCfg<BWD, false>::EC;
     size_t s = ((size_t)BOX_LDS * 4 + 15) / 16 * 16;
-    if (BWD && want_vol) s += ((size_t)BOX_LDS * 8 + 15) / 16 * 16;
+    if (BWD && want_vol) s += ((size_t)DR_DBOX_WORDS * 8 + 15) / 16 * 16;
     s += (size_t)EC * 32;
     s += (size_t)EC * 4 + (((size_t)EC + 8) * 4 + 15) / 16 * 16 + (size_t)EC * 4 + (size_t)EC * 4;  // s_rel, offs, valid, slen
     s += (size_t)EC * 4;  // segi
@@ -119,7 +144,7 @@ __host__ __device__ constexpr size_t flat_fixed_bytes(bool want_vol) {
 }
 template <bool BWD>
 __host__ __device__ inline size_t flat_lds_bytes(int R, bool want_vol, bool want_tf) {
-    return flat_fixed_bytes<BWD>(want_vol) + (size_t)R * 16 + ((BWD && want_tf) ? (size_t)R * 32 : 0);
+    return flat_fixed_bytes<BWD>(want_vol) + (size_t)R * 16 + ((BWD && want_tf) ? (want_vol ? DR_DTF_BYTES(R) : (size_t)R * 32) : 0);
 }
 template <bool BWD, bool WANT_VOL, bool WANT_TF>
 __device__ __forceinline__ FlatLds flat_carve(unsigned char *smem, int R) {
@@ -128,7 +153,7 @@ __device__ __forceinline__ FlatLds flat_carve(unsigned char *smem, int R) {
     size_t o = 0;
     L.box = reinterpret_cast<float *>(smem + o); o += align16(BOX_LDS * 4);
     L.dbox = nullptr; L.dtf = nullptr; L.live = nullptr;
-    if (BWD && WANT_VOL) { L.dbox = reinterpret_cast<unsigned long long *>(smem + o); o += align16(BOX_LDS * 8); }
+    if (BWD && WANT_VOL) { L.dbox = reinterpret_cast<unsigned long long *>(smem + o); o += align16(DR_DBOX_WORDS * 8); }
     L.ray0 = reinterpret_cast<float4 *>(smem + o); o += (size_t)EC * 16;
     L.ray1 = reinterpret_cast<float4 *>(smem + o); o += (size_t)EC * 16;
     L.s_rel = reinterpret_cast<int *>(smem + o); o += (size_t)EC * 4;
@@ -776,8 +801,8 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
         if (BWD && WANT_VOL) cand_grad_range<VT, FNT>(P, c, view, r_lo, r_hi, hits, c_lo, ncand_all, gm, gn);  // upstream gradients of the candidates,
         if (!reuse_box) box_issue<VT, FNT>(P, vol, c, P.tf + view * P.tf_vs, stage);      // voxel box + TF: in flight ...
         if (BWD) {
-            if (WANT_VOL) for (int k = threadIdx.x; k < BOX_LDS; k += FNT) L.dbox[k] = 0ull;
-            if (WANT_TF) for (int k = threadIdx.x; k < 4 * P.R; k += FNT) L.dtf[k] = 0ull;
+            if (WANT_VOL) for (int k = threadIdx.x; k < DR_DBOX_WORDS; k += FNT) L.dbox[k] = 0ull;
+            if (WANT_TF) for (int k = threadIdx.x; k < (WANT_VOL ? (int)(DR_DTF_BYTES(P.R) / 8) : 4 * P.R); k += FNT) L.dtf[k] = 0ull;
             if (WANT_VOL) {
                 gm = wave_max_f(gm); gn = wave_min_f(gn);
                 if ((threadIdx.x & 63) == 0) { L.gmax[threadIdx.x >> 6] = gm; L.gmax[8 + (threadIdx.x >> 6)] = gn; }
@@ -1216,7 +1241,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                     // d_tf accumulates in double; a NaN or an absurd run total takes the sanitising path
                     if (__any(emit && !(vmax <= ACC_LIM))) {
                         if (emit) {
-                            unsigned long long *d0 = L.dtf + 4 * sm.lo, *d1 = L.dtf + 4 * sm.hi;
+                            unsigned long long *d0 = L.dtf + 4 * DR_DTF_TEXEL(sm.lo), *d1 = L.dtf + 4 * DR_DTF_TEXEL(sm.hi);
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 acc_add_f64(d0 + q, acc_sanitise(v8[q]));
@@ -1224,7 +1249,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                             }
                         }
                     } else if (emit) {
-                        unsigned long long *d0 = L.dtf + 4 * sm.lo, *d1 = L.dtf + 4 * sm.hi;
+                        unsigned long long *d0 = L.dtf + 4 * DR_DTF_TEXEL(sm.lo), *d1 = L.dtf + 4 * DR_DTF_TEXEL(sm.hi);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             acc_add_f64(d0 + q, v8[q]);
@@ -1241,7 +1266,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                     // suffices unless some adjoint of the wave exceeds 2^31 / 2^shift (then: exact wide path).
                     // the 24 tap coordinates are cheap to rebuild from the position (45 VALU) and expensive to keep
                     // alive across shading and the adjoint (the kernel is register-bound: spills go to scratch)
-                    const int cbase_i = valid ? (t.lx * BOX_SX + t.ly * BOX_SY + t.lz) : 0;
+                    const int cbase_i = valid ? DR_DBOX_IDX(t.lx * BOX_SX + t.ly * BOX_SY + t.lz) : 0;
                     float I_bar = 0.f;
                     float gq[3] = {0.f, 0.f, 0.f};
                     if (valid) {
@@ -1340,7 +1365,11 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
             for (int r = row; r < BOX * BOX; r += FNT / 16) {
                 int b, d;
                 box_row(r, b, d);
-                const unsigned long long raw = L.dbox[a * w.la + b * w.lb + d * w.ld];
+                const unsigned long long raw = L.dbox[DR_DBOX_FLUSH_IDX(a * w.la + b * w.lb + d * w.ld)];
+#ifdef DR_ABL_SMALLBOX
+                // (the aliased what-if box holds garbage in elements that lie outside the volume: keep the flush inside it)
+                if (!((unsigned)(w.oa + a) < (unsigned)w.Va && (unsigned)(w.ob + b) < (unsigned)w.Vb && (unsigned)(w.od + d) < (unsigned)w.Vd)) continue;
+#endif
                 if (raw != 0ull)  // in range whenever raw != 0
                     atomic_add_sat(base + (a * w.ga + b * w.gb + d * w.gd), acc64 ? acc_f64_to_float(raw) : fix_to_float(raw, fs));
             }
@@ -1349,7 +1378,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
     if (WANT_TF) {
         float *dtf = P.d_tf + view * P.dtf_vs * 4;
         for (int k = threadIdx.x; k < 4 * P.R; k += FNT) {
-            const unsigned long long raw = L.dtf[k];
+            const unsigned long long raw = L.dtf[WANT_VOL ? DR_DTF_FLUSH_IDX(k) : k];
             if (raw != 0ull) atomic_add_sat(dtf + k, acc_f64_to_float(raw));
         }
     }
@@ -1388,6 +1417,26 @@ __global__ __launch_bounds__((FlatCfg<BWD, WANT_VOL>::FNT), (FlatCfg<BWD, WANT_V
     brick_flat_body<VT, MODE, BWD, WANT_VOL, WANT_TF, ALPHA, KF, false, NARROW>(P, smem, blockIdx.x, blockIdx.y,
                                                                                0, MAIN_CAND, bv);
 #endif
+}
+// Tuning experiment (right results): the main launch as a RESIDENT grid -- DR_F1_RESIDENT workgroups that draw
+// (view, brick) slots near-first through a ticket instead of one workgroup per slot -- against the ramp / drain of 8.3 rounds of
+// workgroups at 256^3. Forward march only (not the pre-pass, not the backward).
+#ifndef DR_F1_RESIDENT
+#define DR_F1_RESIDENT 0
+#endif
+template <typename VT, int MODE, int KF, bool NARROW>
+__global__ __launch_bounds__((FlatCfg<false, false>::FNT), (FlatCfg<false, false>::WAVES)) void brick_flat_resident_kernel(BrickParams<VT> P, int nbricks, int total) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int s_next;
+    for (int slot = blockIdx.x; slot < total;) {  // uniform
+        bool bv = false;
+        brick_flat_body<VT, MODE, false, false, false, false, KF, false, NARROW>(P, smem, slot % nbricks, slot / nbricks, 0, MAIN_CAND, bv);
+        __syncthreads();
+        if (threadIdx.x == 0) s_next = (int)gridDim.x + (int)atomicAdd(&P.stats[ST_TICKET_MAIN], 1u);
+        __syncthreads();
+        slot = s_next;
+    }
+    if (threadIdx.x == 0 && atomicAdd(&P.stats[ST_DONE_MAIN], 1u) == gridDim.x - 1) { P.stats[ST_TICKET_MAIN] = 0u; P.stats[ST_DONE_MAIN] = 0u; }
 }
 // the overflow items of heavy bricks (all views), worked off by a fixed, small grid
 template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, bool ALPHA = false, int KF = 1, bool NARROW = true>
@@ -1444,7 +1493,11 @@ bool brick_image_supported(int W, int H, int VX, int VY, int VZ) {
 bool brick_path_supported(int VX, int VY, int VZ, int R) {
     const int m = VX > VY ? (VX > VZ ? VX : VZ) : (VY > VZ ? VY : VZ);
     if (m - 1 >= 2000) return false;       // normal taps must stay within one voxel of the centre cell
-    return flat_lds_bytes<true>(R, true, true) <= 160 * 1024;
+    // The largest LDS request of the path is the backward's work-item kernel (its list of hits behind the regular layout). The
+    // runtime does not grant the CU's full 160 KiB to one workgroup: 163 232 B launched, 163 616 B did not (R = 2040 / 2048,
+    // tools/lds_limit_probe.py on the GPU box, round 5 -- until then R = 2041 .. 2223 passed this test and failed at the backward's
+    // launch). 1 KiB of headroom: R <= 2030; a larger TF is served by the plain kernels, which have no limit.
+    return align16(flat_lds_bytes<true>(R, true, true)) + ITEM_EXTRA_LDS + 64 <= 159 * 1024;
 }
 
 #endif  // !DR_FLAT_TU_BWDVOL
@@ -1462,11 +1515,21 @@ static inline bool taps_narrow(const MarchArgs &a) {
 #ifndef DR_ABL_EXTRA_LDS_ALPHA
 #define DR_ABL_EXTRA_LDS_ALPHA 0   // what-if: bytes of unused LDS per workgroup of the alpha pre-pass (fewer workgroups per CU)
 #endif
+#ifdef DR_ABL_NOITEMS   // what-if (WRONG results when heavy bricks exist): the work-item launch is never issued
+#define DR_ABL_NOITEMS_ 1
+#else
+#define DR_ABL_NOITEMS_ 0
+#endif
 #define DR_LAUNCH_BOTH_N(MODE_, BWD_, VOL_, TF_, ALPHA_, K_, NT_, NARROW_)                                                             \
     {                                                                                                                                 \
         if ((e = allow_lds(brick_flat_kernel<VT, MODE_, BWD_, VOL_, TF_, ALPHA_, K_, NARROW_>, lds)) != hipSuccess) return (int)e;    \
         if ((e = allow_lds(brick_flat_items_kernel<VT, MODE_, BWD_, VOL_, TF_, ALPHA_, K_, NARROW_>, align16(lds) + ITEM_EXTRA_LDS)) != hipSuccess) return (int)e; \
+        if constexpr (DR_F1_RESIDENT > 0 && !(BWD_) && !(ALPHA_)) {                                                                   \
+            const int total_ = (int)(grid1.x * grid1.y);                                                                              \
+            hipLaunchKernelGGL((brick_flat_resident_kernel<VT, MODE_, K_, NARROW_>), dim3(total_ < DR_F1_RESIDENT ? total_ : DR_F1_RESIDENT), dim3(NT_), lds, stream, P, (int)grid1.x, total_); \
+        } else                                                                                                                        \
         hipLaunchKernelGGL((brick_flat_kernel<VT, MODE_, BWD_, VOL_, TF_, ALPHA_, K_, NARROW_>), DR_GRID1, dim3(NT_), lds + ((ALPHA_) ? DR_ABL_EXTRA_LDS_ALPHA : 0), stream, P);         \
+        if (!DR_ABL_NOITEMS_)                                                                                                         \
         hipLaunchKernelGGL((brick_flat_items_kernel<VT, MODE_, BWD_, VOL_, TF_, ALPHA_, K_, NARROW_>), dim3(BWD_ ? (VOL_ ? ITEM_GRID_BWD : 2 * ITEM_GRID_BWD) : ITEM_GRID_FWD), dim3(NT_), align16(lds) + ITEM_EXTRA_LDS, stream, P); \
     }
 // NARROW (delta below half a voxel: every edge <= 991 voxels) selects the cheaper shared-lerp taps (dr_brick_common.h); the alpha
@@ -1483,8 +1546,11 @@ int flat_bwd_vol_launch(const MarchArgs &a, BrickParams<VT> P, dim3 grid1, size_
 
 #ifdef DR_FLAT_TU_BWDVOL
 template <typename VT>
-int flat_bwd_vol_launch(const MarchArgs &a, BrickParams<VT> P, dim3 grid1, size_t lds, bool want_tf, hipStream_t stream) {
+int flat_bwd_vol_launch(const MarchArgs &a, BrickParams<VT> P, dim3 grid1, size_t lds_unused, bool want_tf, hipStream_t stream) {
     hipError_t e = hipSuccess;
+    // (the LDS size is this translation unit's own: tuning / what-if switches may be given to it alone, tools/mkvariant.sh BWDVOL_EXTRA)
+    (void)lds_unused;
+    const size_t lds = flat_lds_bytes<true>(a.R, true, want_tf) + DR_ABL_EXTRA_LDS_BWD;
     if (want_tf) DR_LAUNCH_BOTH(DR_MODE_DIFF, true, true, true, false, 1, (FlatCfg<true, true>::FNT))
     else DR_LAUNCH_BOTH(DR_MODE_DIFF, true, true, false, false, 1, (FlatCfg<true, true>::FNT))
     return (int)hipGetLastError();
@@ -1505,7 +1571,12 @@ static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
 #if DR_PHASE_TIMING
     if ((e = hipMemsetAsync(w.stats + ST_TIMING, 0, 64, stream)) != hipSuccess) return (int)e;  // the timing slots
 #endif
+#ifdef DR_ABL_NOMEMSET
+    // what-if (WRONG results unless the caller zeroed the workspace): the bound for folding the count memset into another kernel
+    e = hipSuccess;
+#else
     e = hipMemsetAsync(w.n_items, 0, 16 + w.cnt_bytes, stream);  // the item counter (brick_ctx_kernel appends) and seg_cnt behind it
+#endif
     if (e != hipSuccess) return (int)e;
     const size_t lds = flat_lds_bytes<false>(a.R, false, false);
     const int nbricks = g.NBx * g.NBy * g.NBz;
@@ -1586,9 +1657,6 @@ static int flat_bwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     if (!a.workspace || a.workspace_bytes < need) return DR_EINVAL;
     BrickParams<VT> P = make_brick_params<VT>(a, w);
     const bool wv = a.d_vol != nullptr, wt = a.d_tf != nullptr;
-#ifndef DR_ABL_EXTRA_LDS_BWD
-#define DR_ABL_EXTRA_LDS_BWD 0   // what-if: bytes of unused LDS per backward workgroup (fewer workgroups per CU)
-#endif
     const size_t lds = flat_lds_bytes<true>(a.R, wv, wt) + DR_ABL_EXTRA_LDS_BWD;
     const dim3 grid1(g.NBx * g.NBy * g.NBz, a.n_views);
     hipError_t e = hipSuccess;

@@ -163,10 +163,13 @@ class _TerminationHints:
     reading "exact" for ever, and a TF whose alphas grow under such updates would keep getting "no early termination" -- which
     the device repairs correctly, but by marching every ray of the view with the per-ray kernels (10-40 x slower). Two
     safeguards: the largest alpha is re-read every REFRESH_EVERY-th call even when the version has not moved, and the device's
-    own verdict feeds back -- when a workspace header reports a wrong hint (word 8, `report_wrong_hint`), every cached TF
-    loses the right to that hint for good (a wrong "no termination" is the only hint that costs anything)."""
+    own verdict feeds back -- when a workspace header reports a wrong hint (word 8, `report_wrong_hint`), the TFs that were
+    recently GIVEN that hint (not every cached TF, and nothing at all if the hint was the caller's own: ADVICE r04) lose it for
+    DISTRUST_REFRESHES re-readings of their largest alpha, twice as long after every further report (a wrong "no termination"
+    is the only hint that costs anything)."""
 
     REFRESH_EVERY = 8   # the largest alpha of a TF is re-read on every 8th call at most (whether or not its version moved)
+    DISTRUST_REFRESHES = 4   # clean re-readings before a TF that was given a wrong "no termination" hint may get it again
 
     def __init__(self, capacity=8):
         # key -> entry. The key is WHERE the data lives (storage address, offset, shape, strides) and the entry holds a
@@ -176,18 +179,27 @@ class _TerminationHints:
         # and never does.
         self._seen = {}
         self._capacity = capacity
-        self._distrust_all = False   # a wrong hint was reported before any entry could be blamed
+        self._handed = []            # keys of the TFs that were most recently given DR_HINT_NO_EARLY_TERMINATION (newest last)
+        self._warned = False
 
     def report_wrong_hint(self):
-        """The device found DR_HINT_NO_EARLY_TERMINATION wrong for some view (workspace header word 8): whatever TF that
-        was, its data moved behind the version counter's back. No cached TF gets that hint again."""
-        warnings.warn("differender_amd: the hint DR_HINT_NO_EARLY_TERMINATION (derived from the transfer function's largest "
-                      "alpha) was wrong for a recent render -- the TF was written to without torch's version counter seeing "
-                      "it (`tf.data`, a raw pointer). The device repaired the render (every ray marched one by one: slow); "
-                      "the hint is withheld from now on.", RuntimeWarning, stacklevel=4)
-        self._distrust_all = True
-        for ent in self._seen.values():
-            ent["no_noterm"] = True
+        """The device found DR_HINT_NO_EARLY_TERMINATION wrong for some view of a recent render (workspace header word 8).
+        If that hint came from here, the TFs it was recently derived from had their data moved behind the version counter's
+        back: they lose it for a while (see the class docstring). A hint the CALLER passed explicitly is the caller's business:
+        nothing is withdrawn. Returns the number of cached TFs that were blamed."""
+        blamed = [self._seen[k] for k in self._handed if k in self._seen]
+        self._handed = []
+        for ent in blamed:
+            ent["strikes"] += 1
+            ent["distrust"] = min(self.DISTRUST_REFRESHES << (ent["strikes"] - 1), 1 << 16)
+        if blamed and not self._warned:
+            self._warned = True
+            warnings.warn("differender_amd: the hint DR_HINT_NO_EARLY_TERMINATION (derived from the transfer function's largest "
+                          "alpha) was wrong for a recent render -- the TF was written to without torch's version counter seeing "
+                          "it (`tf.data`, a raw pointer). The device repaired the render (every ray marched one by one: slow); "
+                          "the hint is withheld from that TF until its largest alpha has been re-read a few times.",
+                          RuntimeWarning, stacklevel=4)
+        return len(blamed)
 
     @staticmethod
     def _key(tf):
@@ -199,7 +211,9 @@ class _TerminationHints:
             del self._seen[k]
 
     def _start_read(self, ent, tf, alpha):
-        host = torch.empty((), dtype=torch.float32, pin_memory=True)
+        host = ent["host"]   # one pinned scalar per entry (at most one read of an entry is in flight)
+        if host is None:
+            host = ent["host"] = torch.empty((), dtype=torch.float32, pin_memory=True)
         with torch.no_grad(), torch.cuda.device(tf.device):   # (the event must sit on the stream the copy runs on)
             host.copy_(torch.nan_to_num(alpha(tf.detach()).float(), nan=float("inf")).max(), non_blocking=True)
             ev = torch.cuda.Event()
@@ -216,18 +230,19 @@ class _TerminationHints:
             if len(self._seen) >= self._capacity:
                 self._seen.pop(next(iter(self._seen)))
             self._seen[key] = {"tensor": tf.detach(), "seen": tf._version, "value": None, "value_version": None,
-                               "pending": None, "since": 0, "no_noterm": self._distrust_all}
+                               "pending": None, "since": 0, "host": None, "distrust": 0, "strikes": 0}
             return None, False
         if ent["pending"] is not None and ent["pending"][1].query():
             host, _, ver = ent["pending"]
             ent["value"], ent["value_version"], ent["pending"] = float(host.item()), ver, None
+            ent["distrust"] = max(ent["distrust"] - 1, 0)   # one more re-reading since the last wrong hint
         v = tf._version
         ent["since"] += 1
         if ent["value_version"] == v:
             # (re-read now and then all the same: `tf.data` writes do not bump the version)
             if ent["pending"] is None and ent["since"] >= self.REFRESH_EVERY:
                 self._start_read(ent, tf, alpha)
-            return ent["value"], not ent["no_noterm"]
+            return ent["value"], ent["distrust"] == 0
         if ent["pending"] is None:
             # an unchanged tensor is read on the second sighting of its version; one that is written to between calls on
             # every REFRESH_EVERY-th call (its last reading keeps serving the harmless hint meanwhile)
@@ -256,6 +271,9 @@ class _TerminationHints:
         # "many rays terminate" also from the last reading of a tensor that has been written to since (OPT.py clamps its TF
         # in place every iteration): that hint only chooses how finely the pre-pass proceeds
         if exact and remain > 0.03:   # (the device's threshold is 0.02, evaluated in float: 1.5 x is a wide margin for rounding)
+            key = self._key(tf)
+            if not self._handed or self._handed[-1] != key:
+                self._handed = [k for k in self._handed if k != key][-3:] + [key]
             return N.DR_HINT_NO_EARLY_TERMINATION
         if remain < 1e-4:
             return N.DR_HINT_EARLY_TERMINATION

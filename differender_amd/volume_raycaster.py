@@ -110,6 +110,7 @@ class VolumeRaycaster:
         self.last_stats = None         # workspace header of the most recent forward whose snapshot has arrived (int32 x32)
         self._warned_fallback = False
         self._warned_stale = False
+        self._reported_mark = None
 
     def _watch_workspace(self, workspace, n_rays):
         """Keeps an eye on the fast path's fallback counters without ever synchronising: a 128-byte snapshot of the
@@ -121,7 +122,10 @@ class VolumeRaycaster:
         if self._stats_event is not None and self._stats_event.query():
             self.last_stats = self._stats_host.clone()
             slow = int(self.last_stats[2])
-            if int(self.last_stats[8]):   # the device found a "no early termination" hint wrong: never give it again
+            # the device found a "no early termination" hint wrong: once per forward (its backward's snapshot shows the same
+            # header: same fingerprint in word 3), the TFs that were given the hint lose it for a while
+            if int(self.last_stats[8]) and int(self.last_stats[3]) != self._reported_mark:
+                self._reported_mark = int(self.last_stats[3])
                 F._hints.report_wrong_hint()
             if int(self.last_stats[9]) and not self._warned_stale:
                 self._warned_stale = True

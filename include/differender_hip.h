@@ -54,7 +54,7 @@ enum { DR_HINT_NO_EARLY_TERMINATION = 0x100, DR_HINT_EARLY_TERMINATION = 0x200 }
 
 enum {
     DR_EINVAL = -1,      /* bad argument (null pointer, non-positive extent, unknown enum) */
-    DR_EUNSUPPORTED = -2, /* valid request this build cannot serve (e.g. TF too large for LDS, RCCL not present) */
+    DR_EUNSUPPORTED = -2, /* valid request this build cannot serve (e.g. RCCL not present, LDS opt-in refused by the driver) */
     DR_ECOLLECTIVE = -3   /* RCCL reported an error */
 };
 
@@ -82,7 +82,11 @@ int dr_ray_setup(const float *cam, int n_views, int W, int H, int VX, int VY, in
                  float *entry, float *exit_, float *rays, int32_t *nsamp, void *stream);
 
 /* Scratch memory the fast (brick-centric) march kernels need for n_views views, in bytes; 0 when this
- * problem is only served by the baseline kernels (volume edge > 2000 voxels or a TF too large for LDS).
+ * problem is only served by the baseline kernels (volume edge > 2000 voxels, or a TF of more than 2030 entries: the
+ * brick kernels keep the TF, 16 B per entry, and its double-precision gradient table, 32 B per entry, in LDS beside the
+ * brick). The baseline kernels have NO limit on the TF resolution (like the reference): they stage the TF and the
+ * double-precision d_tf table in LDS up to 3413 entries, the TF alone up to 10240 (d_tf then accumulates with float
+ * atomics on the caller's tensor), and read a larger TF where it lies.
  * The caller allocates it (device memory, 256-byte aligned), passes it to dr_march_fwd and, unchanged,
  * to the dr_march_bwd of the same inputs: the forward leaves the per-segment composite prefixes and the
  * per-ray live sample counts there (the "coarse tape", ~20 B per ray per brick layer). Replaces the

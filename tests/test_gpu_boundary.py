@@ -273,3 +273,41 @@ def test_hidden_tf_writes_heal_themselves(oracle, hiplib):
     assert any("DR_HINT_NO_EARLY_TERMINATION" in str(w.message) for w in caught), [str(w.message) for w in caught]
     assert max(repaired) >= 1 and repaired[-1] == 0, repaired                  # repaired at first, healed at the end
     Fn._hints.__init__()
+
+
+def test_wrong_hint_reports_are_scoped_and_expire(oracle, hiplib):
+    """a wrong-hint report blames the TFs that were recently GIVEN the hint -- not every cached TF, and nobody when the
+    hint was the caller's own -- and the blame expires after a few clean re-readings of the TF's largest alpha."""
+    import warnings
+    from differender_amd import functional as Fn
+    H = Fn._TerminationHints()
+    shape = (32, 32, 32)
+    tf_a = T(oracle.bench_tf(32, 0.004)); tf_b = T(oracle.bench_tf(32, 0.003)); tf_c = T(oracle.bench_tf(32, 0.002))
+
+    def learn(tf):
+        for _ in range(3):
+            h = H.hints(tf, shape, 1.0, 4096, 0); torch.cuda.synchronize()
+        return h
+    assert learn(tf_a) == learn(tf_b) == learn(tf_c) == Fn.N.DR_HINT_NO_EARLY_TERMINATION
+    # a report with nothing handed out recently (an explicit caller hint went wrong): nobody is blamed
+    H._handed = []
+    assert H.report_wrong_hint() == 0
+    assert H.hints(tf_a, shape, 1.0, 4096, 0) == Fn.N.DR_HINT_NO_EARLY_TERMINATION
+    # only the TF that was just given the hint is blamed
+    H._handed = []
+    assert H.hints(tf_b, shape, 1.0, 4096, 0) == Fn.N.DR_HINT_NO_EARLY_TERMINATION
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        assert H.report_wrong_hint() == 1
+    assert any("DR_HINT_NO_EARLY_TERMINATION" in str(w.message) for w in caught)
+    assert H.hints(tf_b, shape, 1.0, 4096, 0) == 0
+    assert H.hints(tf_a, shape, 1.0, 4096, 0) == Fn.N.DR_HINT_NO_EARLY_TERMINATION
+    assert H.hints(tf_c, shape, 1.0, 4096, 0) == Fn.N.DR_HINT_NO_EARLY_TERMINATION
+    # ... and regains it after DISTRUST_REFRESHES clean re-readings (one every REFRESH_EVERY calls), reusing ONE pinned scalar
+    host0 = H._seen[H._key(tf_b)]["host"]
+    calls = 0
+    while H.hints(tf_b, shape, 1.0, 4096, 0) == 0:
+        torch.cuda.synchronize(); calls += 1
+        assert calls <= (H.DISTRUST_REFRESHES + 2) * H.REFRESH_EVERY
+    assert calls >= (H.DISTRUST_REFRESHES - 1) * H.REFRESH_EVERY
+    assert H._seen[H._key(tf_b)]["host"] is host0 and host0 is not None

@@ -446,23 +446,34 @@ def test_tiny_and_ragged_shapes(oracle, F, vshape, WH, R):
         assert grad_close(dt.cpu().numpy(), dt0)[0]
 
 
-def test_large_tf_falls_back_to_supported_kernels(oracle, hiplib):
-    """A TF too large for the LDS budget of the fast kernels: dr_workspace_bytes() reports 0 and AUTO runs the
-    baseline kernels -- same results, no error."""
+@pytest.mark.parametrize("R", [2030, 2048, 4096, 16384])
+def test_large_tf_falls_back_to_supported_kernels(oracle, hiplib, R):
+    """The reference has no limit on the TF resolution. A TF too large for the LDS budget of the fast kernels makes
+    dr_workspace_bytes() report 0 and AUTO run the plain kernels -- same results, no error -- and those keep what fits in LDS:
+    TF + double-precision d_tf table up to R = 3413, the TF alone up to 10240 (d_tf through float atomics), nothing beyond
+    (the double table had silently lowered the backward's limit from 5120 to 3413 entries)."""
     from differender_amd import functional as Fn
     vol, _, cam = scene(oracle, N=24)
-    R = 16384
     tf = oracle.bench_tf(R, 0.03)
-    assert Fn.alloc_workspace(1, (16, 16), vol.shape, R, dev()) is None
-    e, x, r, n = Fn.ray_setup(T(cam[None]), (16, 16), vol.shape, 1.0)
-    with pytest.raises(RuntimeError, match="unsupported"):
-        Fn.march_fwd(T(vol), T(tf), T(cam[None]), e, x, r, n, 4096, 1.0)
-    tf2 = oracle.bench_tf(2048, 0.03)
-    ws = Fn.alloc_workspace(1, (16, 16), vol.shape, 2048, dev())
-    out, _ = Fn.march_fwd(T(vol), T(tf2), T(cam[None]), e, x, r, n, 4096, 1.0, workspace=ws)
-    e0, x0, r0, n0 = oracle.ray_setup(cam, 16, 16, vol.shape)
-    ref, _ = oracle.march_fwd(vol, tf2, cam, e0, x0, r0, n0, 4096, 1.0, 0)
-    assert np.abs(out[0].cpu().numpy() - ref).max() <= FWD_TOL
+    tf[:, 3] = np.linspace(0.01, 0.06, R)
+    WH = (16, 16)
+    ws = Fn.alloc_workspace(1, WH, vol.shape, R, dev())
+    assert (ws is not None) == (R <= 2030)   # the fast kernels' LDS budget (csrc/march_flat.hip: brick_path_supported)
+    e, x, r, n = Fn.ray_setup(T(cam[None]), WH, vol.shape, 1.0)
+    e0, x0, r0, n0 = oracle.ray_setup(cam, *WH, vol.shape)
+    ref, sref = oracle.march_fwd(vol, tf, cam, e0, x0, r0, n0, 4096, 1.0, 0)
+    g = np.random.RandomState(3).randn(*WH, 4).astype(np.float32)
+    dv0, dt0 = oracle.march_bwd(vol, tf, cam, e0, x0, r0, n0, 4096, 1.0, g)
+    for variant in ((0, 1) if ws is not None else (0,)):
+        out, steps = Fn.march_fwd(T(vol), T(tf), T(cam[None]), e, x, r, n, 4096, 1.0, variant=variant, workspace=ws)
+        assert np.array_equal(steps[0].cpu().numpy(), sref)
+        assert np.abs(out[0].cpu().numpy() - ref).max() <= FWD_TOL
+        dv, dt = Fn.march_bwd(T(vol), T(tf), T(cam[None]), e, x, r, n, 4096, 1.0, T(g[None]), out, variant=variant, workspace=ws)
+        assert grad_close(dv.cpu().numpy(), dv0)[0] and grad_close(dt.cpu().numpy(), dt0)[0]
+    for mode in (1,):   # the non-differentiable march with the oversize table
+        refn, _ = oracle.march_fwd(vol, tf, cam, e0, x0, r0, n0, 4096, 1.0, mode)
+        outn, _ = Fn.march_fwd(T(vol), T(tf), T(cam[None]), e, x, r, n, 4096, 1.0, mode, workspace=ws)
+        assert np.abs(outn[0].cpu().numpy() - refn).max() <= FWD_TOL
 
 
 @pytest.mark.parametrize("mode", [0, 1])
