@@ -554,6 +554,7 @@ def main():
     el = torch.tensor([elapsed_local], dtype=torch.float64, device=dev)
     rank_ms = [elapsed_local / max(args.steps, 1) * 1e3]
     rank_phase_ms = None
+    rank_counters = None
     if dist is not None:
         gathered = [torch.zeros_like(el) for _ in range(world)]
         dist.all_gather(gathered, el)
@@ -567,6 +568,14 @@ def main():
         rank_phase_ms = {"fwd_with_allreduce_in_flight": [round(float(t[0]), 4) for t in ph],
                          "fwd_alone": [round(float(t[1]), 4) for t in ph] if fwd_alone_ms is not None else None,
                          "bwd": [round(float(t[2]), 4) for t in ph]}
+        # every rank's workspace counters after its last step (functional.workspace_stats): rays repaired by the count check, rays
+        # marched one by one, wrong "no early termination" hints, backward calls that did not find their forward's tape -- a
+        # mis-sharded run (bands that do not match their buffers, a stale workspace) shows up here, in the one line the driver keeps
+        st_mine = (F.workspace_stats(ws)[:10].to(torch.int64).to(dev) if ws is not None else torch.zeros(10, dtype=torch.int64, device=dev))
+        st_all = [torch.zeros_like(st_mine) for _ in range(world)]
+        dist.all_gather(st_all, st_mine)
+        rank_counters = {"rays_repaired": [int(t[0]) for t in st_all], "rays_marched_individually": [int(t[2]) for t in st_all],
+                         "wrong_hint_views": [int(t[8]) for t in st_all], "stale_workspace_backwards": [int(t[9]) for t in st_all]}
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(total_steps, op=dist.ReduceOp.SUM)
         dist.all_reduce(planned_steps, op=dist.ReduceOp.SUM)
@@ -654,6 +663,7 @@ def main():
         "planned_steps_per_step": int(int(planned_steps.item()) / max(args.steps, 1)),  # executed/planned < 1 = early termination
         "ms_per_step_ranks": [round(v, 4) for v in rank_ms],
         "phase_ms_ranks": rank_phase_ms,   # N > 1: per-rank forward time with / without the gradient all-reduce in flight, backward
+        "workspace_counters_ranks": rank_counters,   # N > 1: per-rank fallback counters (all zero / a few single-sample rays when healthy)
         "allreduce_ms": None if allreduce_ms is None else round(allreduce_ms, 4),
         "allreduce_bytes": allreduce_bytes,
         "allreduce_model_ms": allreduce_model(allreduce_bytes, world),
@@ -685,7 +695,14 @@ def main_opt(args):
     from differender_amd.utils import dssim_mse_loss
 
     torch.manual_seed(1234 + rank)
-    vol_gt = synth_volume_torch(N, dev).permute(1, 2, 0).contiguous()[None]   # (1, D, H, W)
+    field = synth_volume_torch(N, dev)
+    if args.scene == "ct":   # CT-like: the field inside a ball of radius 0.6, air (exactly 0) outside -- mostly empty under tf1
+        ax = torch.linspace(-1.0, 1.0, N, device=dev)
+        r2 = ax[:, None, None] ** 2 + ax[None, :, None] ** 2 + ax[None, None, :] ** 2
+        field = torch.where(r2 < 0.36, field, torch.zeros_like(field))
+        del r2
+    vol_gt = field.permute(1, 2, 0).contiguous()[None]   # (1, D, H, W)
+    del field
     vol = vol_gt.clone()
     mask = torch.rand_like(vol) < 0.05                                         # OPT.py:44-45
     vol[mask] = torch.rand_like(vol[mask])
@@ -768,7 +785,8 @@ def main_opt(args):
         "value": round(args.steps * world / elapsed, 4), "unit": "iterations/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(it_ms, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"OPT demo: {N}^3 f32 volume (5 % voxels randomised), {IMG}^2 image, {BS} views per iteration "
+        "config": {"scene": args.scene, "loss": "DSSIM + MSE" if args.dssim else "MSE",
+                   "workload": f"OPT demo: {N}^3 f32 volume ({'CT-like: air outside a ball; ' if args.scene == 'ct' else ''}5 % voxels randomised), {IMG}^2 image, {BS} views per iteration "
                                f"(1 orbit + {BS - 1} random, r=2.7), tf1 with {R} entries, max_samples=1024, jitter on; per "
                                "iteration: nondiff GT render at sr 8, differentiable render at sr 1, " + ("DSSIM + MSE" if args.dssim else "MSE") + ", backward to volume "
                                "and TF, AdamW + OneCycleLR step, clamp",

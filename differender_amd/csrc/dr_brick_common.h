@@ -31,6 +31,9 @@ struct BrickParams {
                          // ray is marched whole)
     uint8_t *rayflag;    // [view][NP]: 1 = irregular ray (marched whole by F2 / B2)
     int32_t *ws_steps;   // [view][NP]: live samples per ray (F2 -> B1)
+    unsigned long long *unlit;  // [view][lm_words][NP]: non-differentiable renders with an alpha pre-pass -- bit l of a ray's mask: the pre-pass
+    int lm_words;               //   marched the ray's segment of layer l and found NO sample with alpha > 1e-3 (the colour march
+                                //   skips it: its count and its zero partial are already in place). 0: feature off (NL > 128).
     unsigned int *stats; // workspace header, words ST_* below
     unsigned int *vflags; // [view] 1 if some ray of the view may reach alpha >= 0.99 (the alpha pre-pass runs for it);
                           // [n_views + view] 1 if the camera sits inside (or on) the volume: rays start behind the eye, the
@@ -536,6 +539,7 @@ static __global__ __launch_bounds__(256) void clear_counts_if_prepass_kernel(uin
 // ------------------------------------------------------------------------------------------------ host
 struct Workspace {
     float4 *seg_rgba; uint16_t *seg_cnt; int32_t *ws_steps; uint8_t *rayflag; unsigned int *stats, *vflags, *n_items;
+    unsigned long long *unlit; size_t unlit_bytes; int lm_words;   // right behind seg_cnt: one memset clears the counts and the masks
     BrickCtxRec *ctx;
     BrickItem *items;
     size_t cnt_bytes;
@@ -556,6 +560,11 @@ static inline size_t ws_layout(void *base, int n_views, int NP, const BrickGrid 
     o += 16;
     if (w) { w->seg_cnt = reinterpret_cast<uint16_t *>(b + o); w->cnt_bytes = nseg * 2; }
     o += align16(nseg * 2);
+    {   // "all unlit" masks of the non-differentiable render: one bit per (ray, layer), up to 128 layers (volumes up to ~770^3)
+        const int lm = NL <= 64 ? 1 : (NL <= 128 ? 2 : 0);
+        if (w) { w->unlit = reinterpret_cast<unsigned long long *>(b + o); w->lm_words = lm; w->unlit_bytes = (size_t)n_views * NP * 8 * lm; }
+        o += align16((size_t)n_views * NP * 8 * lm);
+    }
     if (w) w->ws_steps = reinterpret_cast<int32_t *>(b + o);
     o += align16((size_t)n_views * NP * 4);
     if (w) w->rayflag = reinterpret_cast<uint8_t *>(b + o);
@@ -587,7 +596,7 @@ static inline BrickParams<VT> make_brick_params(const MarchArgs &a, const Worksp
     P.near_ = (float)a.near_plane; P.near_h = (float)near_h; P.near_w = (float)(near_h * ((double)P.imgW / (double)a.H));
     P.g = make_brick_grid(a.VX, a.VY, a.VZ);
 
-    P.seg_rgba = w.seg_rgba; P.seg_cnt = w.seg_cnt; P.rayflag = w.rayflag; P.stats = w.stats; P.vflags = w.vflags; P.n_views = a.n_views; P.ws_steps = w.ws_steps;
+    P.seg_rgba = w.seg_rgba; P.seg_cnt = w.seg_cnt; P.rayflag = w.rayflag; P.stats = w.stats; P.vflags = w.vflags; P.n_views = a.n_views; P.ws_steps = w.ws_steps; P.unlit = w.unlit; P.lm_words = 0;
     P.hint_noterm = (a.hints & DR_HINT_NO_EARLY_TERMINATION) ? 1 : 0;
     P.use_live = a.use_live; P.ctx = w.ctx; P.items = w.items; P.n_items = w.n_items;
     P.mark = ws_fingerprint(a);

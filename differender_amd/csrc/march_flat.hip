@@ -47,6 +47,9 @@ namespace dr {
 #ifndef DR_FNT_BWD
 #define DR_FNT_BWD 512
 #endif
+#ifndef DR_UNLIT_SKIP
+#define DR_UNLIT_SKIP 1   // nondiff renders: the colour march skips the segments the alpha pre-pass found unlit (round 5)
+#endif
 #ifndef DR_ABL_EXTRA_LDS_BWD
 #define DR_ABL_EXTRA_LDS_BWD 0   // what-if: bytes of unused LDS per backward workgroup (fewer workgroups per CU)
 #endif
@@ -106,17 +109,24 @@ namespace dr {
 #ifndef DR_BWDTF_WAVES
 #define DR_BWDTF_WAVES 4
 #endif
-// Workgroup configuration of a brick kernel: forward / backward with a gradient box / backward w.r.t. the TF only
-template <bool BWD, bool WANT_VOL>
+// Workgroup configuration of a brick kernel: forward / alpha pre-pass / backward with a gradient box / backward w.r.t. the TF only
+#ifndef DR_FEC_ALPHA
+#define DR_FEC_ALPHA DR_FEC_FWD       // alpha pre-pass: segment-table entries (160 + DR_ALPHA_WAVES 6: six workgroups per CU -- measured, round 5)
+#endif
+#ifndef DR_ALPHA_WAVES
+#define DR_ALPHA_WAVES DR_FWD_WAVES
+#endif
+template <bool BWD, bool WANT_VOL, bool ALPHA = false>
 struct FlatCfg {
     static constexpr int FNT = BWD ? (WANT_VOL ? DR_FNT_BWD : DR_FNT_BWDTF) : DR_FNT_FWD;      // threads per workgroup
-    static constexpr int EC = BWD ? (WANT_VOL ? DR_FEC_BWD : DR_FEC_BWDTF) : DR_FEC_FWD;       // segment-table entries (= candidates per round)
-    static constexpr int WAVES = BWD ? (WANT_VOL ? DR_BWD_WAVES : DR_BWDTF_WAVES) : DR_FWD_WAVES;  // waves per SIMD the registers must allow
+    static constexpr int EC = BWD ? (WANT_VOL ? DR_FEC_BWD : DR_FEC_BWDTF) : (ALPHA ? DR_FEC_ALPHA : DR_FEC_FWD);   // segment-table entries (= candidates per round)
+    static constexpr int WAVES = BWD ? (WANT_VOL ? DR_BWD_WAVES : DR_BWDTF_WAVES) : (ALPHA ? DR_ALPHA_WAVES : DR_FWD_WAVES);  // waves per SIMD the registers must allow
     static constexpr int UNEVEN = (BWD && WANT_VOL) ? DR_BWD_UNEVEN : 0;                      // uneven dealing (cand_load)
     static constexpr int FNW = FNT / 64, CW = EC / FNW;                                       // waves; candidates per wave and round
     static_assert(CW <= 64 && CW * FNW == EC, "one candidate per lane and round");
 };
 
+constexpr int VALID_LIT = 1 << 30;   // FlatLds::valid, alpha pre-pass of a non-differentiable render: a piece of the segment held a lit sample
 struct FlatLds {
     float4 *tf; float *box; unsigned long long *dbox; unsigned long long *dtf;
     float4 *ray0;   // (t0, exit, (float)(n-1), RN(1/(n-1)))
@@ -132,8 +142,8 @@ struct FlatLds {
 // LDS layout: everything of compile-time size first (so every address below is an immediate), then the two
 // tables whose size depends on the run-time TF resolution R.
 template <bool BWD>
-__host__ __device__ constexpr size_t flat_fixed_bytes(bool want_vol) {
-    const int EC = want_vol ? FlatCfg<BWD, true>::EC : FlatCfg<BWD, false>::EC;
+__host__ __device__ constexpr size_t flat_fixed_bytes(bool want_vol, bool alpha = false) {
+    const int EC = want_vol ? FlatCfg<BWD, true>::EC : (alpha ? FlatCfg<BWD, false, true>::EC : FlatCfg<BWD, false>::EC);
     size_t s = ((size_t)BOX_LDS * 4 + 15) / 16 * 16;
     if (BWD && want_vol) s += ((size_t)DR_DBOX_WORDS * 8 + 15) / 16 * 16;
     s += (size_t)EC * 32;
@@ -143,12 +153,12 @@ __host__ __device__ constexpr size_t flat_fixed_bytes(bool want_vol) {
     return s;
 }
 template <bool BWD>
-__host__ __device__ inline size_t flat_lds_bytes(int R, bool want_vol, bool want_tf) {
-    return flat_fixed_bytes<BWD>(want_vol) + (size_t)R * 16 + ((BWD && want_tf) ? (want_vol ? DR_DTF_BYTES(R) : (size_t)R * 32) : 0);
+__host__ __device__ inline size_t flat_lds_bytes(int R, bool want_vol, bool want_tf, bool alpha = false) {
+    return flat_fixed_bytes<BWD>(want_vol, alpha) + (size_t)R * 16 + ((BWD && want_tf) ? (want_vol ? DR_DTF_BYTES(R) : (size_t)R * 32) : 0);
 }
-template <bool BWD, bool WANT_VOL, bool WANT_TF>
+template <bool BWD, bool WANT_VOL, bool WANT_TF, bool ALPHA = false>
 __device__ __forceinline__ FlatLds flat_carve(unsigned char *smem, int R) {
-    constexpr int EC = FlatCfg<BWD, WANT_VOL>::EC;
+    constexpr int EC = FlatCfg<BWD, WANT_VOL, ALPHA>::EC;
     FlatLds L;
     size_t o = 0;
     L.box = reinterpret_cast<float *>(smem + o); o += align16(BOX_LDS * 4);
@@ -257,6 +267,7 @@ struct CandData {
     int pl; size_t p;
     int n; float entry, exit_, vx, vy, vz;
     int live; unsigned char rflag;
+    unsigned long long um0, um1;   // the ray's "all unlit" layer masks (colour march of a non-differentiable render)
 };
 constexpr int MAIN_CAND = CTX_MAIN_CAND;  // candidates of a brick the main launch handles (4 listing rounds); the rest become items
 constexpr int ITEM_MAX_CAND = CTX_ITEM_MAX_CAND;  // candidates per overflow item at most (its list of hits lives in LDS: 2 B each)
@@ -299,7 +310,7 @@ __device__ __forceinline__ bool line_meets_brick(const BrickCtx &c, f3 cam, f3 d
 template <typename VT, int MODE, bool BWD, bool ALPHA, bool WANT_VOL>
 __device__ __forceinline__ void cand_load(const BrickParams<VT> &P, const BrickCtx &c, int view, int cbase, int ncand,
                                           const unsigned short *hits, int c_lo, int ncand_all, CandData &d) {
-    using Cfg = FlatCfg<BWD, WANT_VOL>;
+    using Cfg = FlatCfg<BWD, WANT_VOL, ALPHA>;
     constexpr int FNW = Cfg::FNW, CW = Cfg::CW;  // candidates per wave and round
     const int NP = P.W * P.H;
     const int nj = c.j1 - c.j0 + 1;
@@ -324,7 +335,7 @@ __device__ __forceinline__ void cand_load(const BrickParams<VT> &P, const BrickC
         d.have = lane_ < 4 * per && cc < ncand;
     }
     d.pl = 0; d.p = 0; d.n = 0; d.entry = -1.0f; d.exit_ = 0.f; d.vx = d.vy = d.vz = 0.f;
-    d.live = 0; d.rflag = 0;
+    d.live = 0; d.rflag = 0; d.um0 = d.um1 = 0ull;
     if (!d.have) return;
     if (hits) cc = c_lo + (int)hits[cc];
     // cc / nj without the ~25-instruction integer division while the rectangle is small (always, unless the camera sits
@@ -339,6 +350,13 @@ __device__ __forceinline__ void cand_load(const BrickParams<VT> &P, const BrickC
     d.exit_ = P.exit_[d.p];
     d.vx = P.rays[3 * d.p]; d.vy = P.rays[3 * d.p + 1]; d.vz = P.rays[3 * d.p + 2];
     if (BWD || (!ALPHA && P.use_live) || (ALPHA && !P.pp_first)) d.live = P.ws_steps[d.p];
+    if constexpr (MODE == DR_MODE_NONDIFF && !BWD && !ALPHA) {
+        if (P.lm_words > 0) {   // uniform; same batch of loads as the ray buffers
+            const unsigned long long *um = P.unlit + ((size_t)view * P.lm_words * NP + d.pl);
+            d.um0 = um[0];
+            if (P.lm_words > 1) d.um1 = um[NP];
+        }
+    }
     if (BWD) d.rflag = P.rayflag[d.p];  // (the three float4 of the coarse tape / gradients are fetched per chunk: the
                                         //  backward kernel is register-bound and they would be held across the box staging)
 }
@@ -362,7 +380,7 @@ __device__ __forceinline__ int wave_incl_sum(int v) {
 template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool ALPHA = false, int KS = 1>
 __device__ __forceinline__ void flat_build_entries(const BrickParams<VT> &P, const BrickCtx &c, f3 cam, int view,
                                                    const CandData &d, FlatLds &L, int &nE, int &M) {
-    constexpr int CW = FlatCfg<BWD, WANT_VOL>::CW;
+    constexpr int CW = FlatCfg<BWD, WANT_VOL, ALPHA>::CW;
     bool has = false;
     int s0 = 0, s1 = 0;
     float t0 = 0.f, nm1 = 0.f;
@@ -386,6 +404,19 @@ __device__ __forceinline__ void flat_build_entries(const BrickParams<VT> &P, con
             has = segment_range(c, cam, vd, t0, exit_, n, nmarch, s0, s1);
         }
     }
+    // the ray's layer of this brick (dr_brick.h): distance from the brick of the ray's first sample
+    int lay = 0;
+    if (has) {
+        int ebx, eby, ebz;
+        entry_brick(P.vol.scx, P.vol.scy, P.vol.scz, cam, vd, t0, ebx, eby, ebz);
+        lay = ray_layer(c.bx, c.by, c.bz, ebx, eby, ebz);
+    }
+    if constexpr (MODE == DR_MODE_NONDIFF && !BWD && !ALPHA) {
+        // Colour march of a non-differentiable render after an alpha pre-pass (round 5): the pre-pass has marched this very
+        // segment, counted its samples and found none with alpha > 1e-3 (VR.py:334 skips such samples: they composite nothing).
+        // Its count and its all-zero partial are in the workspace already -- nothing to march, nothing to write.
+        if (has && P.lm_words > 0 && (((lay < 64 ? d.um0 : d.um1) >> (lay & 63)) & 1ull)) has = false;
+    }
     const unsigned long long hm = __ballot(has);
     const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
     const int flen = has ? (s1 - s0 + KS - 1) / KS * KS : 0;  // flat length: a multiple of KS
@@ -397,10 +428,7 @@ __device__ __forceinline__ void flat_build_entries(const BrickParams<VT> &P, con
         const int off = incl - flen;
         L.ray0[slot] = make_float4(t0, exit_, nm1, 1.0f / nm1);  // n >= 2 (ray_is_regular)
         L.ray1[slot] = make_float4(vd.x, vd.y, vd.z, __int_as_float(pl));
-        // the ray's layer of this brick (dr_brick.h): distance from the brick of the ray's first sample
-        int ebx, eby, ebz;
-        entry_brick(P.vol.scx, P.vol.scy, P.vol.scz, cam, vd, t0, ebx, eby, ebz);
-        L.segi[slot] = ray_layer(c.bx, c.by, c.bz, ebx, eby, ebz) * (P.W * P.H) + pl;
+        L.segi[slot] = lay * (P.W * P.H) + pl;
         L.s_rel[slot] = s0 - off;
         L.offs[slot + wave_] = off;
         L.slen[slot] = s1 - s0;
@@ -703,7 +731,7 @@ template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, bool ALP
 __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsigned char *smem, const int slot, const int view,
                                                 const int c_lo, const int c_hi, bool &box_valid) {
     if (ALPHA && P.vflags[view] == 0u) return;  // uniform: no ray of this view can terminate early
-    using Cfg = FlatCfg<BWD, WANT_VOL>;
+    using Cfg = FlatCfg<BWD, WANT_VOL, ALPHA>;
     constexpr int EC = Cfg::EC;
     constexpr int ROUND = Cfg::UNEVEN ? 4 * (8 * Cfg::UNEVEN + 4 * (8 - Cfg::UNEVEN)) : EC;  // candidates consumed per round (cand_load)
     constexpr int FNT = Cfg::FNT;
@@ -730,7 +758,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
 #if DR_SETPRIO
     __builtin_amdgcn_s_setprio(3);  // the staging / listing prologue is short and latency-bound: let it overtake sample loops
 #endif
-    FlatLds L = flat_carve<BWD, WANT_VOL, WANT_TF>(smem, P.R);
+    FlatLds L = flat_carve<BWD, WANT_VOL, WANT_TF, ALPHA>(smem, P.R);
     VolView<VT> vol = P.vol;
     vol.p += view * P.vol_vs;
     const int NP = P.W * P.H;
@@ -748,7 +776,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
     const unsigned short *hits = nullptr;
     int r_lo = c_lo, r_hi = ncand;
     if (HEAVY) {
-        unsigned short *hl = reinterpret_cast<unsigned short *>(smem + align16(flat_lds_bytes<BWD>(P.R, WANT_VOL, WANT_TF)));
+        unsigned short *hl = reinterpret_cast<unsigned short *>(smem + align16(flat_lds_bytes<BWD>(P.R, WANT_VOL, WANT_TF, ALPHA)));
         int *nhit = reinterpret_cast<int *>(hl + ITEM_MAX_CAND);
         if (threadIdx.x == 0) *nhit = 0;
         __syncthreads();
@@ -897,6 +925,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                 const int slen = L.slen[e];
                 float Tl = 1.0f;
                 int cnt_lane = 0;  // in-brick samples of this lane
+                bool lit_lane = false;  // nondiff: some sample of this lane has alpha > 1e-3
 #pragma unroll
                 for (int j = 0; j < KS; ++j) {
                     if (j >= ks) continue;  // uniform
@@ -920,6 +949,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                     // alpha <= 1e-3 (VR.py:334), and transparent stretches are wave-uniform (lanes = consecutive samples)
                     if constexpr (MODE == DR_MODE_NONDIFF) {
                         const bool vis = va && sa.a > 1e-3f;
+                        lit_lane = lit_lane || vis;
                         if (__any(vis)) {
                             if (vis) Tl *= 1.0f - opacity_of_alpha(sa.a, P.inv_sr);
                         }
@@ -939,11 +969,34 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                 float cf[1] = {(float)cnt_lane};
                 seg_scan_sum<1>(cf, lane, sl);
                 const bool piece_end = act && (seg_end || lane == 63 || f + ks >= fb);
+                // nondiff: does the piece [sl, lane] hold a lit sample? (bit VALID_LIT of the segment's counter collects the pieces)
+                unsigned long long litm = 0ull;
+                if constexpr (MODE == DR_MODE_NONDIFF) litm = __ballot(lit_lane);
                 if (piece_end) {
                     const int cntp = (int)cf[0];
-                    const int before = cntp ? atomicAdd(&L.valid[e], cntp) : L.valid[e];
-                    if (seg_end && before + cntp > 0)
-                        P.seg_rgba[seg_view + L.segi[e]] = make_float4(0.f, 0.f, 0.f, 1.0f - Tl);
+                    int before = cntp ? atomicAdd(&L.valid[e], cntp) : L.valid[e];
+                    bool seg_lit = true;
+                    if constexpr (MODE == DR_MODE_NONDIFF) {
+                        const unsigned long long upto = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+                        const bool piece_lit = (litm & upto & ~((1ull << sl) - 1ull)) != 0ull;
+                        seg_lit = piece_lit || (before & VALID_LIT);
+                        if (piece_lit && !(before & VALID_LIT)) atomicOr(&L.valid[e], VALID_LIT);
+                        before &= VALID_LIT - 1;
+                    }
+                    if (seg_end && before + cntp > 0) {
+                        const int sgi = L.segi[e];
+                        P.seg_rgba[seg_view + sgi] = make_float4(0.f, 0.f, 0.f, 1.0f - Tl);
+                        if constexpr (MODE == DR_MODE_NONDIFF) {
+                            // every sample of the ray in this brick was marched (the pre-pass has no live limit) and none is lit: tell the
+                            // colour march (flat_build_entries). Layer = (slot - pixel) / NP through the float reciprocal: exact, the
+                            // quotient is an integer below 128 and the error of the product below 1e-4.
+                            if (!seg_lit && P.lm_words > 0) {
+                                const int plq = __float_as_int(r1.w);
+                                const int lay = (int)((float)(sgi - plq) * __builtin_amdgcn_rcpf((float)NP) + 0.5f);
+                                atomicOr(P.unlit + ((size_t)view * P.lm_words + (lay >> 6)) * NP + plq, 1ull << (lay & 63));
+                            }
+                        }
+                    }
                 }
                 continue;
             }
@@ -1320,7 +1373,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
             // sample counts of the segments this wave owns (only this wave added to them)
             bool some = false;
             for (int e = ea + lane; e < eb; e += 64) {
-                const int v = L.valid[e];
+                const int v = L.valid[e] & (VALID_LIT - 1);
                 if (v > 0) { P.seg_cnt[seg_view + L.segi[e]] = (uint16_t)min(v, 65535); some = true; }
             }
             if (!ALPHA && __any(some) && lane == 0)  // tell the backward that this brick holds live samples of the view
@@ -1404,7 +1457,7 @@ constexpr int ITEM_GRID_FWD = DR_ITEM_GRID_FWD, ITEM_GRID_BWD = DR_ITEM_GRID_BWD
 constexpr int ITEM_RUN = DR_ITEM_RUN;   // consecutive items a workgroup takes at a time
 
 template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, bool ALPHA = false, int KF = 1, bool NARROW = true>
-__global__ __launch_bounds__((FlatCfg<BWD, WANT_VOL>::FNT), (FlatCfg<BWD, WANT_VOL>::WAVES)) void brick_flat_kernel(BrickParams<VT> P) {
+__global__ __launch_bounds__((FlatCfg<BWD, WANT_VOL, ALPHA>::FNT), (FlatCfg<BWD, WANT_VOL, ALPHA>::WAVES)) void brick_flat_kernel(BrickParams<VT> P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef DR_VIEW_FASTEST
     // (tried: consecutive workgroups = the same brick of consecutive views, so that the box comes from L2 after its first
@@ -1440,7 +1493,7 @@ __global__ __launch_bounds__((FlatCfg<false, false>::FNT), (FlatCfg<false, false
 }
 // the overflow items of heavy bricks (all views), worked off by a fixed, small grid
 template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, bool ALPHA = false, int KF = 1, bool NARROW = true>
-__global__ __launch_bounds__((FlatCfg<BWD, WANT_VOL>::FNT), (FlatCfg<BWD, WANT_VOL>::WAVES)) void brick_flat_items_kernel(BrickParams<VT> P) {
+__global__ __launch_bounds__((FlatCfg<BWD, WANT_VOL, ALPHA>::FNT), (FlatCfg<BWD, WANT_VOL, ALPHA>::WAVES)) void brick_flat_items_kernel(BrickParams<VT> P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (BWD && P.stats[ST_MARK] != P.mark) return;  // uniform over the grid: not this call's workspace, the item list is garbage
     const int n_items = min((int)*P.n_items, ITEM_CAP);
@@ -1575,7 +1628,13 @@ static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     // what-if (WRONG results unless the caller zeroed the workspace): the bound for folding the count memset into another kernel
     e = hipSuccess;
 #else
-    e = hipMemsetAsync(w.n_items, 0, 16 + w.cnt_bytes, stream);  // the item counter (brick_ctx_kernel appends) and seg_cnt behind it
+    // Non-differentiable render with an alpha pre-pass: the pre-pass tells the colour march which (ray, layer) segments hold no
+    // sample with alpha > 1e-3 ("unlit" masks behind seg_cnt, BrickParams::unlit); such segments keep the pre-pass's count and
+    // zero partial, so seg_cnt is NOT cleared between the two passes (see below).
+    const bool unlit_masks = a.mode == DR_MODE_NONDIFF && !(a.hints & DR_HINT_NO_EARLY_TERMINATION) && w.lm_words > 0 && DR_UNLIT_SKIP;
+    P.lm_words = unlit_masks ? w.lm_words : 0;
+    // the item counter (brick_ctx_kernel appends) and seg_cnt behind it (and the masks behind that)
+    e = hipMemsetAsync(w.n_items, 0, 16 + (unlit_masks ? align16(w.cnt_bytes) + w.unlit_bytes : w.cnt_bytes), stream);
 #endif
     if (e != hipSuccess) return (int)e;
     const size_t lds = flat_lds_bytes<false>(a.R, false, false);
@@ -1609,15 +1668,18 @@ static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
         // launches (~10 us: +0.7 % on the 512^3 headline at G = 2 for -2.5 % with tf1), so below sampling rate 3: G = 1.
         const int G = (a.sr >= 3.0f || (a.hints & DR_HINT_EARLY_TERMINATION)) ? DR_PP_GROUPS : 1;
         MarchArgs pa = a;
+        const size_t lds_f1 = lds;
+        (void)lds_f1;
+        const size_t lds = flat_lds_bytes<false>(a.R, false, false, true);   // the pre-pass's own table size (FlatCfg<.., ALPHA>)
         for (int gi = 0; gi < G; ++gi) {
             pa.pp_l0 = g.NL * gi / G; pa.pp_l1 = g.NL * (gi + 1) / G; pa.pp_first = gi == 0;
             P.pp_l0 = pa.pp_l0; P.pp_l1 = pa.pp_l1; P.pp_first = pa.pp_first;
             // (several bricks per workgroup would quarter the cost of this launch when it is gated off -- 27 us of workgroup
             // exits at 512^3 -- but the looped kernel needs 96 VGPRs instead of 66 and is 3-5 % slower when it runs)
             if (a.mode == DR_MODE_DIFF) {
-                DR_LAUNCH_BOTH(DR_MODE_DIFF, false, false, false, true, DR_ALPHA_K, (FlatCfg<false, false>::FNT))
+                DR_LAUNCH_BOTH(DR_MODE_DIFF, false, false, false, true, DR_ALPHA_K, (FlatCfg<false, false, true>::FNT))
             } else {
-                DR_LAUNCH_BOTH(DR_MODE_NONDIFF, false, false, false, true, DR_ALPHA_K, (FlatCfg<false, false>::FNT))
+                DR_LAUNCH_BOTH(DR_MODE_NONDIFF, false, false, false, true, DR_ALPHA_K, (FlatCfg<false, false, true>::FNT))
             }
             if ((e = hipGetLastError()) != hipSuccess) return (int)e;
             const int rc = launch_ray_alpha(pa, stream);
@@ -1626,6 +1688,10 @@ static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
         const int rc2 = launch_ray_cross(a, stream);
         if (rc2) return rc2;
         const size_t n16 = (w.cnt_bytes + 15) / 16;  // (seg_cnt is 16-byte aligned and padded)
+        // With the unlit masks the counts stay: the colour march overwrites the count of every segment it marches; what it does
+        // not touch is either an unlit segment in front of the ray's last live sample (count complete: a ray terminates on a
+        // lit sample, and nondiff marches have no sample limit) or lies in a layer behind it, which F2 never reads.
+        if (!unlit_masks)
         hipLaunchKernelGGL(clear_counts_if_prepass_kernel, dim3((unsigned)((n16 + 255) / 256 < 4096 ? (n16 + 255) / 256 : 4096)), dim3(256), 0,
                            stream, reinterpret_cast<uint4 *>(w.seg_cnt), n16, w.vflags, a.n_views);
     }
