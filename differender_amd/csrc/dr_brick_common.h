@@ -41,6 +41,7 @@ struct BrickParams {
     int n_views;
     unsigned int mark;   // fingerprint of this forward/backward pair (ws_fingerprint): the forward leaves it in stats[ST_MARK],
                          // the backward trusts records, live flags, ray flags and work items only if it finds it there
+    int nondiff;         // forward: non-differentiable march (a sample composites only if alpha > 1e-3, VR.py:334; differentiable: if alpha != 0)
     int hint_noterm;     // forward: the caller said no ray can terminate early and the pre-pass was not launched; F2 checks
     int use_live;        // forward: ws_steps holds each ray's exact live sample count (from the alpha pre-pass)
     int pp_l0, pp_l1, pp_first;  // alpha pre-pass phase: brick layers [pp_l0, pp_l1); later phases skip terminated rays
@@ -76,6 +77,7 @@ struct BrickCtx {
     float lo[3], hi[3];           // world AABB of the brick's cells, with slack
     int i0, i1, j0, j1;           // candidate pixel rectangle (inclusive); empty if i0 > i1
     int live;                     // from the workspace record (see BrickCtxRec)
+    int maybe_empty;              // forward: nine probes of the brick found nothing that composites (brick_ctx_kernel; see brick_empty_test)
 };
 
 // BrickCtx as stored in the workspace (64 B): every workgroup of F1 / P1 / B1 reads its record with scalar loads
@@ -86,14 +88,14 @@ struct BrickCtxRec {
     float hi[3]; int i1;
     int j0, j1;
     int live;   // set by the flat forward when the brick marched at least one sample of the view (backward skips the others)
-    int pad1;
+    int maybe_empty;   // forward: the brick's corner and centre voxels all map to transfer-function texels that composite nothing
 };
 __device__ __forceinline__ void brick_ctx_load(const BrickCtxRec *rec, BrickCtx &c) {
     const BrickCtxRec r = *rec;
     c.bx = r.bx; c.by = r.by; c.bz = r.bz; c.layer = r.layer;
     c.ox = c.bx * BRK - 1; c.oy = c.by * BRK - 1; c.oz = c.bz * BRK - 1;
     for (int k = 0; k < 3; ++k) { c.lo[k] = r.lo[k]; c.hi[k] = r.hi[k]; }
-    c.i0 = r.i0; c.i1 = r.i1; c.j0 = r.j0; c.j1 = r.j1; c.live = r.live;
+    c.i0 = r.i0; c.i1 = r.i1; c.j0 = r.j0; c.j1 = r.j1; c.live = r.live; c.maybe_empty = r.maybe_empty;
 }
 
 #ifndef DR_RECT_SLACK
@@ -234,6 +236,32 @@ __device__ __forceinline__ unsigned int may_terminate(const float4 *t, int R, fl
     const float remain = powf(1.0f - op, n_max);  // transmittance left after the longest possible ray
     return (remain <= 0.02f) ? 1u : 0u;           // 0.01 is the exact bound; keep a margin
 }
+// ---- Empty bricks (round 5) ------------------------------------------------------------------------------------------------
+// A sample composites nothing when its TF alpha is <= 1e-3 (non-differentiable march, VR.py:334: the sample is skipped) or
+// exactly 0 (differentiable march: opacity 0, colour L * rgb * 0). CT-like data under the reference's presets is mostly such
+// samples -- air. A brick ALL of whose samples composite nothing needs no tap, no TF lookup, no shading: only its rays' sample
+// counts (F2's check) and all-zero partials. Deciding that exactly takes the brick's voxel range, which the workgroup has when
+// its box is staged (brick_empty_test in march_flat.hip); whether the test is worth running is guessed here, once per brick,
+// from nine voxels: a brick whose corners and centre all composite nothing is a candidate.
+__device__ __forceinline__ bool texel_composites(float a, int nondiff) { return nondiff ? !(a <= 1e-3f * (1.0f - 4.8e-7f)) : !(a == 0.0f); }
+template <typename VT>
+__device__ __forceinline__ int brick_probe_empty(const BrickParams<VT> &P, int view, const BrickCtx &c) {
+    const VT *vp = P.vol.p + view * P.vol_vs;
+    const float4 *tf = P.tf + view * P.tf_vs;
+    bool ok = true;
+    for (int k = 0; k < 9 && ok; ++k) {
+        // corners of the brick's cell range (voxels ox+1 .. ox+1+BRK, clamped into the volume) and its centre
+        const int dx = k == 8 ? BRK / 2 : ((k & 1) ? BRK : 0), dy = k == 8 ? BRK / 2 : ((k & 2) ? BRK : 0), dz = k == 8 ? BRK / 2 : ((k & 4) ? BRK : 0);
+        const int x = min(c.ox + 1 + dx, P.vol.VX - 1), y = min(c.oy + 1 + dy, P.vol.VY - 1), z = min(c.oz + 1 + dz, P.vol.VZ - 1);
+        const float v = ld_voxel(vp + ((long long)x * P.vol.sx + (long long)y * P.vol.sy + (long long)z * P.vol.sz));
+        int lo; float fr;
+        low_high_frac(v * P.tf_len, lo, fr);
+        lo = min(lo, P.R - 1);
+        ok = (v == v) && !texel_composites(tf[lo].w, P.nondiff) && !texel_composites(tf[min(lo + 1, P.R - 1)].w, P.nondiff);
+    }
+    return ok ? 1 : 0;
+}
+
 // Also initialises the workspace header for this call: counters, per-view "may terminate" flags (n_max > 0: the alpha
 // pre-pass is available) and the mark -- no separate memset / flag kernel. Runs once per forward; the backward of the same
 // inputs reuses the records (and the live flags the forward march leaves in them).
@@ -260,7 +288,8 @@ static __global__ __launch_bounds__(256) void brick_ctx_kernel(BrickParams<VT> P
     BrickCtxRec r;
     r.bx = c.bx; r.by = c.by; r.bz = c.bz; r.layer = c.layer;
     for (int k = 0; k < 3; ++k) { r.lo[k] = c.lo[k]; r.hi[k] = c.hi[k]; }
-    r.i0 = c.i0; r.i1 = c.i1; r.j0 = c.j0; r.j1 = c.j1; r.pad1 = 0;
+    r.i0 = c.i0; r.i1 = c.i1; r.j0 = c.j0; r.j1 = c.j1;
+    r.maybe_empty = forward ? brick_probe_empty(P, view, c) : 0;
     const int slot_b = near_first_brick(P, b, view);  // (an involution: slot -> brick and brick -> slot are the same flips)
     r.live = forward ? 0 : out[(size_t)view * nbricks + slot_b].live;
     out[(size_t)view * nbricks + slot_b] = r;
@@ -598,6 +627,7 @@ static inline BrickParams<VT> make_brick_params(const MarchArgs &a, const Worksp
 
     P.seg_rgba = w.seg_rgba; P.seg_cnt = w.seg_cnt; P.rayflag = w.rayflag; P.stats = w.stats; P.vflags = w.vflags; P.n_views = a.n_views; P.ws_steps = w.ws_steps; P.unlit = w.unlit; P.lm_words = 0;
     P.hint_noterm = (a.hints & DR_HINT_NO_EARLY_TERMINATION) ? 1 : 0;
+    P.nondiff = a.mode == DR_MODE_NONDIFF ? 1 : 0;
     P.use_live = a.use_live; P.ctx = w.ctx; P.items = w.items; P.n_items = w.n_items;
     P.mark = ws_fingerprint(a);
     P.pp_l0 = a.pp_l0; P.pp_l1 = a.pp_l1; P.pp_first = a.pp_first;

@@ -138,6 +138,7 @@ struct FlatLds {
     int *slen;      // true length of the segment (its flat extent is padded to a multiple of the samples per lane)
     int *live;      // backward: live sample count of the ray
     float *gmax;    // backward: per wave, the largest |grad_out| among the brick's candidate pixels
+    float *mm;      // forward: per wave, smallest / largest staged voxel and a NaN flag (brick_empty_test)
 };
 // LDS layout: everything of compile-time size first (so every address below is an immediate), then the two
 // tables whose size depends on the run-time TF resolution R.
@@ -150,6 +151,7 @@ __host__ __device__ constexpr size_t flat_fixed_bytes(bool want_vol, bool alpha 
     s += (size_t)EC * 4 + (((size_t)EC + 8) * 4 + 15) / 16 * 16 + (size_t)EC * 4 + (size_t)EC * 4;  // s_rel, offs, valid, slen
     s += (size_t)EC * 4;  // segi
     if (BWD) s += (size_t)EC * 4 + 64;  // live; gmax, gmin per wave
+    else s += 48;                       // mm: min, max, NaN flag per wave (brick_empty_test)
     return s;
 }
 template <bool BWD>
@@ -172,7 +174,9 @@ __device__ __forceinline__ FlatLds flat_carve(unsigned char *smem, int R) {
     L.valid = reinterpret_cast<int *>(smem + o); o += (size_t)EC * 4;
     L.gmax = nullptr;
     L.slen = reinterpret_cast<int *>(smem + o); o += (size_t)EC * 4;
+    L.mm = nullptr;
     if (BWD) { L.live = reinterpret_cast<int *>(smem + o); o += (size_t)EC * 4; L.gmax = reinterpret_cast<float *>(smem + o); o += 64; }
+    else { L.mm = reinterpret_cast<float *>(smem + o); o += 48; }
     L.tf = reinterpret_cast<float4 *>(smem + o); o += (size_t)R * 16;
     if (BWD && WANT_TF) L.dtf = reinterpret_cast<unsigned long long *>(smem + o);
     return L;
@@ -258,6 +262,65 @@ __device__ __forceinline__ void box_commit(const BrickParams<VT> &P, const VolVi
     }
     if (P.R <= FNT) { if ((int)threadIdx.x < P.R) L.tf[threadIdx.x] = st.tfv; }
     else { for (int k = threadIdx.x; k < P.R; k += FNT) L.tf[k] = tfg[k]; }
+}
+
+// ---- Empty bricks (round 5; see brick_probe_empty in dr_brick_common.h) -------------------------------------------------------
+// Part 1, with the staged values still in registers: every wave leaves the smallest and the largest voxel it staged (padding
+// outside the volume is staged as 0 and counts: conservative) and whether it saw a NaN. Before the workgroup's barrier.
+template <int FNT>
+__device__ __forceinline__ void brick_empty_publish(const BoxStage<FNT> &st, FlatLds &L) {
+    using S = BoxStage<FNT>;
+    const int a = threadIdx.x & 15, row = threadIdx.x >> 4;
+    float mn = 3.0e38f, mx = -3.0e38f;
+    bool nanv = false;
+    if (a < BOX) {
+#pragma unroll
+        for (int k = 0; k < S::NPASS; ++k) {
+            if (row + k * S::RP < BOX * BOX) { const float v = st.bv[k]; mn = fminf(mn, v); mx = fmaxf(mx, v); nanv = nanv || (v != v); }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
+    const bool wnan = __any(nanv);
+    if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; L.mm[w] = mn; L.mm[4 + w] = mx; L.mm[8 + w] = wnan ? 1.0f : 0.0f; }
+}
+// Part 2, after the barrier (box and TF are in LDS): every intensity a sample of this brick can take lies between the smallest and
+// the largest staged voxel (trilinear taps are convex combinations; a few ulps of rounding are absorbed by the texel of slack on
+// either side), so it indexes TF texels [lo, hi]; if none of those composites, no sample of the brick does. One more barrier
+// (only for bricks whose nine probes said "maybe"). Workgroup-uniform result.
+template <typename VT, int FNT>
+__device__ __forceinline__ bool brick_empty_decide(const BrickParams<VT> &P, const FlatLds &L) {
+    static_assert(FNT / 64 <= 4, "mm holds four waves");
+    float mn = 3.0e38f, mx = -3.0e38f, nn = 0.0f;
+#pragma unroll
+    for (int w = 0; w < FNT / 64; ++w) { mn = fminf(mn, L.mm[w]); mx = fmaxf(mx, L.mm[4 + w]); nn += L.mm[8 + w]; }
+    const int lo = max((int)(fmaxf(mn, 0.0f) * P.tf_len) - 1, 0);                                  // (a negative intensity indexes texel 0)
+    const int hi = min((int)fminf(fmaxf(mx, 0.0f) * P.tf_len, (float)P.R) + 2, P.R - 1);
+    bool bad = nn != 0.0f;   // a NaN voxel: leave the brick to the ordinary path
+    for (int k = lo + (int)threadIdx.x; k <= hi; k += FNT) bad = bad || texel_composites(L.tf[k].w, P.nondiff);
+    return !__syncthreads_or(bad);
+}
+// Part 3: the brick is empty -- the wave's segments need their exact in-brick sample counts and nothing else. One lane per
+// segment: the in-brick samples of a ray are one run (every coordinate is monotone along a line) inside the listed conservative
+// range [s0, s1), so the run's ends are found by testing a few samples at either end of the range with the sample loop's own
+// position and cell arithmetic. A lane that does not find both ends within four probes reports failure, and its wave marches
+// the round the ordinary way (the box is staged). Returns the count (0: no sample of the ray in this brick).
+template <typename VT>
+__device__ __forceinline__ bool empty_segment_count(const VolView<VT> &vol, const BrickCtx &c, f3 cam, float4 r0, float4 r1, int s0, int s1, int &count) {
+    auto inside = [&](int s) {
+        float px, py, pz, fr;
+        int x0, y0, z0;
+        sample_pos_rcp(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, cam.x, cam.y, cam.z, s, px, py, pz);
+        axis_coord(px, vol.scx, x0, fr); axis_coord(py, vol.scy, y0, fr); axis_coord(pz, vol.scz, z0, fr);
+        return (unsigned)(x0 - c.ox - 1) < (unsigned)BRK && (unsigned)(y0 - c.oy - 1) < (unsigned)BRK && (unsigned)(z0 - c.oz - 1) < (unsigned)BRK;
+    };
+    int first = -1, last = -1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int s = s0 + k; if (first < 0 && s < s1 && inside(s)) first = s; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int s = s1 - 1 - k; if (last < 0 && s >= s0 && inside(s)) last = s; }
+    count = 0;
+    if (first >= 0 && last >= first) { count = last - first + 1; return true; }
+    return first < 0 && last < 0 && s1 - s0 <= 4;   // every listed sample was tested: none is in the brick
 }
 
 // What a thread reads from global memory for its candidate pixel of a round -- issued as ONE batch of loads (the
@@ -729,7 +792,7 @@ __device__ __forceinline__ float wave_min_f(float v) {
 // bricks next to the camera would each be one workgroup's job: 61 ms instead of 6 for a 512^2 view from inside a 512^3 volume.
 template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, bool ALPHA, int KF, bool HEAVY, bool NARROW>
 __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsigned char *smem, const int slot, const int view,
-                                                const int c_lo, const int c_hi, bool &box_valid) {
+                                                const int c_lo, const int c_hi, int &box_valid) {   // box_valid: 0 no box staged, 1 staged, 2 staged and EMPTY
     if (ALPHA && P.vflags[view] == 0u) return;  // uniform: no ray of this view can terminate early
     using Cfg = FlatCfg<BWD, WANT_VOL, ALPHA>;
     constexpr int EC = Cfg::EC;
@@ -810,7 +873,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
 #endif
     // A work item that follows another item of the same brick in its workgroup finds the voxel box (and the TF) in LDS already.
     // (Forward and pre-pass only: the backward's gradient box is flushed per item.)
-    const bool reuse_box = HEAVY && !BWD && box_valid;  // uniform
+    const bool reuse_box = HEAVY && !BWD && box_valid != 0;  // uniform
     CandData cd;
     cand_load<VT, MODE, BWD, ALPHA, WANT_VOL>(P, c, view, r_lo, r_hi, hits, c_lo, ncand_all, cd);  // ray buffers of the first round's candidates
     BoxStage<FNT> stage;
@@ -842,7 +905,9 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
     const long long tq2 = clock64();   // candidates loaded and listed
 #endif
     if (!reuse_box) box_commit<VT, FNT>(P, vol, c, P.tf + view * P.tf_vs, stage, L);
-    box_valid = true;
+    const bool test_empty = !BWD && !reuse_box && c.maybe_empty != 0;  // uniform
+    if constexpr (!BWD) { if (test_empty) brick_empty_publish<FNT>(stage, L); }
+    if (!reuse_box) box_valid = 1;
 #if DR_PHASE_TIMING == 3
     const long long tq3 = clock64();   // box arrived and stored
 #endif
@@ -856,6 +921,11 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
         atomicAdd(tt + 3, (unsigned long long)(clock64() - tq3));
     }
 #endif
+    bool brick_empty = false;  // uniform: no sample of this brick composites anything (forward passes only)
+    if constexpr (!BWD) {
+        if (test_empty) { if (brick_empty_decide<VT, FNT>(P, L)) box_valid = 2; }
+        brick_empty = box_valid == 2;
+    }
     bool acc64 = false;  // brick-uniform: d_volume accumulates in double
     if (BWD && WANT_VOL) {
         // this brick's fixed-point scale, or doubles if its candidates' |grad_out| span more than 2^DR_MIXED_BITS
@@ -886,8 +956,38 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
         any = any || nE > 0;
         // this wave's own segment table: entries [ea, eb), flat samples [0, M); offsets live at index entry + wave
         const int ea = wave * (EC / FNW), eb = ea + nE;
-        const int fa = 0, fb = M;
         const int *offs = L.offs + wave;
+        bool skip_loop = false;  // wave-uniform
+        if constexpr (!BWD) {
+            if (brick_empty) {  // uniform: counts and all-zero partials, no sample is evaluated (empty_segment_count)
+                const int e = ea + lane;
+                int count = 0;
+                bool resolved = true;
+                float4 r1e = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < eb) {
+                    const float4 r0e = L.ray0[e];
+                    r1e = L.ray1[e];
+                    const int s0e = L.s_rel[e] + offs[e];
+                    resolved = empty_segment_count(vol, c, cam, r0e, r1e, s0e, s0e + L.slen[e], count);
+                }
+                if (!__any(!resolved)) {
+                    skip_loop = true;
+                    if (e < eb && count > 0) {
+                        const int sgi = L.segi[e];
+                        L.valid[e] = count;   // (written to seg_cnt with the other counts below)
+                        P.seg_rgba[seg_view + sgi] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if constexpr (ALPHA && MODE == DR_MODE_NONDIFF) {
+                            if (P.lm_words > 0) {   // tell the colour march that this segment is done (see flat_build_entries)
+                                const int plq = __float_as_int(r1e.w);
+                                const int lay = (int)((float)(sgi - plq) * __builtin_amdgcn_rcpf((float)NP) + 0.5f);
+                                atomicOr(P.unlit + ((size_t)view * P.lm_words + (lay >> 6)) * NP + plq, 1ull << (lay & 63));
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        const int fa = 0, fb = skip_loop ? 0 : M;
 #if DR_PHASE_TIMING
         if (cbase == 0) tk2 = clock64();
 #endif
@@ -1463,10 +1563,10 @@ __global__ __launch_bounds__((FlatCfg<BWD, WANT_VOL, ALPHA>::FNT), (FlatCfg<BWD,
     // (tried: consecutive workgroups = the same brick of consecutive views, so that the box comes from L2 after its first
     // read -- 2 % slower with 8 views, 13 % on the demo loop)
     const int nv = P.n_views;
-    bool bv = false;
+    int bv = 0;
     brick_flat_body<VT, MODE, BWD, WANT_VOL, WANT_TF, ALPHA, KF, false, NARROW>(P, smem, blockIdx.x / nv, blockIdx.x % nv, 0, MAIN_CAND, bv);
 #else
-    bool bv = false;
+    int bv = 0;
     brick_flat_body<VT, MODE, BWD, WANT_VOL, WANT_TF, ALPHA, KF, false, NARROW>(P, smem, blockIdx.x, blockIdx.y,
                                                                                0, MAIN_CAND, bv);
 #endif
@@ -1482,7 +1582,7 @@ __global__ __launch_bounds__((FlatCfg<false, false>::FNT), (FlatCfg<false, false
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int s_next;
     for (int slot = blockIdx.x; slot < total;) {  // uniform
-        bool bv = false;
+        int bv = 0;
         brick_flat_body<VT, MODE, false, false, false, false, KF, false, NARROW>(P, smem, slot % nbricks, slot / nbricks, 0, MAIN_CAND, bv);
         __syncthreads();
         if (threadIdx.x == 0) s_next = (int)gridDim.x + (int)atomicAdd(&P.stats[ST_TICKET_MAIN], 1u);
@@ -1512,11 +1612,11 @@ __global__ __launch_bounds__((FlatCfg<BWD, WANT_VOL, ALPHA>::FNT), (FlatCfg<BWD,
             __syncthreads();
         }
         if (first >= n_items) break;
-        bool box_valid = false;
+        int box_valid = 0;
         int pv = -1, ps = -1;
         for (int it = first; it < min(first + ITEM_RUN, n_items); ++it) {
             const BrickItem item = P.items[it];
-            if (item.view != pv || item.brick != ps) { box_valid = false; pv = item.view; ps = item.brick; }
+            if (item.view != pv || item.brick != ps) { box_valid = 0; pv = item.view; ps = item.brick; }
             brick_flat_body<VT, MODE, BWD, WANT_VOL, WANT_TF, ALPHA, KF, true, NARROW>(P, smem, item.brick, item.view, item.c0, item.c1, box_valid);
             __syncthreads();  // the next item reuses the LDS
         }

@@ -1106,3 +1106,79 @@ def test_long_volume_both_normal_taps_leave_the_cell(oracle, hiplib, vshape, cam
     ok, err = grad_close(dt.cpu().numpy(), dt0); assert ok, f"d_tf rel err {err}"
     _, dt_only = Fn.march_bwd(vt, tt, ct, e, x, r, n, 1 << 20, 1.0, T(g[None]), out, want_vol=False, workspace=ws)
     ok, err = grad_close(dt_only.cpu().numpy(), dt0); assert ok, f"d_tf (TF-only backward) rel err {err}"
+
+
+def _ct_like(O, N):
+    """The field inside a ball of radius 0.6, air (exactly 0) outside it -- most bricks hold nothing but transparent samples."""
+    vol = O.synth_volume(N)
+    ax = np.linspace(-1.0, 1.0, N, dtype=np.float32)
+    r2 = ax[:, None, None] ** 2 + ax[None, :, None] ** 2 + ax[None, None, :] ** 2
+    return np.where(r2 < 0.36, vol, np.float32(0.0)).astype(np.float32)
+
+
+@pytest.mark.parametrize("mode,sr", [(1, 1.0), (1, 4.0), (1, 8.0), (0, 1.0), (0, 2.0)])
+def test_empty_bricks_and_unlit_segments(oracle, hiplib, mode, sr):
+    """Round 5: bricks in which no sample composites anything (air under the reference's tf1 preset) deliver their rays' sample
+    counts from the ends of each segment and evaluate nothing (march_flat.hip: brick_empty_*), and in non-differentiable renders
+    the alpha pre-pass tells the colour march which (ray, layer) segments hold no sample with alpha > 1e-3. Both are ways of
+    NOT computing zeros: images, sample counts and -- through the untouched backward -- gradients stay the oracle's."""
+    from differender_amd import functional as Fn
+    from differender_amd.utils import get_tf
+    N, WH, R = 96, (72, 64), 64
+    vol = _ct_like(oracle, N)
+    tf = get_tf("tf1", R).t().contiguous().numpy()
+    cam = oracle.in_circles(0.8)
+    e0, x0, r0, n0 = oracle.ray_setup(cam, *WH, vol.shape, sr=sr)
+    ref, sref = oracle.march_fwd(vol, tf, cam, e0, x0, r0, n0, 1 << 20, sr, mode)
+    assert (sref < n0)[n0 > 10].mean() > 0.2 and (sref == n0)[n0 > 10].mean() > 0.05   # terminating rays and rays through air only
+    e, x, r, n = Fn.ray_setup(T(cam[None]), WH, vol.shape, sr)
+    for hint in (0, Fn.N.DR_HINT_EARLY_TERMINATION):
+        ws = Fn.alloc_workspace(1, WH, vol.shape, R, dev())
+        out, steps = Fn.march_fwd(T(vol), T(tf), T(cam[None]), e, x, r, n, 1 << 20, sr, mode, workspace=ws, hints=hint)
+        assert int(Fn.workspace_stats(ws)[0]) == 0, "rays failed their sample count and were marched one by one"
+        assert np.array_equal(steps[0].cpu().numpy(), sref)
+        assert np.abs(out[0].cpu().numpy() - ref).max() <= FWD_TOL
+    if mode == 0:   # the backward re-marches every live sample itself (alpha = 0 has a slope): d_tf of the air's texels included
+        g = np.random.RandomState(9).randn(*WH, 4).astype(np.float32)
+        dv0, dt0 = oracle.march_bwd(vol, tf, cam, e0, x0, r0, n0, 1 << 20, sr, g)
+        dv, dt = Fn.march_bwd(T(vol), T(tf), T(cam[None]), e, x, r, n, 1 << 20, sr, T(g[None]), out, workspace=ws)
+        assert grad_close(dv.cpu().numpy(), dv0)[0] and grad_close(dt.cpu().numpy(), dt0)[0]
+        assert np.abs(dt0[0]).max() > 0   # texel 0 (air) does receive a gradient
+
+
+def test_empty_brick_test_is_exact_at_its_edges(oracle, hiplib):
+    """The empty-brick decision rests on the staged voxel range and a texel of slack: a brick that is air except for ONE voxel
+    (an interior one, an apron one, a NaN) must not be taken for empty, and a TF whose first lit texel sits right above the air's
+    must be honoured. Fast path against the sequential kernels (the oracle's twin), image and counts."""
+    from differender_amd import functional as Fn
+    N, WH, R = 48, (48, 48), 32
+    cam = oracle.in_circles(0.5)
+    tf = np.zeros((R, 4), np.float32)
+    tf[:, :3] = 0.7
+    tf[2:, 3] = 0.2          # texels 0 and 1 composite nothing, texel 2 and up do
+    e, x, r, n = Fn.ray_setup(T(cam[None]), WH, (N, N, N), 2.0)
+    for kind in ("interior", "apron", "nan", "just_lit", "just_unlit"):
+        vol = np.zeros((N, N, N), np.float32)
+        if kind == "interior":
+            vol[18, 19, 20] = 0.9
+        elif kind == "apron":
+            vol[24, 24, 12] = 0.9          # on the plane shared by two bricks (cells 12.. belong to the next brick)
+        elif kind == "nan":
+            vol[30, 17, 22] = np.nan
+        elif kind == "just_lit":
+            vol[:] = np.float32(1.02 / (R - 1))  # index 1.02: lerps texel 1 (0) with texel 2 (0.2): alpha 0.004, lit in both modes
+        else:
+            vol[:] = np.float32(0.98 / (R - 1))  # index 0.98: texels 0 and 1 only: nothing composites
+        for mode in (0, 1):
+            ws = Fn.alloc_workspace(1, WH, vol.shape, R, dev())
+            out, steps = Fn.march_fwd(T(vol), T(tf), T(cam[None]), e, x, r, n, 1 << 20, 2.0, mode, workspace=ws)
+            assert int(Fn.workspace_stats(ws)[0]) == 0
+            outb, stepsb = Fn.march_fwd(T(vol), T(tf), T(cam[None]), e, x, r, n, 1 << 20, 2.0, mode, variant=1)
+            assert torch.equal(steps, stepsb), (kind, mode)
+            a, b = out.cpu().numpy(), outb.cpu().numpy()
+            assert np.array_equal(np.isnan(a), np.isnan(b)), (kind, mode)
+            assert np.nanmax(np.abs(a - b), initial=0.0) <= FWD_TOL, (kind, mode)
+            if kind in ("interior", "apron", "just_lit"):
+                assert float(np.nanmax(b)) > 0.0   # the lit voxel is seen
+            if kind == "just_unlit":
+                assert float(np.abs(b).max()) == 0.0
