@@ -265,8 +265,8 @@ def _dominant_kernel(pm, want_bwd_kernel):
         if "brick_flat_kernel<" not in k:
             continue
         targs = [t.strip(" >") for t in k.split("<")[1].split(",")]  # <VT, MODE, BWD, VOL, TF, ALPHA, K>
-        if len(targs) >= 6 and targs[5] == "true":
-            continue  # the (gated) alpha pre-pass
+        if len(targs) >= 6 and targs[5] not in ("false", "0"):
+            continue  # the (gated) alpha pre-pass (a bool until round 4, the pre-pass's configuration 1 / 2 since)
         if (targs[2] == "true") == want_bwd_kernel:
             return k, v
     return None, None

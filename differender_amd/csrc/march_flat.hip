@@ -109,18 +109,22 @@ namespace dr {
 #ifndef DR_BWDTF_WAVES
 #define DR_BWDTF_WAVES 4
 #endif
-// Workgroup configuration of a brick kernel: forward / alpha pre-pass / backward with a gradient box / backward w.r.t. the TF only
-#ifndef DR_FEC_ALPHA
-#define DR_FEC_ALPHA DR_FEC_FWD       // alpha pre-pass: segment-table entries (160 + DR_ALPHA_WAVES 6: six workgroups per CU -- measured, round 5)
+// Workgroup configuration of a brick kernel: forward / alpha pre-pass / backward with a gradient box / backward w.r.t. the TF only.
+// ALPHA: 0 = not the pre-pass; 1 = the pre-pass in the forward's shape (256-entry tables, five workgroups per CU); 2 = the pre-pass
+// of HIGH sampling rates (>= 3): 160-entry tables and 80 VGPRs put SIX workgroups on a CU -- at rate 8 a segment holds ~400
+// samples and occupancy is what the short, latency-bound workgroups lack (demo loop 10.35 -> 10.14 ms); at rate 1 a brick's ~196
+// candidates would take two listing rounds (512^3 tf1 forward +2.5 %): same-device rows in profiles/r05_ab_experiments.txt.
+#ifndef DR_FEC_ALPHA_HI
+#define DR_FEC_ALPHA_HI 160
 #endif
-#ifndef DR_ALPHA_WAVES
-#define DR_ALPHA_WAVES DR_FWD_WAVES
+#ifndef DR_ALPHA_WAVES_HI
+#define DR_ALPHA_WAVES_HI 6
 #endif
-template <bool BWD, bool WANT_VOL, bool ALPHA = false>
+template <bool BWD, bool WANT_VOL, int ALPHA = 0>
 struct FlatCfg {
     static constexpr int FNT = BWD ? (WANT_VOL ? DR_FNT_BWD : DR_FNT_BWDTF) : DR_FNT_FWD;      // threads per workgroup
-    static constexpr int EC = BWD ? (WANT_VOL ? DR_FEC_BWD : DR_FEC_BWDTF) : (ALPHA ? DR_FEC_ALPHA : DR_FEC_FWD);   // segment-table entries (= candidates per round)
-    static constexpr int WAVES = BWD ? (WANT_VOL ? DR_BWD_WAVES : DR_BWDTF_WAVES) : (ALPHA ? DR_ALPHA_WAVES : DR_FWD_WAVES);  // waves per SIMD the registers must allow
+    static constexpr int EC = BWD ? (WANT_VOL ? DR_FEC_BWD : DR_FEC_BWDTF) : (ALPHA == 2 ? DR_FEC_ALPHA_HI : DR_FEC_FWD);   // segment-table entries (= candidates per round)
+    static constexpr int WAVES = BWD ? (WANT_VOL ? DR_BWD_WAVES : DR_BWDTF_WAVES) : (ALPHA == 2 ? DR_ALPHA_WAVES_HI : DR_FWD_WAVES);  // waves per SIMD the registers must allow
     static constexpr int UNEVEN = (BWD && WANT_VOL) ? DR_BWD_UNEVEN : 0;                      // uneven dealing (cand_load)
     static constexpr int FNW = FNT / 64, CW = EC / FNW;                                       // waves; candidates per wave and round
     static_assert(CW <= 64 && CW * FNW == EC, "one candidate per lane and round");
@@ -143,8 +147,8 @@ struct FlatLds {
 // LDS layout: everything of compile-time size first (so every address below is an immediate), then the two
 // tables whose size depends on the run-time TF resolution R.
 template <bool BWD>
-__host__ __device__ constexpr size_t flat_fixed_bytes(bool want_vol, bool alpha = false) {
-    const int EC = want_vol ? FlatCfg<BWD, true>::EC : (alpha ? FlatCfg<BWD, false, true>::EC : FlatCfg<BWD, false>::EC);
+__host__ __device__ constexpr size_t flat_fixed_bytes(bool want_vol, int alpha = 0) {
+    const int EC = want_vol ? FlatCfg<BWD, true>::EC : (alpha == 2 ? FlatCfg<BWD, false, 2>::EC : FlatCfg<BWD, false>::EC);
     size_t s = ((size_t)BOX_LDS * 4 + 15) / 16 * 16;
     if (BWD && want_vol) s += ((size_t)DR_DBOX_WORDS * 8 + 15) / 16 * 16;
     s += (size_t)EC * 32;
@@ -155,10 +159,10 @@ __host__ __device__ constexpr size_t flat_fixed_bytes(bool want_vol, bool alpha 
     return s;
 }
 template <bool BWD>
-__host__ __device__ inline size_t flat_lds_bytes(int R, bool want_vol, bool want_tf, bool alpha = false) {
+__host__ __device__ inline size_t flat_lds_bytes(int R, bool want_vol, bool want_tf, int alpha = 0) {
     return flat_fixed_bytes<BWD>(want_vol, alpha) + (size_t)R * 16 + ((BWD && want_tf) ? (want_vol ? DR_DTF_BYTES(R) : (size_t)R * 32) : 0);
 }
-template <bool BWD, bool WANT_VOL, bool WANT_TF, bool ALPHA = false>
+template <bool BWD, bool WANT_VOL, bool WANT_TF, int ALPHA = 0>
 __device__ __forceinline__ FlatLds flat_carve(unsigned char *smem, int R) {
     constexpr int EC = FlatCfg<BWD, WANT_VOL, ALPHA>::EC;
     FlatLds L;
@@ -370,7 +374,7 @@ __device__ __forceinline__ bool line_meets_brick(const BrickCtx &c, f3 cam, f3 d
 }
 // `hits` (overflow items of heavy bricks): the item's candidates that passed the geometric pre-test, as offsets from c_lo;
 // the rounds then run over [0, number of hits) instead of over the raw candidate range.
-template <typename VT, int MODE, bool BWD, bool ALPHA, bool WANT_VOL>
+template <typename VT, int MODE, bool BWD, int ALPHA, bool WANT_VOL>
 __device__ __forceinline__ void cand_load(const BrickParams<VT> &P, const BrickCtx &c, int view, int cbase, int ncand,
                                           const unsigned short *hits, int c_lo, int ncand_all, CandData &d) {
     using Cfg = FlatCfg<BWD, WANT_VOL, ALPHA>;
@@ -440,7 +444,7 @@ __device__ __forceinline__ int wave_incl_sum(int v) {
 // marker) and its own flat sample space [0, M). No workgroup barrier, no serial phase: the compaction is a ballot,
 // the offsets a DPP scan. Slots follow the candidate order, so the flat sample order -- and with it every
 // rounding -- is reproducible.
-template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool ALPHA = false, int KS = 1>
+template <typename VT, int MODE, bool BWD, bool WANT_VOL, int ALPHA = 0, int KS = 1>
 __device__ __forceinline__ void flat_build_entries(const BrickParams<VT> &P, const BrickCtx &c, f3 cam, int view,
                                                    const CandData &d, FlatLds &L, int &nE, int &M) {
     constexpr int CW = FlatCfg<BWD, WANT_VOL, ALPHA>::CW;
@@ -790,7 +794,7 @@ __device__ __forceinline__ float wave_min_f(float v) {
 // inside the volume: the brick around the eye is a candidate of every pixel -- had the rest cut into items of ITEM_CAND
 // candidates by brick_ctx_kernel, which a second, small launch works off (brick_flat_items_kernel). Without that, the few
 // bricks next to the camera would each be one workgroup's job: 61 ms instead of 6 for a 512^2 view from inside a 512^3 volume.
-template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, bool ALPHA, int KF, bool HEAVY, bool NARROW>
+template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, int ALPHA, int KF, bool HEAVY, bool NARROW>
 __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsigned char *smem, const int slot, const int view,
                                                 const int c_lo, const int c_hi, int &box_valid) {   // box_valid: 0 no box staged, 1 staged, 2 staged and EMPTY
     if (ALPHA && P.vflags[view] == 0u) return;  // uniform: no ray of this view can terminate early
@@ -1556,7 +1560,7 @@ constexpr int ITEM_GRID_FWD = DR_ITEM_GRID_FWD, ITEM_GRID_BWD = DR_ITEM_GRID_BWD
 #endif
 constexpr int ITEM_RUN = DR_ITEM_RUN;   // consecutive items a workgroup takes at a time
 
-template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, bool ALPHA = false, int KF = 1, bool NARROW = true>
+template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, int ALPHA = 0, int KF = 1, bool NARROW = true>
 __global__ __launch_bounds__((FlatCfg<BWD, WANT_VOL, ALPHA>::FNT), (FlatCfg<BWD, WANT_VOL, ALPHA>::WAVES)) void brick_flat_kernel(BrickParams<VT> P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef DR_VIEW_FASTEST
@@ -1592,7 +1596,7 @@ __global__ __launch_bounds__((FlatCfg<false, false>::FNT), (FlatCfg<false, false
     if (threadIdx.x == 0 && atomicAdd(&P.stats[ST_DONE_MAIN], 1u) == gridDim.x - 1) { P.stats[ST_TICKET_MAIN] = 0u; P.stats[ST_DONE_MAIN] = 0u; }
 }
 // the overflow items of heavy bricks (all views), worked off by a fixed, small grid
-template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, bool ALPHA = false, int KF = 1, bool NARROW = true>
+template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, int ALPHA = 0, int KF = 1, bool NARROW = true>
 __global__ __launch_bounds__((FlatCfg<BWD, WANT_VOL, ALPHA>::FNT), (FlatCfg<BWD, WANT_VOL, ALPHA>::WAVES)) void brick_flat_items_kernel(BrickParams<VT> P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (BWD && P.stats[ST_MARK] != P.mark) return;  // uniform over the grid: not this call's workspace, the item list is garbage
@@ -1770,16 +1774,19 @@ static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
         MarchArgs pa = a;
         const size_t lds_f1 = lds;
         (void)lds_f1;
-        const size_t lds = flat_lds_bytes<false>(a.R, false, false, true);   // the pre-pass's own table size (FlatCfg<.., ALPHA>)
+        const bool alpha_hi = a.sr >= 3.0f;   // six workgroups per CU (FlatCfg<.., 2>)
+        const size_t lds = flat_lds_bytes<false>(a.R, false, false, alpha_hi ? 2 : 1);   // the pre-pass's own table size
         for (int gi = 0; gi < G; ++gi) {
             pa.pp_l0 = g.NL * gi / G; pa.pp_l1 = g.NL * (gi + 1) / G; pa.pp_first = gi == 0;
             P.pp_l0 = pa.pp_l0; P.pp_l1 = pa.pp_l1; P.pp_first = pa.pp_first;
             // (several bricks per workgroup would quarter the cost of this launch when it is gated off -- 27 us of workgroup
             // exits at 512^3 -- but the looped kernel needs 96 VGPRs instead of 66 and is 3-5 % slower when it runs)
             if (a.mode == DR_MODE_DIFF) {
-                DR_LAUNCH_BOTH(DR_MODE_DIFF, false, false, false, true, DR_ALPHA_K, (FlatCfg<false, false, true>::FNT))
+                if (alpha_hi) DR_LAUNCH_BOTH(DR_MODE_DIFF, false, false, false, 2, DR_ALPHA_K, (FlatCfg<false, false, 2>::FNT))
+                else DR_LAUNCH_BOTH(DR_MODE_DIFF, false, false, false, 1, DR_ALPHA_K, (FlatCfg<false, false, 1>::FNT))
             } else {
-                DR_LAUNCH_BOTH(DR_MODE_NONDIFF, false, false, false, true, DR_ALPHA_K, (FlatCfg<false, false, true>::FNT))
+                if (alpha_hi) DR_LAUNCH_BOTH(DR_MODE_NONDIFF, false, false, false, 2, DR_ALPHA_K, (FlatCfg<false, false, 2>::FNT))
+                else DR_LAUNCH_BOTH(DR_MODE_NONDIFF, false, false, false, 1, DR_ALPHA_K, (FlatCfg<false, false, 1>::FNT))
             }
             if ((e = hipGetLastError()) != hipSuccess) return (int)e;
             const int rc = launch_ray_alpha(pa, stream);

@@ -1130,7 +1130,7 @@ def test_empty_bricks_and_unlit_segments(oracle, hiplib, mode, sr):
     cam = oracle.in_circles(0.8)
     e0, x0, r0, n0 = oracle.ray_setup(cam, *WH, vol.shape, sr=sr)
     ref, sref = oracle.march_fwd(vol, tf, cam, e0, x0, r0, n0, 1 << 20, sr, mode)
-    assert (sref < n0)[n0 > 10].mean() > 0.2 and (sref == n0)[n0 > 10].mean() > 0.05   # terminating rays and rays through air only
+    assert (sref < n0)[n0 > 10].mean() > 0.05 and (sref == n0)[n0 > 10].mean() > 0.05   # terminating rays and rays through air only
     e, x, r, n = Fn.ray_setup(T(cam[None]), WH, vol.shape, sr)
     for hint in (0, Fn.N.DR_HINT_EARLY_TERMINATION):
         ws = Fn.alloc_workspace(1, WH, vol.shape, R, dev())
