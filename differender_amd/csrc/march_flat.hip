@@ -48,7 +48,7 @@ namespace dr {
 #define DR_FNT_BWD 512
 #endif
 #ifndef DR_UNLIT_SKIP
-#define DR_UNLIT_SKIP 1   // nondiff renders: the colour march skips the segments the alpha pre-pass found unlit (round 5)
+#define DR_UNLIT_SKIP 2   // the colour march skips the segments the alpha pre-pass found unlit: 1 = non-differentiable renders, 2 = all (round 5)
 #endif
 #ifndef DR_ABL_EXTRA_LDS_BWD
 #define DR_ABL_EXTRA_LDS_BWD 0   // what-if: bytes of unused LDS per backward workgroup (fewer workgroups per CU)
@@ -417,7 +417,7 @@ __device__ __forceinline__ void cand_load(const BrickParams<VT> &P, const BrickC
     d.exit_ = P.exit_[d.p];
     d.vx = P.rays[3 * d.p]; d.vy = P.rays[3 * d.p + 1]; d.vz = P.rays[3 * d.p + 2];
     if (BWD || (!ALPHA && P.use_live) || (ALPHA && !P.pp_first)) d.live = P.ws_steps[d.p];
-    if constexpr (MODE == DR_MODE_NONDIFF && !BWD && !ALPHA) {
+    if constexpr (!BWD && !ALPHA) {
         if (P.lm_words > 0) {   // uniform; same batch of loads as the ray buffers
             const unsigned long long *um = P.unlit + ((size_t)view * P.lm_words * NP + d.pl);
             d.um0 = um[0];
@@ -446,7 +446,7 @@ __device__ __forceinline__ int wave_incl_sum(int v) {
 // rounding -- is reproducible.
 template <typename VT, int MODE, bool BWD, bool WANT_VOL, int ALPHA = 0, int KS = 1>
 __device__ __forceinline__ void flat_build_entries(const BrickParams<VT> &P, const BrickCtx &c, f3 cam, int view,
-                                                   const CandData &d, FlatLds &L, int &nE, int &M) {
+                                                   const CandData &d, FlatLds &L, int &nE, int &M, int *live_flag) {
     constexpr int CW = FlatCfg<BWD, WANT_VOL, ALPHA>::CW;
     bool has = false;
     int s0 = 0, s1 = 0;
@@ -478,11 +478,14 @@ __device__ __forceinline__ void flat_build_entries(const BrickParams<VT> &P, con
         entry_brick(P.vol.scx, P.vol.scy, P.vol.scz, cam, vd, t0, ebx, eby, ebz);
         lay = ray_layer(c.bx, c.by, c.bz, ebx, eby, ebz);
     }
-    if constexpr (MODE == DR_MODE_NONDIFF && !BWD && !ALPHA) {
-        // Colour march of a non-differentiable render after an alpha pre-pass (round 5): the pre-pass has marched this very
-        // segment, counted its samples and found none with alpha > 1e-3 (VR.py:334 skips such samples: they composite nothing).
-        // Its count and its all-zero partial are in the workspace already -- nothing to march, nothing to write.
-        if (has && P.lm_words > 0 && (((lay < 64 ? d.um0 : d.um1) >> (lay & 63)) & 1ull)) has = false;
+    if constexpr (!BWD && !ALPHA) {
+        // Colour march after an alpha pre-pass (round 5): the pre-pass has marched this very segment, counted its samples and
+        // found none that composites (alpha <= 1e-3 in a non-differentiable render, VR.py:334; opacity exactly 0 in a
+        // differentiable one). Its count and its all-zero partial are in the workspace already -- nothing to march, nothing to
+        // write. The brick still holds live samples of the view: the backward (alpha = 0 has a slope) must not skip it.
+        const bool skip = has && P.lm_words > 0 && (((lay < 64 ? d.um0 : d.um1) >> (lay & 63)) & 1ull);
+        if (skip) has = false;
+        if constexpr (MODE == DR_MODE_DIFF) { if (__any(skip) && (threadIdx.x & 63) == 0) *live_flag = 1; }
     }
     const unsigned long long hm = __ballot(has);
     const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
@@ -806,6 +809,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
     constexpr bool BWD_TF = BWD && !WANT_VOL;             // backward w.r.t. the TF only
     constexpr int KS = BWD ? (BWD_TF ? DR_BWDTF_K : 1) : KF;  // consecutive samples per lane
     const int nbricks = P.g.NBx * P.g.NBy * P.g.NBz;
+    int *live_flag = &const_cast<BrickCtxRec *>(P.ctx)[(size_t)view * nbricks + slot].live;   // "this brick holds live samples of the view"
 #if DR_PHASE_TIMING == 3
     const long long tq0 = clock64();
 #endif
@@ -888,7 +892,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
     // anything when there are none.
     const bool lazy = (!BWD && !ALPHA && P.use_live && P.vflags[view] != 0u) || (ALPHA && !P.pp_first);  // uniform
     if (lazy) {
-        flat_build_entries<VT, MODE, BWD, WANT_VOL, ALPHA, KS>(P, c, cam, view, cd, L, nE0, M0);
+        flat_build_entries<VT, MODE, BWD, WANT_VOL, ALPHA, KS>(P, c, cam, view, cd, L, nE0, M0, live_flag);
         if (!__syncthreads_or(nE0 > 0) && r_hi - r_lo <= ROUND) return;  // uniform: no wave found a segment
         if (!reuse_box) box_issue<VT, FNT>(P, vol, c, P.tf + view * P.tf_vs, stage);
     } else {
@@ -903,7 +907,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                 if ((threadIdx.x & 63) == 0) { L.gmax[threadIdx.x >> 6] = gm; L.gmax[8 + (threadIdx.x >> 6)] = gn; }
             }
         }
-        flat_build_entries<VT, MODE, BWD, WANT_VOL, ALPHA, KS>(P, c, cam, view, cd, L, nE0, M0);  // ... while the segments are listed
+        flat_build_entries<VT, MODE, BWD, WANT_VOL, ALPHA, KS>(P, c, cam, view, cd, L, nE0, M0, live_flag);  // ... while the segments are listed
     }
 #if DR_PHASE_TIMING == 3
     const long long tq2 = clock64();   // candidates loaded and listed
@@ -955,7 +959,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
         int nE = nE0, M = M0;
         if (cbase > r_lo) {
             cand_load<VT, MODE, BWD, ALPHA, WANT_VOL>(P, c, view, cbase, r_hi, hits, c_lo, ncand_all, cd);
-            flat_build_entries<VT, MODE, BWD, WANT_VOL, ALPHA, KS>(P, c, cam, view, cd, L, nE, M);  // syncs inside
+            flat_build_entries<VT, MODE, BWD, WANT_VOL, ALPHA, KS>(P, c, cam, view, cd, L, nE, M, live_flag);  // syncs inside
         }
         any = any || nE > 0;
         // this wave's own segment table: entries [ea, eb), flat samples [0, M); offsets live at index entry + wave
@@ -980,7 +984,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                         const int sgi = L.segi[e];
                         L.valid[e] = count;   // (written to seg_cnt with the other counts below)
                         P.seg_rgba[seg_view + sgi] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if constexpr (ALPHA && MODE == DR_MODE_NONDIFF) {
+                        if constexpr (ALPHA != 0) {
                             if (P.lm_words > 0) {   // tell the colour march that this segment is done (see flat_build_entries)
                                 const int plq = __float_as_int(r1e.w);
                                 const int lay = (int)((float)(sgi - plq) * __builtin_amdgcn_rcpf((float)NP) + 0.5f);
@@ -1029,7 +1033,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                 const int slen = L.slen[e];
                 float Tl = 1.0f;
                 int cnt_lane = 0;  // in-brick samples of this lane
-                bool lit_lane = false;  // nondiff: some sample of this lane has alpha > 1e-3
+                bool lit_lane = false;  // some sample of this lane composites (alpha > 1e-3 / opacity != 0)
 #pragma unroll
                 for (int j = 0; j < KS; ++j) {
                     if (j >= ks) continue;  // uniform
@@ -1046,7 +1050,11 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                     if (va) {
                         sa.I = tri_lds(L.box, (x0 - c.ox) * BOX_SX + (y0 - c.oy) * BOX_SY + (z0 - c.oz), fx, fy, fz);
                         tf_lookup_from_I(L.tf, P.R, P.tf_len, sa);
-                        if constexpr (MODE != DR_MODE_NONDIFF) Tl *= 1.0f - opacity_of_alpha(sa.a, P.inv_sr);
+                        if constexpr (MODE != DR_MODE_NONDIFF) {
+                            const float opj = opacity_of_alpha(sa.a, P.inv_sr);
+                            lit_lane = lit_lane || opj != 0.0f;   // (the colour march's own test: c = L * rgb * op is exactly 0 for op == 0)
+                            Tl *= 1.0f - opj;
+                        }
                         ++cnt_lane;
                     }
                     // the opacity (a power at sampling rates other than 1) only where it counts: the nondiff march skips
@@ -1074,13 +1082,12 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                 seg_scan_sum<1>(cf, lane, sl);
                 const bool piece_end = act && (seg_end || lane == 63 || f + ks >= fb);
                 // nondiff: does the piece [sl, lane] hold a lit sample? (bit VALID_LIT of the segment's counter collects the pieces)
-                unsigned long long litm = 0ull;
-                if constexpr (MODE == DR_MODE_NONDIFF) litm = __ballot(lit_lane);
+                const unsigned long long litm = __ballot(lit_lane);
                 if (piece_end) {
                     const int cntp = (int)cf[0];
                     int before = cntp ? atomicAdd(&L.valid[e], cntp) : L.valid[e];
                     bool seg_lit = true;
-                    if constexpr (MODE == DR_MODE_NONDIFF) {
+                    {
                         const unsigned long long upto = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
                         const bool piece_lit = (litm & upto & ~((1ull << sl) - 1ull)) != 0ull;
                         seg_lit = piece_lit || (before & VALID_LIT);
@@ -1090,7 +1097,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                     if (seg_end && before + cntp > 0) {
                         const int sgi = L.segi[e];
                         P.seg_rgba[seg_view + sgi] = make_float4(0.f, 0.f, 0.f, 1.0f - Tl);
-                        if constexpr (MODE == DR_MODE_NONDIFF) {
+                        {
                             // every sample of the ray in this brick was marched (the pre-pass has no live limit) and none is lit: tell the
                             // colour march (flat_build_entries). Layer = (slot - pixel) / NP through the float reciprocal: exact, the
                             // quotient is an integer below 128 and the error of the product below 1e-4.
@@ -1481,7 +1488,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                 if (v > 0) { P.seg_cnt[seg_view + L.segi[e]] = (uint16_t)min(v, 65535); some = true; }
             }
             if (!ALPHA && __any(some) && lane == 0)  // tell the backward that this brick holds live samples of the view
-                const_cast<BrickCtxRec *>(P.ctx)[(size_t)view * nbricks + slot].live = 1;
+                *live_flag = 1;
         }
     }
 #if DR_PHASE_TIMING == 2
@@ -1735,7 +1742,7 @@ static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     // Non-differentiable render with an alpha pre-pass: the pre-pass tells the colour march which (ray, layer) segments hold no
     // sample with alpha > 1e-3 ("unlit" masks behind seg_cnt, BrickParams::unlit); such segments keep the pre-pass's count and
     // zero partial, so seg_cnt is NOT cleared between the two passes (see below).
-    const bool unlit_masks = a.mode == DR_MODE_NONDIFF && !(a.hints & DR_HINT_NO_EARLY_TERMINATION) && w.lm_words > 0 && DR_UNLIT_SKIP;
+    const bool unlit_masks = (a.mode == DR_MODE_NONDIFF || DR_UNLIT_SKIP > 1) && !(a.hints & DR_HINT_NO_EARLY_TERMINATION) && w.lm_words > 0 && DR_UNLIT_SKIP;
     P.lm_words = unlit_masks ? w.lm_words : 0;
     // the item counter (brick_ctx_kernel appends) and seg_cnt behind it (and the masks behind that)
     e = hipMemsetAsync(w.n_items, 0, 16 + (unlit_masks ? align16(w.cnt_bytes) + w.unlit_bytes : w.cnt_bytes), stream);

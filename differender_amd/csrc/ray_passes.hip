@@ -486,14 +486,22 @@ static int ray_alpha_dispatch(const MarchArgs &a, hipStream_t stream, bool cross
     Workspace w;
     ws_layout(a.workspace, a.n_views, NP, g, &w);
     BrickParams<VT> P = make_brick_params<VT>(a, w);
-    const dim3 grid2((NP + 255) / 256, a.n_views), grid3((NP + 3) / 4 < 16384 ? (NP + 3) / 4 : 16384, a.n_views);
+    // The crossing search runs as ~8 192 workgroups over all views (32 768 waves: four rounds of what the chip holds), each staging
+    // the TF once and striding over the rays -- not one workgroup per four rays: 131 072 of them for the demo's 8 x 256^2 rays,
+    // each paying the TF load and a barrier first (demo loop 10.25 -> 10.20 ms; 2 048 workgroups: +0.1 ms, rays queue up behind
+    // long ones). DR_CROSS_GRID = workgroups over all views.
+#ifndef DR_CROSS_GRID
+#define DR_CROSS_GRID 8192
+#endif
+    const int cross_cap = (DR_CROSS_GRID + a.n_views - 1) / a.n_views < 64 ? 64 : (DR_CROSS_GRID + a.n_views - 1) / a.n_views;
+    const dim3 grid2((NP + 255) / 256, a.n_views), grid3((NP + 3) / 4 < cross_cap ? (NP + 3) / 4 : cross_cap, a.n_views);
     const size_t lds3 = (size_t)a.R * 16;
     // below sampling rate 2 a crossing segment is short: four rays per wave (ray_cross_quad_kernel)
 #ifndef DR_CROSS_QUAD_BELOW
 #define DR_CROSS_QUAD_BELOW 2.0f
 #endif
     const bool quad = a.sr < DR_CROSS_QUAD_BELOW;
-    const dim3 grid3q((NP + 15) / 16 < 16384 ? (NP + 15) / 16 : 16384, a.n_views);
+    const dim3 grid3q((NP + 15) / 16 < cross_cap ? (NP + 15) / 16 : cross_cap, a.n_views);
     if (a.mode == DR_MODE_DIFF) {
         if (!cross) hipLaunchKernelGGL((ray_alpha_kernel<VT, DR_MODE_DIFF>), grid2, dim3(256), 0, stream, P);
         else if (quad) hipLaunchKernelGGL((ray_cross_quad_kernel<VT, DR_MODE_DIFF>), grid3q, dim3(256), lds3, stream, P);
