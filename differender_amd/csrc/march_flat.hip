@@ -297,7 +297,8 @@ __device__ __forceinline__ bool brick_empty_decide(const BrickParams<VT> &P, con
     float mn = 3.0e38f, mx = -3.0e38f, nn = 0.0f;
 #pragma unroll
     for (int w = 0; w < FNT / 64; ++w) { mn = fminf(mn, L.mm[w]); mx = fmaxf(mx, L.mm[4 + w]); nn += L.mm[8 + w]; }
-    const int lo = max((int)(fmaxf(mn, 0.0f) * P.tf_len) - 1, 0);                                  // (a negative intensity indexes texel 0)
+    // (a negative intensity indexes texel 0, an infinite one the last texel -- as low_high_frac and the clamp of tf_lookup_from_I do)
+    const int lo = min(max((int)fminf(fmaxf(mn, 0.0f) * P.tf_len, (float)P.R) - 1, 0), P.R - 1);
     const int hi = min((int)fminf(fmaxf(mx, 0.0f) * P.tf_len, (float)P.R) + 2, P.R - 1);
     bool bad = nn != 0.0f;   // a NaN voxel: leave the brick to the ordinary path
     for (int k = lo + (int)threadIdx.x; k <= hi; k += FNT) bad = bad || texel_composites(L.tf[k].w, P.nondiff);

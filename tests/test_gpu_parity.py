@@ -1157,7 +1157,7 @@ def test_empty_brick_test_is_exact_at_its_edges(oracle, hiplib):
     tf[:, :3] = 0.7
     tf[2:, 3] = 0.2          # texels 0 and 1 composite nothing, texel 2 and up do
     e, x, r, n = Fn.ray_setup(T(cam[None]), WH, (N, N, N), 2.0)
-    for kind in ("interior", "apron", "nan", "just_lit", "just_unlit"):
+    for kind in ("interior", "apron", "nan", "inf", "just_lit", "just_unlit"):
         vol = np.zeros((N, N, N), np.float32)
         if kind == "interior":
             vol[18, 19, 20] = 0.9
@@ -1165,6 +1165,8 @@ def test_empty_brick_test_is_exact_at_its_edges(oracle, hiplib):
             vol[24, 24, 12] = 0.9          # on the plane shared by two bricks (cells 12.. belong to the next brick)
         elif kind == "nan":
             vol[30, 17, 22] = np.nan
+        elif kind == "inf":
+            vol[:] = np.inf                # every intensity indexes the LAST texel (lit), whatever the range arithmetic makes of it
         elif kind == "just_lit":
             vol[:] = np.float32(1.02 / (R - 1))  # index 1.02: lerps texel 1 (0) with texel 2 (0.2): alpha 0.004, lit in both modes
         else:
