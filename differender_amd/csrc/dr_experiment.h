@@ -14,9 +14,9 @@
 #else
 #define DR_EXPERIMENT_WRONG 0
 #endif
-// ---- right results, but not the shipped kernels: LDS ballast, instrumentation ----
+// ---- right results, but not the shipped kernels: LDS ballast, instrumentation, launch shapes measured slower ----
 #if (defined(DR_ABL_EXTRA_LDS_BWD) && DR_ABL_EXTRA_LDS_BWD != 0) || (defined(DR_ABL_EXTRA_LDS_ALPHA) && DR_ABL_EXTRA_LDS_ALPHA != 0) || \
-    (defined(DR_PHASE_TIMING) && DR_PHASE_TIMING != 0) || defined(DR_LANE_STATS) || defined(DR_CROSS_STATS) || defined(DR_VIEW_FASTEST)
+    (defined(DR_PHASE_TIMING) && DR_PHASE_TIMING != 0) || defined(DR_LANE_STATS) || defined(DR_CROSS_STATS) || defined(DR_VIEW_FASTEST) || (defined(DR_F1_RESIDENT) && DR_F1_RESIDENT != 0)
 #define DR_EXPERIMENT_DIAG 1
 #else
 #define DR_EXPERIMENT_DIAG 0

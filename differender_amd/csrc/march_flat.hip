@@ -1707,21 +1707,20 @@ static inline bool taps_narrow(const MarchArgs &a) {
 
 // B1 (the backward with a gradient box), launched from its own translation unit
 template <typename VT>
-int flat_bwd_vol_launch(const MarchArgs &a, BrickParams<VT> P, dim3 grid1, size_t lds, bool want_tf, hipStream_t stream);
+int flat_bwd_vol_launch(const MarchArgs &a, BrickParams<VT> P, dim3 grid1, bool want_tf, hipStream_t stream);
 
 #ifdef DR_FLAT_TU_BWDVOL
 template <typename VT>
-int flat_bwd_vol_launch(const MarchArgs &a, BrickParams<VT> P, dim3 grid1, size_t lds_unused, bool want_tf, hipStream_t stream) {
+int flat_bwd_vol_launch(const MarchArgs &a, BrickParams<VT> P, dim3 grid1, bool want_tf, hipStream_t stream) {
     hipError_t e = hipSuccess;
     // (the LDS size is this translation unit's own: tuning / what-if switches may be given to it alone, tools/mkvariant.sh BWDVOL_EXTRA)
-    (void)lds_unused;
     const size_t lds = flat_lds_bytes<true>(a.R, true, want_tf) + DR_ABL_EXTRA_LDS_BWD;
     if (want_tf) DR_LAUNCH_BOTH(DR_MODE_DIFF, true, true, true, false, 1, (FlatCfg<true, true>::FNT))
     else DR_LAUNCH_BOTH(DR_MODE_DIFF, true, true, false, false, 1, (FlatCfg<true, true>::FNT))
     return (int)hipGetLastError();
 }
-template int flat_bwd_vol_launch<float>(const MarchArgs &, BrickParams<float>, dim3, size_t, bool, hipStream_t);
-template int flat_bwd_vol_launch<__half>(const MarchArgs &, BrickParams<__half>, dim3, size_t, bool, hipStream_t);
+template int flat_bwd_vol_launch<float>(const MarchArgs &, BrickParams<float>, dim3, bool, hipStream_t);
+template int flat_bwd_vol_launch<__half>(const MarchArgs &, BrickParams<__half>, dim3, bool, hipStream_t);
 #else
 
 template <typename VT>
@@ -1843,7 +1842,7 @@ static int flat_bwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     hipError_t e = hipSuccess;
     // (the brick records, live flags and work items are the forward's: same inputs, same workspace)
     if (wv) {   // B1: march_flat_bwdvol.o
-        const int rc = flat_bwd_vol_launch<VT>(a, P, grid1, lds, wt, stream);
+        const int rc = flat_bwd_vol_launch<VT>(a, P, grid1, wt, stream);
         if (rc) return rc;
     } else DR_LAUNCH_BOTH(DR_MODE_DIFF, true, false, true, false, 1, (FlatCfg<true, false>::FNT))
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
