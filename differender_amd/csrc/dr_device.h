@@ -253,6 +253,15 @@ __device__ __forceinline__ float pow_inv_sr(float base, float inv_sr) {
 // VR.py:205-219 + 284-285. tf is a [R][4] table (LDS or global). sm.I must be set.
 // Two halves: the TF lookup, and the opacity of the sample's alpha at this sampling rate -- at rates other than 1 a
 // power of 10 - 60 instructions that the non-differentiable march only needs where alpha > 1e-3 (VR.py:334).
+// ... its alpha alone, from a table of alphas (the alpha pre-pass keeps nothing else of the TF in LDS): the same index, fraction
+// and lerp as below, so sm.a is bit-identical
+__device__ __forceinline__ void tf_alpha_from_I(const float *tfa, int R, float tf_len, Sample &sm) {
+    sm.xtf = sm.I * tf_len;
+    low_high_frac(sm.xtf, sm.lo, sm.fr);
+    sm.lo = min(sm.lo, R - 1);
+    sm.hi = min(sm.lo + 1, R - 1);
+    sm.a = mixf(tfa[sm.lo], tfa[sm.hi], sm.fr);
+}
 __device__ __forceinline__ void tf_lookup_from_I(const float4 *tf, int R, float tf_len, Sample &sm) {
     sm.xtf = sm.I * tf_len;
     low_high_frac(sm.xtf, sm.lo, sm.fr);

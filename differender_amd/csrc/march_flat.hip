@@ -111,11 +111,11 @@ namespace dr {
 #endif
 // Workgroup configuration of a brick kernel: forward / alpha pre-pass / backward with a gradient box / backward w.r.t. the TF only.
 // ALPHA: 0 = not the pre-pass; 1 = the pre-pass in the forward's shape (256-entry tables, five workgroups per CU); 2 = the pre-pass
-// of HIGH sampling rates (>= 3): 160-entry tables and 80 VGPRs put SIX workgroups on a CU -- at rate 8 a segment holds ~400
+// of HIGH sampling rates (>= 3): 192-entry tables, an alpha-only TF table (4 B per entry) and 80 VGPRs put SIX workgroups on a CU -- at rate 8 a segment holds ~400
 // samples and occupancy is what the short, latency-bound workgroups lack (demo loop 10.35 -> 10.14 ms); at rate 1 a brick's ~196
 // candidates would take two listing rounds (512^3 tf1 forward +2.5 %): same-device rows in profiles/r05_ab_experiments.txt.
 #ifndef DR_FEC_ALPHA_HI
-#define DR_FEC_ALPHA_HI 160
+#define DR_FEC_ALPHA_HI 192   // (with the pre-pass's alpha-only TF table: 25.3 KB at R = 256; 160 and 208 entries within 0.4 %)
 #endif
 #ifndef DR_ALPHA_WAVES_HI
 #define DR_ALPHA_WAVES_HI 6
@@ -142,6 +142,7 @@ struct FlatLds {
     int *slen;      // true length of the segment (its flat extent is padded to a multiple of the samples per lane)
     int *live;      // backward: live sample count of the ray
     float *gmax;    // backward: per wave, the largest |grad_out| among the brick's candidate pixels
+    float *tfa;     // alpha pre-pass: the TF table holds the R alphas only (4 B per entry instead of 16)
     float *mm;      // forward: per wave, smallest / largest staged voxel and a NaN flag (brick_empty_test)
 };
 // LDS layout: everything of compile-time size first (so every address below is an immediate), then the two
@@ -160,7 +161,7 @@ __host__ __device__ constexpr size_t flat_fixed_bytes(bool want_vol, int alpha =
 }
 template <bool BWD>
 __host__ __device__ inline size_t flat_lds_bytes(int R, bool want_vol, bool want_tf, int alpha = 0) {
-    return flat_fixed_bytes<BWD>(want_vol, alpha) + (size_t)R * 16 + ((BWD && want_tf) ? (want_vol ? DR_DTF_BYTES(R) : (size_t)R * 32) : 0);
+    return flat_fixed_bytes<BWD>(want_vol, alpha) + (alpha ? align16((size_t)R * 4) : (size_t)R * 16) + ((BWD && want_tf) ? (want_vol ? DR_DTF_BYTES(R) : (size_t)R * 32) : 0);
 }
 template <bool BWD, bool WANT_VOL, bool WANT_TF, int ALPHA = 0>
 __device__ __forceinline__ FlatLds flat_carve(unsigned char *smem, int R) {
@@ -181,7 +182,8 @@ __device__ __forceinline__ FlatLds flat_carve(unsigned char *smem, int R) {
     L.mm = nullptr;
     if (BWD) { L.live = reinterpret_cast<int *>(smem + o); o += (size_t)EC * 4; L.gmax = reinterpret_cast<float *>(smem + o); o += 64; }
     else { L.mm = reinterpret_cast<float *>(smem + o); o += 48; }
-    L.tf = reinterpret_cast<float4 *>(smem + o); o += (size_t)R * 16;
+    L.tf = reinterpret_cast<float4 *>(smem + o); o += ALPHA ? align16((size_t)R * 4) : (size_t)R * 16;   // (the pre-pass: R alphas, read as L.tfa)
+    L.tfa = reinterpret_cast<float *>(L.tf);
     if (BWD && WANT_TF) L.dtf = reinterpret_cast<unsigned long long *>(smem + o);
     return L;
 }
@@ -227,7 +229,7 @@ struct BoxStage {
     float bv[NPASS];
     float4 tfv;
 };
-template <typename VT, int FNT>
+template <typename VT, int FNT, bool ALPHA_TF = false>
 __device__ __forceinline__ void box_issue(const BrickParams<VT> &P, const VolView<VT> &vol, const BrickCtx &c,
                                           const float4 *tfg, BoxStage<FNT> &st) {
     using S = BoxStage<FNT>;
@@ -246,9 +248,11 @@ __device__ __forceinline__ void box_issue(const BrickParams<VT> &P, const VolVie
             st.bv[k] = ld_voxel(base + (a_off + b * w.gb + d * w.gd));
     }
     st.tfv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (P.R <= FNT) { if ((int)threadIdx.x < P.R) st.tfv = tfg[threadIdx.x]; }  // uniform: the usual one texel per thread
+    if (P.R <= FNT) {   // uniform: the usual one texel per thread
+        if ((int)threadIdx.x < P.R) { if (ALPHA_TF) st.tfv.w = tfg[threadIdx.x].w; else st.tfv = tfg[threadIdx.x]; }
+    }
 }
-template <typename VT, int FNT>
+template <typename VT, int FNT, bool ALPHA_TF = false>
 __device__ __forceinline__ void box_commit(const BrickParams<VT> &P, const VolView<VT> &vol, const BrickCtx &c,
                                            const float4 *tfg, const BoxStage<FNT> &st, FlatLds &L) {
     using S = BoxStage<FNT>;
@@ -264,8 +268,13 @@ __device__ __forceinline__ void box_commit(const BrickParams<VT> &P, const VolVi
             if (r < BOX * BOX) L.box[a_lds + b * w.lb + d * w.ld] = st.bv[k];
         }
     }
-    if (P.R <= FNT) { if ((int)threadIdx.x < P.R) L.tf[threadIdx.x] = st.tfv; }
-    else { for (int k = threadIdx.x; k < P.R; k += FNT) L.tf[k] = tfg[k]; }
+    if (ALPHA_TF) {
+        if (P.R <= FNT) { if ((int)threadIdx.x < P.R) L.tfa[threadIdx.x] = st.tfv.w; }
+        else { for (int k = threadIdx.x; k < P.R; k += FNT) L.tfa[k] = tfg[k].w; }
+    } else {
+        if (P.R <= FNT) { if ((int)threadIdx.x < P.R) L.tf[threadIdx.x] = st.tfv; }
+        else { for (int k = threadIdx.x; k < P.R; k += FNT) L.tf[k] = tfg[k]; }
+    }
 }
 
 // ---- Empty bricks (round 5; see brick_probe_empty in dr_brick_common.h) -------------------------------------------------------
@@ -291,7 +300,7 @@ __device__ __forceinline__ void brick_empty_publish(const BoxStage<FNT> &st, Fla
 // the largest staged voxel (trilinear taps are convex combinations; a few ulps of rounding are absorbed by the texel of slack on
 // either side), so it indexes TF texels [lo, hi]; if none of those composites, no sample of the brick does. One more barrier
 // (only for bricks whose nine probes said "maybe"). Workgroup-uniform result.
-template <typename VT, int FNT>
+template <typename VT, int FNT, bool ALPHA_TF>
 __device__ __forceinline__ bool brick_empty_decide(const BrickParams<VT> &P, const FlatLds &L) {
     static_assert(FNT / 64 <= 4, "mm holds four waves");
     float mn = 3.0e38f, mx = -3.0e38f, nn = 0.0f;
@@ -301,7 +310,7 @@ __device__ __forceinline__ bool brick_empty_decide(const BrickParams<VT> &P, con
     const int lo = min(max((int)fminf(fmaxf(mn, 0.0f) * P.tf_len, (float)P.R) - 1, 0), P.R - 1);
     const int hi = min((int)fminf(fmaxf(mx, 0.0f) * P.tf_len, (float)P.R) + 2, P.R - 1);
     bool bad = nn != 0.0f;   // a NaN voxel: leave the brick to the ordinary path
-    for (int k = lo + (int)threadIdx.x; k <= hi; k += FNT) bad = bad || texel_composites(L.tf[k].w, P.nondiff);
+    for (int k = lo + (int)threadIdx.x; k <= hi; k += FNT) bad = bad || texel_composites(ALPHA_TF ? L.tfa[k] : L.tf[k].w, P.nondiff);
     return !__syncthreads_or(bad);
 }
 // Part 3: the brick is empty -- the wave's segments need their exact in-brick sample counts and nothing else. One lane per
@@ -895,11 +904,11 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
     if (lazy) {
         flat_build_entries<VT, MODE, BWD, WANT_VOL, ALPHA, KS>(P, c, cam, view, cd, L, nE0, M0, live_flag);
         if (!__syncthreads_or(nE0 > 0) && r_hi - r_lo <= ROUND) return;  // uniform: no wave found a segment
-        if (!reuse_box) box_issue<VT, FNT>(P, vol, c, P.tf + view * P.tf_vs, stage);
+        if (!reuse_box) box_issue<VT, FNT, ALPHA != 0>(P, vol, c, P.tf + view * P.tf_vs, stage);
     } else {
         float gm = 0.0f, gn = 3.0e38f;
         if (BWD && WANT_VOL) cand_grad_range<VT, FNT>(P, c, view, r_lo, r_hi, hits, c_lo, ncand_all, gm, gn);  // upstream gradients of the candidates,
-        if (!reuse_box) box_issue<VT, FNT>(P, vol, c, P.tf + view * P.tf_vs, stage);      // voxel box + TF: in flight ...
+        if (!reuse_box) box_issue<VT, FNT, ALPHA != 0>(P, vol, c, P.tf + view * P.tf_vs, stage);      // voxel box + TF: in flight ...
         if (BWD) {
             if (WANT_VOL) for (int k = threadIdx.x; k < DR_DBOX_WORDS; k += FNT) L.dbox[k] = 0ull;
             if (WANT_TF) for (int k = threadIdx.x; k < (WANT_VOL ? (int)(DR_DTF_BYTES(P.R) / 8) : 4 * P.R); k += FNT) L.dtf[k] = 0ull;
@@ -913,7 +922,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
 #if DR_PHASE_TIMING == 3
     const long long tq2 = clock64();   // candidates loaded and listed
 #endif
-    if (!reuse_box) box_commit<VT, FNT>(P, vol, c, P.tf + view * P.tf_vs, stage, L);
+    if (!reuse_box) box_commit<VT, FNT, ALPHA != 0>(P, vol, c, P.tf + view * P.tf_vs, stage, L);
     const bool test_empty = !BWD && !reuse_box && c.maybe_empty != 0;  // uniform
     if constexpr (!BWD) { if (test_empty) brick_empty_publish<FNT>(stage, L); }
     if (!reuse_box) box_valid = 1;
@@ -932,7 +941,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
 #endif
     bool brick_empty = false;  // uniform: no sample of this brick composites anything (forward passes only)
     if constexpr (!BWD) {
-        if (test_empty) { if (brick_empty_decide<VT, FNT>(P, L)) box_valid = 2; }
+        if (test_empty) { if (brick_empty_decide<VT, FNT, ALPHA != 0>(P, L)) box_valid = 2; }
         brick_empty = box_valid == 2;
     }
     bool acc64 = false;  // brick-uniform: d_volume accumulates in double
@@ -1050,7 +1059,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                     }
                     if (va) {
                         sa.I = tri_lds(L.box, (x0 - c.ox) * BOX_SX + (y0 - c.oy) * BOX_SY + (z0 - c.oz), fx, fy, fz);
-                        tf_lookup_from_I(L.tf, P.R, P.tf_len, sa);
+                        tf_alpha_from_I(L.tfa, P.R, P.tf_len, sa);
                         if constexpr (MODE != DR_MODE_NONDIFF) {
                             const float opj = opacity_of_alpha(sa.a, P.inv_sr);
                             lit_lane = lit_lane || opj != 0.0f;   // (the colour march's own test: c = L * rgb * op is exactly 0 for op == 0)
