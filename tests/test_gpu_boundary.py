@@ -311,3 +311,23 @@ def test_wrong_hint_reports_are_scoped_and_expire(oracle, hiplib):
         assert calls <= (H.DISTRUST_REFRESHES + 2) * H.REFRESH_EVERY
     assert calls >= (H.DISTRUST_REFRESHES - 1) * H.REFRESH_EVERY
     assert H._seen[H._key(tf_b)]["host"] is host0 and host0 is not None
+
+
+def test_trainable_tf_is_read_on_first_sight(oracle, hiplib):
+    """A TF that requires grad is a parameter somebody optimises: its largest alpha is read the first time it is seen (a plain
+    tensor: the second time), so a training loop that rewrites it every iteration gets the harmless "many rays terminate" hint
+    from its second or third iteration on instead of its ninth."""
+    from differender_amd import functional as Fn
+    H = Fn._TerminationHints()
+    tf_h = oracle.bench_tf(32, 0.5)                      # opaque: rays terminate
+    shape = (32, 32, 32)
+    tf_p = T(tf_h).requires_grad_(True)
+    tf_c = T(tf_h * 1.0)
+    got_p, got_c = [], []
+    for k in range(3):
+        got_p.append(H.hints(tf_p, shape, 1.0, 4096, 0)); got_c.append(H.hints(tf_c, shape, 1.0, 4096, 0))
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            tf_p.mul_(0.999); tf_c.mul_(0.999)          # an optimiser step: the version moves every iteration
+    assert got_p[0] == 0 and Fn.N.DR_HINT_EARLY_TERMINATION in got_p[1:], got_p
+    assert got_c == [0, 0, 0], got_c                     # a plain tensor that changes every call is not read before its eighth call
