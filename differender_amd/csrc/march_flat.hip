@@ -83,6 +83,10 @@ namespace dr {
 #ifndef DR_PP_GROUPS
 #define DR_PP_GROUPS 6   // layer groups of the alpha pre-pass at sampling rates >= 3
 #endif
+#ifndef DR_PP_GROUPS_LO
+#define DR_PP_GROUPS_LO 3   // ... and below 3 under DR_HINT_EARLY_TERMINATION (round 5: 2 / 3 / 4 / 6 / 9 groups at rate 1 -- demo forward
+                            // 1.75 / 1.63 / 1.63 / 1.68 / 1.80 ms, 512^3 tf1 forward 1.54 / 1.42 / 1.43 / 1.45 / 1.51, CT-like 1.35 / 1.40 / 1.44 / 1.50 / 1.62)
+#endif
 #ifndef DR_ALPHA_K
 #define DR_ALPHA_K 4    // alpha pre-pass
 #endif
@@ -1786,7 +1790,7 @@ static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
         // quarters of all samples lie behind the termination point): ground-truth renders at sampling rate 8 take
         // 11.0 instead of 15.0 ms (8 views, 256^3). Each extra group costs the non-terminating case two empty
         // launches (~10 us: +0.7 % on the 512^3 headline at G = 2 for -2.5 % with tf1), so below sampling rate 3: G = 1.
-        const int G = (a.sr >= 3.0f || (a.hints & DR_HINT_EARLY_TERMINATION)) ? DR_PP_GROUPS : 1;
+        const int G = a.sr >= 3.0f ? DR_PP_GROUPS : ((a.hints & DR_HINT_EARLY_TERMINATION) ? DR_PP_GROUPS_LO : 1);
         MarchArgs pa = a;
         const size_t lds_f1 = lds;
         (void)lds_f1;
