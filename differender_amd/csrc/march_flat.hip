@@ -460,7 +460,7 @@ __device__ __forceinline__ int wave_incl_sum(int v) {
 // rounding -- is reproducible.
 template <typename VT, int MODE, bool BWD, bool WANT_VOL, int ALPHA = 0, int KS = 1>
 __device__ __forceinline__ void flat_build_entries(const BrickParams<VT> &P, const BrickCtx &c, f3 cam, int view,
-                                                   const CandData &d, FlatLds &L, int &nE, int &M, int *live_flag) {
+                                                   const CandData &d, FlatLds &L, int &nE, int &M, int *live_flag, bool count_stats) {
     constexpr int CW = FlatCfg<BWD, WANT_VOL, ALPHA>::CW;
     bool has = false;
     int s0 = 0, s1 = 0;
@@ -499,7 +499,13 @@ __device__ __forceinline__ void flat_build_entries(const BrickParams<VT> &P, con
         // write. The brick still holds live samples of the view: the backward (alpha = 0 has a slope) must not skip it.
         const bool skip = has && P.lm_words > 0 && (((lay < 64 ? d.um0 : d.um1) >> (lay & 63)) & 1ull);
         if (skip) has = false;
-        if constexpr (MODE == DR_MODE_DIFF) { if (__any(skip) && (threadIdx.x & 63) == 0) *live_flag = 1; }
+        const unsigned long long skm = __ballot(skip);
+        if (skm != 0ull && (threadIdx.x & 63) == 0) {
+            // (diagnostics, workspace_stats()[12]: every 64th workgroup reports -- atomics of EVERY wave on one word cost the
+            //  CT-like 512^3 forward 3.3 ms)
+            if (count_stats) atomicAdd(&P.stats[ST_UNLIT_SKIPPED], (unsigned int)__popcll(skm));
+            if constexpr (MODE == DR_MODE_DIFF) *live_flag = 1;
+        }
     }
     const unsigned long long hm = __ballot(has);
     const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
@@ -824,6 +830,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
     constexpr int KS = BWD ? (BWD_TF ? DR_BWDTF_K : 1) : KF;  // consecutive samples per lane
     const int nbricks = P.g.NBx * P.g.NBy * P.g.NBz;
     int *live_flag = &const_cast<BrickCtxRec *>(P.ctx)[(size_t)view * nbricks + slot].live;   // "this brick holds live samples of the view"
+    const bool count_stats = (slot & 63) == 0;   // diagnostics counters (ST_UNLIT_SKIPPED, ST_EMPTY_BRICKS) are SAMPLED: one workgroup in 64
 #if DR_PHASE_TIMING == 3
     const long long tq0 = clock64();
 #endif
@@ -906,7 +913,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
     // anything when there are none.
     const bool lazy = (!BWD && !ALPHA && P.use_live && P.vflags[view] != 0u) || (ALPHA && !P.pp_first);  // uniform
     if (lazy) {
-        flat_build_entries<VT, MODE, BWD, WANT_VOL, ALPHA, KS>(P, c, cam, view, cd, L, nE0, M0, live_flag);
+        flat_build_entries<VT, MODE, BWD, WANT_VOL, ALPHA, KS>(P, c, cam, view, cd, L, nE0, M0, live_flag, count_stats);
         if (!__syncthreads_or(nE0 > 0) && r_hi - r_lo <= ROUND) return;  // uniform: no wave found a segment
         if (!reuse_box) box_issue<VT, FNT, ALPHA != 0>(P, vol, c, P.tf + view * P.tf_vs, stage);
     } else {
@@ -921,7 +928,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                 if ((threadIdx.x & 63) == 0) { L.gmax[threadIdx.x >> 6] = gm; L.gmax[8 + (threadIdx.x >> 6)] = gn; }
             }
         }
-        flat_build_entries<VT, MODE, BWD, WANT_VOL, ALPHA, KS>(P, c, cam, view, cd, L, nE0, M0, live_flag);  // ... while the segments are listed
+        flat_build_entries<VT, MODE, BWD, WANT_VOL, ALPHA, KS>(P, c, cam, view, cd, L, nE0, M0, live_flag, count_stats);  // ... while the segments are listed
     }
 #if DR_PHASE_TIMING == 3
     const long long tq2 = clock64();   // candidates loaded and listed
@@ -947,6 +954,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
     if constexpr (!BWD) {
         if (test_empty) { if (brick_empty_decide<VT, FNT, ALPHA != 0>(P, L)) box_valid = 2; }
         brick_empty = box_valid == 2;
+        if (brick_empty && count_stats && threadIdx.x == 0) atomicAdd(&P.stats[ST_EMPTY_BRICKS], 1u);   // (diagnostics: workspace_stats()[13])
     }
     bool acc64 = false;  // brick-uniform: d_volume accumulates in double
     if (BWD && WANT_VOL) {
@@ -973,7 +981,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
         int nE = nE0, M = M0;
         if (cbase > r_lo) {
             cand_load<VT, MODE, BWD, ALPHA, WANT_VOL>(P, c, view, cbase, r_hi, hits, c_lo, ncand_all, cd);
-            flat_build_entries<VT, MODE, BWD, WANT_VOL, ALPHA, KS>(P, c, cam, view, cd, L, nE, M, live_flag);  // syncs inside
+            flat_build_entries<VT, MODE, BWD, WANT_VOL, ALPHA, KS>(P, c, cam, view, cd, L, nE, M, live_flag, count_stats);  // syncs inside
         }
         any = any || nE > 0;
         // this wave's own segment table: entries [ea, eb), flat samples [0, M); offsets live at index entry + wave

@@ -102,7 +102,10 @@ def workspace_stats(workspace):
     (those plus the irregular ones: single-sample rays), [4] = bricks whose d_volume box accumulated in double (last
     backward), [5] = overflow work items heavy bricks were cut into, [8] = views for which a DR_HINT_NO_EARLY_TERMINATION
     hint turned out wrong (their rays were marched one by one), [9] = backward calls that did not find their forward's
-    fingerprint in this workspace and marched every ray one by one, [3] = the forward's fingerprint (0: nobody's)."""
+    fingerprint in this workspace and marched every ray one by one, [3] = the forward's fingerprint (0: nobody's),
+    [12] = (ray, layer) segments the colour march skipped because the alpha pre-pass had found them unlit, [13] = brick workgroups
+    (of all forward passes) that took the empty-brick path -- both SAMPLED (every 64th workgroup reports), 0 when the mechanisms have
+    nothing to do."""
     return workspace[:64].view(torch.int32).cpu()
 
 

@@ -1135,7 +1135,11 @@ def test_empty_bricks_and_unlit_segments(oracle, hiplib, mode, sr):
     for hint in (0, Fn.N.DR_HINT_EARLY_TERMINATION):
         ws = Fn.alloc_workspace(1, WH, vol.shape, R, dev())
         out, steps = Fn.march_fwd(T(vol), T(tf), T(cam[None]), e, x, r, n, 1 << 20, sr, mode, workspace=ws, hints=hint)
-        assert int(Fn.workspace_stats(ws)[0]) == 0, "rays failed their sample count and were marched one by one"
+        st = Fn.workspace_stats(ws)
+        assert int(st[0]) == 0, "rays failed their sample count and were marched one by one"
+        # ... and both mechanisms DID run (workspace header words 12 / 13): this scene is mostly air, its rays cross unlit TF ranges
+        assert int(st[13]) > 5, f"only {int(st[13])} of the sampled workgroups (1 in 64) took the empty-brick path"
+        assert int(st[12]) > 5, f"only {int(st[12])} segments were skipped by the colour march (sampled: 1 workgroup in 64)"
         assert np.array_equal(steps[0].cpu().numpy(), sref)
         assert np.abs(out[0].cpu().numpy() - ref).max() <= FWD_TOL
     if mode == 0:   # the backward re-marches every live sample itself (alpha = 0 has a slope): d_tf of the air's texels included
