@@ -234,10 +234,11 @@ class _TerminationHints:
                 self._seen.pop(next(iter(self._seen)))
             self._seen[key] = {"tensor": tf.detach(), "seen": tf._version, "value": None, "value_version": None,
                                "pending": None, "since": 0, "host": None, "distrust": 0, "strikes": 0}
-            # A tensor that requires grad is a parameter somebody optimises: it WILL be seen again (unlike a temporary), so its
-            # largest alpha is read at once -- the harmless "many rays terminate" hint is then there from the second or third
-            # iteration of a training loop instead of the ninth (OPT.py's TF: forward 1.81 -> 1.69 ms per iteration).
-            if tf.requires_grad:
+            # A LEAF that requires grad is a parameter somebody optimises: it WILL be seen again (unlike a temporary -- and unlike
+            # the result of a differentiable op, e.g. torch.sigmoid(logits): a new tensor every iteration that also "requires
+            # grad"), so its largest alpha is read at once -- the harmless "many rays terminate" hint is then there from the second
+            # or third iteration of a training loop instead of the ninth (OPT.py's TF: forward 1.81 -> 1.63 ms per iteration).
+            if tf.requires_grad and tf.is_leaf:
                 self._start_read(self._seen[key], tf, alpha)
             return None, False
         if ent["pending"] is not None and ent["pending"][1].query():

@@ -331,3 +331,11 @@ def test_trainable_tf_is_read_on_first_sight(oracle, hiplib):
             tf_p.mul_(0.999); tf_c.mul_(0.999)          # an optimiser step: the version moves every iteration
     assert got_p[0] == 0 and Fn.N.DR_HINT_EARLY_TERMINATION in got_p[1:], got_p
     assert got_c == [0, 0, 0], got_c                     # a plain tensor that changes every call is not read before its eighth call
+    # the RESULT of a differentiable op also "requires grad" but is a new tensor every iteration: no read, no cache entry kept hot
+    logits = T(tf_h).requires_grad_(True)
+    for k in range(3):
+        t = torch.sigmoid(logits)
+        assert t.requires_grad and not t.is_leaf
+        assert H.hints(t, shape, 1.0, 4096, 0) == 0
+        assert H._seen[H._key(t)]["pending"] is None
+        torch.cuda.synchronize(); del t
