@@ -79,7 +79,8 @@ struct BrickCtx {
     float lo[3], hi[3];           // world AABB of the brick's cells, with slack
     int i0, i1, j0, j1;           // candidate pixel rectangle (inclusive); empty if i0 > i1
     int live;                     // from the workspace record (see BrickCtxRec)
-    int maybe_empty;              // forward: nine probes of the brick found nothing that composites (brick_ctx_kernel; see brick_empty_test)
+    int maybe_empty;              // forward: bit 0 = nine probes of the brick found nothing that composites (brick_ctx_kernel); bit 1 = the
+                                  // workgroup that staged it DECIDED it empty (brick_empty_decide) -- the d_volume-only backward skips it
 };
 
 // BrickCtx as stored in the workspace (64 B): every workgroup of F1 / P1 / B1 reads its record with scalar loads

@@ -846,6 +846,11 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
     }
     // backward after a flat forward: bricks in which the forward marched nothing (rays terminated before them) have no work
     if (BWD && !DR_PHASE_TIMING && c.live == 0) return;  // uniform
+    // ... and bricks the forward found EMPTY (no sample composites: every TF texel their voxels can index has alpha exactly 0) give
+    // d_volume nothing: a sample's intensity adjoint is r_bar (r_hi - r_lo) + ... + a_bar (a_hi - a_lo) with r/g/b_bar = L op T go = 0
+    // and a_hi = a_lo = 0, its normal-path adjoint carries the factor op = 0. (d_tf is another matter: alpha = 0 has a slope, the
+    // air's texels collect a_bar from every such sample -- with a TF gradient wanted the brick is marched like any other.)
+    if (BWD && WANT_VOL && !WANT_TF && !DR_PHASE_TIMING && (c.maybe_empty & 2) != 0) return;  // uniform
 
 #if DR_SETPRIO
     __builtin_amdgcn_s_setprio(3);  // the staging / listing prologue is short and latency-bound: let it overtake sample loops
@@ -934,7 +939,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
     const long long tq2 = clock64();   // candidates loaded and listed
 #endif
     if (!reuse_box) box_commit<VT, FNT, ALPHA != 0>(P, vol, c, P.tf + view * P.tf_vs, stage, L);
-    const bool test_empty = !BWD && !reuse_box && c.maybe_empty != 0;  // uniform
+    const bool test_empty = !BWD && !reuse_box && (c.maybe_empty & 1) != 0;  // uniform
     if constexpr (!BWD) { if (test_empty) brick_empty_publish<FNT>(stage, L); }
     if (!reuse_box) box_valid = 1;
 #if DR_PHASE_TIMING == 3
@@ -952,7 +957,15 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
 #endif
     bool brick_empty = false;  // uniform: no sample of this brick composites anything (forward passes only)
     if constexpr (!BWD) {
-        if (test_empty) { if (brick_empty_decide<VT, FNT, ALPHA != 0>(P, L)) box_valid = 2; }
+        if (test_empty) {
+            if (brick_empty_decide<VT, FNT, ALPHA != 0>(P, L)) {
+                box_valid = 2;
+                // the record remembers it (bit 1): a backward that only wants d_volume has nothing to do in this brick -- opacity 0
+                // and a flat alpha (both texels exactly 0) make every d_volume term of its samples vanish (see B1 below)
+                if (MODE == DR_MODE_DIFF && threadIdx.x == 0)
+                    const_cast<BrickCtxRec *>(P.ctx)[(size_t)view * nbricks + slot].maybe_empty = 3;
+            }
+        }
         brick_empty = box_valid == 2;
         if (brick_empty && count_stats && threadIdx.x == 0) atomicAdd(&P.stats[ST_EMPTY_BRICKS], 1u);   // (diagnostics: workspace_stats()[13])
     }

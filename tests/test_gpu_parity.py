@@ -1148,6 +1148,11 @@ def test_empty_bricks_and_unlit_segments(oracle, hiplib, mode, sr):
         dv, dt = Fn.march_bwd(T(vol), T(tf), T(cam[None]), e, x, r, n, 1 << 20, sr, T(g[None]), out, workspace=ws)
         assert grad_close(dv.cpu().numpy(), dv0)[0] and grad_close(dt.cpu().numpy(), dt0)[0]
         assert np.abs(dt0[0]).max() > 0   # texel 0 (air) does receive a gradient
+        # a backward that wants d_volume ONLY skips the bricks the forward decided empty (opacity 0 and a flat alpha: every d_volume
+        # term of their samples vanishes): same d_volume
+        dv_only, none = Fn.march_bwd(T(vol), T(tf), T(cam[None]), e, x, r, n, 1 << 20, sr, T(g[None]), out, workspace=ws, want_tf=False)
+        assert none is None and grad_close(dv_only.cpu().numpy(), dv0)[0]
+        assert float((dv_only - dv).abs().max()) <= 1e-6 * float(dv.abs().max())
 
 
 def test_empty_brick_test_is_exact_at_its_edges(oracle, hiplib):
