@@ -67,6 +67,8 @@ enum {
     ST_DONE_MAIN = 11,
     ST_UNLIT_SKIPPED = 12, // forward: (ray, layer) segments the colour march dropped because the alpha pre-pass had found them unlit ...
     ST_EMPTY_BRICKS = 13,  // ... and (view, brick) workgroups (all passes) that took the empty-brick path: both SAMPLED, every 64th workgroup reports
+    ST_MASKS = 14,         // forward (differentiable): words per ray of "unlit" layer masks it left behind seg_cnt (0: none) -- read by the
+                           // d_volume-only backward
     ST_STALE_BWD = 9,      // backward calls that did not find their forward's fingerprint here and marched every ray one by one
     ST_F64_BRICKS = 4,     // backward: (view, brick) pairs whose d_volume box accumulated in double (wide local range of |grad_out|)
     ST_TIMING = 16,        // DR_PHASE_TIMING: u64 x3 forward phases, u64 x3 backward phases, u64 backward lifetime
@@ -280,7 +282,7 @@ static __global__ __launch_bounds__(256) void brick_ctx_kernel(BrickParams<VT> P
                 const float lim = 1.0f + 1e-3f;
                 P.vflags[view] = flag;
                 P.vflags[P.n_views + view] = (fabsf(cx) <= lim && fabsf(cy) <= lim && fabsf(cz) <= lim) ? 1u : 0u;
-                if (view == 0) { P.stats[ST_REPAIR] = 0u; P.stats[ST_BASELINE_RAYS] = 0u; P.stats[ST_HINT_BAD] = 0u; P.stats[ST_STALE_BWD] = 0u; P.stats[ST_F64_BRICKS] = 0u; P.stats[ST_TICKET] = 0u; P.stats[ST_DONE] = 0u; P.stats[ST_TICKET_MAIN] = 0u; P.stats[ST_DONE_MAIN] = 0u; P.stats[ST_UNLIT_SKIPPED] = 0u; P.stats[ST_EMPTY_BRICKS] = 0u; P.stats[ST_MARK] = P.mark; }
+                if (view == 0) { P.stats[ST_REPAIR] = 0u; P.stats[ST_BASELINE_RAYS] = 0u; P.stats[ST_HINT_BAD] = 0u; P.stats[ST_STALE_BWD] = 0u; P.stats[ST_F64_BRICKS] = 0u; P.stats[ST_TICKET] = 0u; P.stats[ST_DONE] = 0u; P.stats[ST_TICKET_MAIN] = 0u; P.stats[ST_DONE_MAIN] = 0u; P.stats[ST_UNLIT_SKIPPED] = 0u; P.stats[ST_EMPTY_BRICKS] = 0u; P.stats[ST_MASKS] = P.nondiff ? 0u : (unsigned int)P.lm_words; P.stats[ST_MARK] = P.mark; }
             }
         }
     }

@@ -390,7 +390,7 @@ __device__ __forceinline__ bool line_meets_brick(const BrickCtx &c, f3 cam, f3 d
 // the rounds then run over [0, number of hits) instead of over the raw candidate range.
 template <typename VT, int MODE, bool BWD, int ALPHA, bool WANT_VOL>
 __device__ __forceinline__ void cand_load(const BrickParams<VT> &P, const BrickCtx &c, int view, int cbase, int ncand,
-                                          const unsigned short *hits, int c_lo, int ncand_all, CandData &d) {
+                                          const unsigned short *hits, int c_lo, int ncand_all, CandData &d, int lmw) {
     using Cfg = FlatCfg<BWD, WANT_VOL, ALPHA>;
     constexpr int FNW = Cfg::FNW, CW = Cfg::CW;  // candidates per wave and round
     const int NP = P.W * P.H;
@@ -431,11 +431,11 @@ __device__ __forceinline__ void cand_load(const BrickParams<VT> &P, const BrickC
     d.exit_ = P.exit_[d.p];
     d.vx = P.rays[3 * d.p]; d.vy = P.rays[3 * d.p + 1]; d.vz = P.rays[3 * d.p + 2];
     if (BWD || (!ALPHA && P.use_live) || (ALPHA && !P.pp_first)) d.live = P.ws_steps[d.p];
-    if constexpr (!BWD && !ALPHA) {
-        if (P.lm_words > 0) {   // uniform; same batch of loads as the ray buffers
-            const unsigned long long *um = P.unlit + ((size_t)view * P.lm_words * NP + d.pl);
+    if constexpr (!ALPHA && (!BWD || WANT_VOL)) {
+        if (lmw > 0) {   // uniform; same batch of loads as the ray buffers
+            const unsigned long long *um = P.unlit + ((size_t)view * lmw * NP + d.pl);
             d.um0 = um[0];
-            if (P.lm_words > 1) d.um1 = um[NP];
+            if (lmw > 1) d.um1 = um[NP];
         }
     }
     if (BWD) d.rflag = P.rayflag[d.p];  // (the three float4 of the coarse tape / gradients are fetched per chunk: the
@@ -460,7 +460,7 @@ __device__ __forceinline__ int wave_incl_sum(int v) {
 // rounding -- is reproducible.
 template <typename VT, int MODE, bool BWD, bool WANT_VOL, int ALPHA = 0, int KS = 1>
 __device__ __forceinline__ void flat_build_entries(const BrickParams<VT> &P, const BrickCtx &c, f3 cam, int view,
-                                                   const CandData &d, FlatLds &L, int &nE, int &M, int *live_flag, bool count_stats) {
+                                                   const CandData &d, FlatLds &L, int &nE, int &M, int *live_flag, bool count_stats, int lmw) {
     constexpr int CW = FlatCfg<BWD, WANT_VOL, ALPHA>::CW;
     bool has = false;
     int s0 = 0, s1 = 0;
@@ -492,19 +492,21 @@ __device__ __forceinline__ void flat_build_entries(const BrickParams<VT> &P, con
         entry_brick(P.vol.scx, P.vol.scy, P.vol.scz, cam, vd, t0, ebx, eby, ebz);
         lay = ray_layer(c.bx, c.by, c.bz, ebx, eby, ebz);
     }
-    if constexpr (!BWD && !ALPHA) {
+    if constexpr (!ALPHA && (!BWD || WANT_VOL)) {
+        // (B1 gets here only as the d_volume-ONLY backward, lmw = 0 otherwise: an unlit segment's samples have opacity 0 and a flat
+        //  alpha, nothing of theirs reaches d_volume -- see the pre-pass's definition of "lit")
         // Colour march after an alpha pre-pass (round 5): the pre-pass has marched this very segment, counted its samples and
         // found none that composites (alpha <= 1e-3 in a non-differentiable render, VR.py:334; opacity exactly 0 in a
         // differentiable one). Its count and its all-zero partial are in the workspace already -- nothing to march, nothing to
         // write. The brick still holds live samples of the view: the backward (alpha = 0 has a slope) must not skip it.
-        const bool skip = has && P.lm_words > 0 && (((lay < 64 ? d.um0 : d.um1) >> (lay & 63)) & 1ull);
+        const bool skip = has && lmw > 0 && (((lay < 64 ? d.um0 : d.um1) >> (lay & 63)) & 1ull);
         if (skip) has = false;
         const unsigned long long skm = __ballot(skip);
         if (skm != 0ull && (threadIdx.x & 63) == 0) {
             // (diagnostics, workspace_stats()[12]: every 64th workgroup reports -- atomics of EVERY wave on one word cost the
             //  CT-like 512^3 forward 3.3 ms)
-            if (count_stats) atomicAdd(&P.stats[ST_UNLIT_SKIPPED], (unsigned int)__popcll(skm));
-            if constexpr (MODE == DR_MODE_DIFF) *live_flag = 1;
+            if (!BWD && count_stats) atomicAdd(&P.stats[ST_UNLIT_SKIPPED], (unsigned int)__popcll(skm));
+            if constexpr (MODE == DR_MODE_DIFF && !BWD) *live_flag = 1;
         }
     }
     const unsigned long long hm = __ballot(has);
@@ -831,6 +833,9 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
     const int nbricks = P.g.NBx * P.g.NBy * P.g.NBz;
     int *live_flag = &const_cast<BrickCtxRec *>(P.ctx)[(size_t)view * nbricks + slot].live;   // "this brick holds live samples of the view"
     const bool count_stats = (slot & 63) == 0;   // diagnostics counters (ST_UNLIT_SKIPPED, ST_EMPTY_BRICKS) are SAMPLED: one workgroup in 64
+    // words of the rays' "unlit" layer masks this pass may use (uniform): the forward's own; for the d_volume-only backward what the
+    // forward LEFT (header word ST_MASKS, written with the fingerprint checked above), for every other backward none
+    const int lmw = BWD ? ((WANT_VOL && !WANT_TF && P.lm_words > 0 && (int)P.stats[ST_MASKS] == P.lm_words) ? P.lm_words : 0) : P.lm_words;
 #if DR_PHASE_TIMING == 3
     const long long tq0 = clock64();
 #endif
@@ -909,7 +914,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
     // (Forward and pre-pass only: the backward's gradient box is flushed per item.)
     const bool reuse_box = HEAVY && !BWD && box_valid != 0;  // uniform
     CandData cd;
-    cand_load<VT, MODE, BWD, ALPHA, WANT_VOL>(P, c, view, r_lo, r_hi, hits, c_lo, ncand_all, cd);  // ray buffers of the first round's candidates
+    cand_load<VT, MODE, BWD, ALPHA, WANT_VOL>(P, c, view, r_lo, r_hi, hits, c_lo, ncand_all, cd, lmw);  // ray buffers of the first round's candidates
     BoxStage<FNT> stage;
     FixScale fs;
     int nE0, M0;
@@ -918,7 +923,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
     // anything when there are none.
     const bool lazy = (!BWD && !ALPHA && P.use_live && P.vflags[view] != 0u) || (ALPHA && !P.pp_first);  // uniform
     if (lazy) {
-        flat_build_entries<VT, MODE, BWD, WANT_VOL, ALPHA, KS>(P, c, cam, view, cd, L, nE0, M0, live_flag, count_stats);
+        flat_build_entries<VT, MODE, BWD, WANT_VOL, ALPHA, KS>(P, c, cam, view, cd, L, nE0, M0, live_flag, count_stats, lmw);
         if (!__syncthreads_or(nE0 > 0) && r_hi - r_lo <= ROUND) return;  // uniform: no wave found a segment
         if (!reuse_box) box_issue<VT, FNT, ALPHA != 0>(P, vol, c, P.tf + view * P.tf_vs, stage);
     } else {
@@ -933,7 +938,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                 if ((threadIdx.x & 63) == 0) { L.gmax[threadIdx.x >> 6] = gm; L.gmax[8 + (threadIdx.x >> 6)] = gn; }
             }
         }
-        flat_build_entries<VT, MODE, BWD, WANT_VOL, ALPHA, KS>(P, c, cam, view, cd, L, nE0, M0, live_flag, count_stats);  // ... while the segments are listed
+        flat_build_entries<VT, MODE, BWD, WANT_VOL, ALPHA, KS>(P, c, cam, view, cd, L, nE0, M0, live_flag, count_stats, lmw);  // ... while the segments are listed
     }
 #if DR_PHASE_TIMING == 3
     const long long tq2 = clock64();   // candidates loaded and listed
@@ -993,8 +998,8 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
     for (int cbase = r_lo; cbase < r_hi; cbase += ROUND) {
         int nE = nE0, M = M0;
         if (cbase > r_lo) {
-            cand_load<VT, MODE, BWD, ALPHA, WANT_VOL>(P, c, view, cbase, r_hi, hits, c_lo, ncand_all, cd);
-            flat_build_entries<VT, MODE, BWD, WANT_VOL, ALPHA, KS>(P, c, cam, view, cd, L, nE, M, live_flag, count_stats);  // syncs inside
+            cand_load<VT, MODE, BWD, ALPHA, WANT_VOL>(P, c, view, cbase, r_hi, hits, c_lo, ncand_all, cd, lmw);
+            flat_build_entries<VT, MODE, BWD, WANT_VOL, ALPHA, KS>(P, c, cam, view, cd, L, nE, M, live_flag, count_stats, lmw);  // syncs inside
         }
         any = any || nE > 0;
         // this wave's own segment table: entries [ea, eb), flat samples [0, M); offsets live at index entry + wave
@@ -1087,7 +1092,10 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                         tf_alpha_from_I(L.tfa, P.R, P.tf_len, sa);
                         if constexpr (MODE != DR_MODE_NONDIFF) {
                             const float opj = opacity_of_alpha(sa.a, P.inv_sr);
-                            lit_lane = lit_lane || opj != 0.0f;   // (the colour march's own test: c = L * rgb * op is exactly 0 for op == 0)
+                            // "lit" for the masks: the colour march's own test (c = L * rgb * op is exactly 0 for op == 0) AND a flat
+                            // alpha -- both texels exactly 0 -- so that the same bit also tells the d_volume-only backward that the
+                            // sample's intensity adjoint vanishes (it carries the factor a_hi - a_lo next to terms with the factor op)
+                            lit_lane = lit_lane || opj != 0.0f || L.tfa[sa.lo] != 0.0f || L.tfa[sa.hi] != 0.0f;
                             Tl *= 1.0f - opj;
                         }
                         ++cnt_lane;
@@ -1871,6 +1879,7 @@ static int flat_bwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     if (!a.workspace || a.workspace_bytes < need) return DR_EINVAL;
     BrickParams<VT> P = make_brick_params<VT>(a, w);
     const bool wv = a.d_vol != nullptr, wt = a.d_tf != nullptr;
+    P.lm_words = (wv && !wt && DR_UNLIT_SKIP > 1) ? w.lm_words : 0;   // the d_volume-only backward may skip unlit segments (if the forward left masks)
     const size_t lds = flat_lds_bytes<true>(a.R, wv, wt) + DR_ABL_EXTRA_LDS_BWD;
     const dim3 grid1(g.NBx * g.NBy * g.NBz, a.n_views);
     hipError_t e = hipSuccess;
