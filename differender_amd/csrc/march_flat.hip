@@ -1821,9 +1821,8 @@ static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
         // launches (~10 us: +0.7 % on the 512^3 headline at G = 2 for -2.5 % with tf1), so below sampling rate 3: G = 1.
         const int G = a.sr >= 3.0f ? DR_PP_GROUPS : ((a.hints & DR_HINT_EARLY_TERMINATION) ? DR_PP_GROUPS_LO : 1);
         MarchArgs pa = a;
-        const size_t lds_f1 = lds;
-        (void)lds_f1;
         const bool alpha_hi = a.sr >= 3.0f;   // six workgroups per CU (FlatCfg<.., 2>)
+        // (shadows the colour march's `lds` on purpose: the launch macros read that name)
         const size_t lds = flat_lds_bytes<false>(a.R, false, false, alpha_hi ? 2 : 1);   // the pre-pass's own table size
         for (int gi = 0; gi < G; ++gi) {
             pa.pp_l0 = g.NL * gi / G; pa.pp_l1 = g.NL * (gi + 1) / G; pa.pp_first = gi == 0;
