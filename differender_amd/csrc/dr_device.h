@@ -83,11 +83,43 @@ __device__ __forceinline__ void tri_cell(const VolView<VT> &v, float px, float p
     c.x1 = min(c.x0 + 1, v.VX - 1); c.y1 = min(c.y0 + 1, v.VY - 1); c.z1 = min(c.z0 + 1, v.VZ - 1);
 }
 
-// VR.py:173-189: 8 gathers, lerp order x -> y -> z
+// two voxels that are neighbours in memory, fetched as ONE element-pair load (4-byte aligned: global_load_dwordx2 / dword)
+struct __attribute__((packed, aligned(4))) VoxPairF { float a, b; };
+struct __attribute__((packed, aligned(2))) VoxPairH { unsigned short a, b; };
+__device__ __forceinline__ void ld_voxel_pair(const float *p, float &a, float &b) { const VoxPairF q = *reinterpret_cast<const VoxPairF *>(p); a = q.a; b = q.b; }
+__device__ __forceinline__ void ld_voxel_pair(const __half *p, float &a, float &b) {
+    const VoxPairH q = *reinterpret_cast<const VoxPairH *>(p);
+    a = __half2float(__ushort_as_half(q.a)); b = __half2float(__ushort_as_half(q.b));
+}
+
+// VR.py:173-189: 8 gathers, lerp order x -> y -> z. When one axis of the volume is contiguous (stride 1: z for a field-order tensor,
+// x for the reference's (1, D, H, W) layout seen through Raycaster) the cell's corners come in four neighbour PAIRS: four loads
+// instead of eight -- a wave-wide gather costs the texture-address path ~25 cycles whatever its width, and the per-ray kernels
+// (ray_cross_kernel: 72 % of its time there at sampling rate 8) are bound by exactly that. Same voxels, same lerps, same bits.
 template <typename VT>
 __device__ __forceinline__ float tri_sample(const VolView<VT> &v, float px, float py, float pz) {
     Cell c;
     tri_cell(v, px, py, pz, c);
+    if (v.sx == 1 && c.x1 == c.x0 + 1) {   // (uniform stride test; the high index is only clamped for positions tri_cell never produces)
+        const VT *b0 = v.p + c.x0 + c.y0 * v.sy, *b1 = v.p + c.x0 + c.y1 * v.sy;
+        const int64_t o0 = c.z0 * v.sz, o1 = c.z1 * v.sz;
+        float v000, v100, v010, v110, v001, v101, v011, v111;
+        ld_voxel_pair(b0 + o0, v000, v100); ld_voxel_pair(b1 + o0, v010, v110);
+        ld_voxel_pair(b0 + o1, v001, v101); ld_voxel_pair(b1 + o1, v011, v111);
+        const float zl = mixf(mixf(v000, v100, c.fx), mixf(v010, v110, c.fx), c.fy);
+        const float zh = mixf(mixf(v001, v101, c.fx), mixf(v011, v111, c.fx), c.fy);
+        return mixf(zl, zh, c.fz);
+    }
+    if (v.sz == 1 && c.z1 == c.z0 + 1) {
+        const VT *b00 = v.p + c.x0 * v.sx + c.y0 * v.sy + c.z0, *b10 = v.p + c.x1 * v.sx + c.y0 * v.sy + c.z0;
+        const VT *b01 = v.p + c.x0 * v.sx + c.y1 * v.sy + c.z0, *b11 = v.p + c.x1 * v.sx + c.y1 * v.sy + c.z0;
+        float v000, v001, v100, v101, v010, v011, v110, v111;
+        ld_voxel_pair(b00, v000, v001); ld_voxel_pair(b10, v100, v101);
+        ld_voxel_pair(b01, v010, v011); ld_voxel_pair(b11, v110, v111);
+        const float zl = mixf(mixf(v000, v100, c.fx), mixf(v010, v110, c.fx), c.fy);
+        const float zh = mixf(mixf(v001, v101, c.fx), mixf(v011, v111, c.fx), c.fy);
+        return mixf(zl, zh, c.fz);
+    }
     const VT *b00 = v.p + c.x0 * v.sx + c.y0 * v.sy, *b10 = v.p + c.x1 * v.sx + c.y0 * v.sy;
     const VT *b01 = v.p + c.x0 * v.sx + c.y1 * v.sy, *b11 = v.p + c.x1 * v.sx + c.y1 * v.sy;
     int64_t o0 = c.z0 * v.sz, o1 = c.z1 * v.sz;
