@@ -226,7 +226,9 @@ __device__ __forceinline__ float cross_opacity(const BrickParams<VT> &P, const V
     Sample sm;
     sm.a = 0.0f;
     if (sl < nmarch) {
-        sample_pos(rg, cam.x, cam.y, cam.z, sl, sm.px, sm.py, sm.pz);
+        // (the quotient s / (n - 1) from the ray's reciprocal: the correctly rounded quotient in three instructions instead of the
+        //  division's twelve -- sample_pos_rcp, as in the brick kernels; rg.inv_nm1 is set where the ray is loaded)
+        sample_pos_rcp(rg.t0, rg.exit_, (float)(rg.n - 1), rg.inv_nm1, rg.vx, rg.vy, rg.vz, cam.x, cam.y, cam.z, sl, sm.px, sm.py, sm.pz);
         sm.I = tri_sample(vol, sm.px, sm.py, sm.pz);
         tf_lookup_from_I(lds_tf, P.R, P.tf_len, sm);
     }
@@ -334,6 +336,7 @@ __global__ __launch_bounds__(256) void ray_cross_kernel(BrickParams<VT> P) {
         RayGeom rg;
         load_ray(P.entry, P.exit_, P.rays, P.nsamp, p, rg);
         if (flag != -1) continue;  // wave-uniform: no crossing to resolve
+        rg.inv_nm1 = 1.0f / (float)(rg.n - 1);   // (n >= 2: a crossing ray is regular)
         const int nmarch = (MODE == DR_MODE_DIFF && rg.n > P.S) ? P.S : rg.n;
         float A = parked.x, A_prev = A;
         int s = __float_as_int(parked.y);
@@ -400,6 +403,7 @@ __global__ __launch_bounds__(256) void ray_cross_quad_kernel(BrickParams<VT> P) 
         const float4 parked = reinterpret_cast<const float4 *>(P.out)[p];
         RayGeom rg;
         load_ray(P.entry, P.exit_, P.rays, P.nsamp, p, rg);
+        rg.inv_nm1 = 1.0f / (float)max(rg.n - 1, 1);
         const bool act = in && flag == -1;  // row-uniform
         const unsigned long long actm = __ballot(act);
         if (actm == 0ull) continue;  // wave-uniform: none of the four rays crosses
@@ -442,7 +446,7 @@ __global__ __launch_bounds__(256) void ray_cross_quad_kernel(BrickParams<VT> P) 
                 RayGeom ru;
                 ru.entry = __shfl(rg.entry, 16 * r); ru.exit_ = __shfl(rg.exit_, 16 * r);
                 ru.vx = __shfl(rg.vx, 16 * r); ru.vy = __shfl(rg.vy, 16 * r); ru.vz = __shfl(rg.vz, 16 * r);
-                ru.n = __shfl(rg.n, 16 * r); ru.t0 = __shfl(rg.t0, 16 * r); ru.inv_nm1 = 0.0f;
+                ru.n = __shfl(rg.n, 16 * r); ru.t0 = __shfl(rg.t0, 16 * r); ru.inv_nm1 = __shfl(rg.inv_nm1, 16 * r);
                 const int nm_u = __shfl(nmarch, 16 * r);
                 const int s_u = cross_exact_walk<VT, MODE>(P, vol, lds_tf, ru, cam, nm_u, lane);
                 if (row == r) s = s_u;
