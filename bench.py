@@ -342,6 +342,36 @@ def traffic_bytes(pm, want_bwd_kernel):
     return None
 
 
+def roofline_entry(name, ms, bytes_per_step, marched_per_launch, evaluated, key):
+    """One `roofline*` object of the bench line. `achieved` / `frac` price the ALGORITHMIC bytes of the samples the
+    kernel really EVALUATED: evaluated[key] / evaluated['marched'] of the marched count when the counting step ran (brick
+    kernels), the marched count otherwise. A fraction above 1 would mean the numerator prices work the kernel did not do: it is
+    refused (null + the reason), never printed. `bound` is None until counters of THIS run name it (observed_bound)."""
+    ratio, kind = 1.0, "model: algorithmic bytes of the marched samples / time / HBM peak"
+    if evaluated is not None and evaluated.get(key) is not None and evaluated.get("marched"):
+        ratio = evaluated[key] / evaluated["marched"]
+        kind = "model: algorithmic bytes of the EVALUATED samples / time / HBM peak"
+        if ratio < 0.98:
+            kind += f" (work-skipping active: {ratio:.3f} of the marched samples were evaluated)"
+    per_launch = marched_per_launch * ratio
+    ach = per_launch * bytes_per_step / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    frac = ach / HBM_PEAK_GBS
+    entry = {"kernel": name, "bound": None, "model_bound": "hbm",
+             "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(frac, 5), "frac_kind": kind,
+             "traffic": None, "hbm_gbs_measured": None, "hbm_frac_measured": None,
+             "avg_launch_ms": round(ms, 4), "bytes_per_voxel_step": bytes_per_step,
+             "voxel_steps_per_launch": int(marched_per_launch),
+             "evaluated_voxel_steps_per_launch": int(per_launch),
+             "note": "achieved/frac price the ALGORITHMIC bytes (model); hbm_gbs_measured = traffic / avg_launch is what "
+                     "the memory-side counters saw; bound: from the counters of this run, else null (unmeasured)"}
+    if frac > 1.0:
+        entry["achieved"] = entry["frac"] = None
+        entry["frac_refused"] = (f"{frac:.2f} > 1: the timed launches did not do the work the numerator prices "
+                                 "(samples skipped that the count still holds)")
+    return entry
+
+
 def allreduce_model(nbytes, world):
     """SURVEY section 5 cost model of the gradient all-reduce over xGMI (7 links x ~153 GB/s per GPU, point to point):
     a single ring is bound by one link, 2 (G-1)/G S / 153 GB/s; with all links in use (direct reduce-scatter + all-gather,
@@ -469,7 +499,10 @@ def main():
                              for k in range(nstep_total)], dtype=torch.float32, device=dev)
     reducer = GradientReducer()
 
-    def step(k, timed):
+    def step(k, timed, sync_grads=False, count=False):
+        """One pass of the hot path. sync_grads: the gradient all-reduce is AWAITED before the step ends (what an optimisation
+        loop needs: backward -> optimiser step -> next forward, examples/test_opt_tf.py:73-86) instead of overlapping the next
+        step's forward. count: measurement only -- the brick kernels count the samples they evaluate (DR_COUNT_EVALUATED)."""
         cam = cams_all[k]
         e, x, r, n = F.ray_setup(cam, (ROWS, IMG), (N, N, N), sr, rows=rows_arg, jitter_seed=(42 if args.jitter else 0),
                                  view_base=k * V)
@@ -477,7 +510,7 @@ def main():
         a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a0.record()
         out, steps = F.march_fwd(vol, tf, cam, e, x, r, n, S, sr, variant=args.variant, workspace=ws, rows=rows_arg,
-                                 hints=("auto" if args.hints == "auto" else 0))
+                                 hints=(F.N.DR_COUNT_EVALUATED if count else ("auto" if args.hints == "auto" else 0)))
         a1.record()
         if timed:
             ev["fwd"].append((a0, a1))
@@ -487,7 +520,7 @@ def main():
             b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             b0.record()
             dv, dt = F.march_bwd(vol, tf, cam, e, x, r, n, S, sr, grad_out, out, want_vol=want_vol, want_tf=want_tf,
-                                 variant=args.variant, workspace=ws, rows=rows_arg)
+                                 variant=args.variant, workspace=ws, rows=rows_arg, count_evaluated=count)
             b1.record()
             if timed:
                 ev["bwd"].append((b0, b1))
@@ -495,8 +528,12 @@ def main():
                 # RCCL sum of the shared gradients on its own stream: it overlaps the next step's forward; the
                 # previous step's reduction is awaited first so at most one is in flight (and all before timing ends)
                 reducer.submit([dv, dt])
+                if sync_grads:
+                    reducer.wait()   # the reduced gradient is in hand before the next step starts
         if timed:
             total_steps.add_(steps.sum()); planned_steps.add_(n.sum())
+        elif count:
+            return int(steps.sum().item())
         else:
             steps.sum(); n.sum()  # same launches as a timed step
         return dv, dt
@@ -517,6 +554,38 @@ def main():
         last = step(args.warmup + k, True)
     barrier()
     elapsed_local = time.perf_counter() - t0
+
+    # N > 1: the number an OPTIMISATION loop would see, next to the overlapped one -- the same steps once more with every
+    # step's gradient all-reduce awaited before the next forward starts (a throughput benchmark may hide the
+    # exchange behind the next forward, backward -> optimiser step -> next forward cannot)
+    ms_per_step_sync, sync_steps = None, 0
+    if dist is not None and want_bwd:
+        sync_steps = min(max(args.steps, 1), 10)
+        barrier()
+        ts = time.perf_counter()
+        for k in range(sync_steps):
+            step(args.warmup + k, False, sync_grads=True)
+        barrier()
+        el_sync = torch.tensor([time.perf_counter() - ts], dtype=torch.float64, device=dev)
+        dist.all_reduce(el_sync, op=dist.ReduceOp.MAX)
+        ms_per_step_sync = float(el_sync.item()) / sync_steps * 1e3
+
+    # Samples the brick kernels EVALUATED, against the samples marched (the reference's unit of work, VR.py:303): one untimed
+    # step under DR_COUNT_EVALUATED. The work-skipping paths (empty bricks, unlit segments) evaluate nothing for samples that
+    # still count as marched, and a roofline priced with the marched count would credit a kernel with bytes it never touched
+    # (profiles/r05_bench_lines.jsonl carried frac = 8.93 for a 0.34 ms backward).
+    evaluated = None
+    if ws is not None:
+        barrier()
+        try:
+            marched_one = step(args.warmup + max(args.steps, 1) - 1, False, count=True)
+            reducer.wait()
+            torch.cuda.synchronize()
+            ev_pre, ev_fwd, ev_bwd = F.evaluated_samples(ws)
+            evaluated = {"marched": marched_one, "alpha_prepass": ev_pre, "march_fwd": ev_fwd,
+                         "march_bwd": (ev_bwd if want_bwd else None)}
+        except RuntimeError as exc:   # (a library of an earlier round named by DIFFERENDER_HIP_LIB for an A/B run: no such flag)
+            print(f"[bench] no evaluated-sample count: {exc}", file=sys.stderr)
 
     # the exchange step on its own (not overlapped): K synchronous all-reduces of the gradient buffers
     allreduce_ms = None
@@ -571,10 +640,11 @@ def main():
         # every rank's workspace counters after its last step (functional.workspace_stats): rays repaired by the count check, rays
         # marched one by one, wrong "no early termination" hints, backward calls that did not find their forward's tape -- a
         # mis-sharded run (bands that do not match their buffers, a stale workspace) shows up here, in the one line the driver keeps
-        st_mine = (F.workspace_stats(ws)[:10].to(torch.int64).to(dev) if ws is not None else torch.zeros(10, dtype=torch.int64, device=dev))
+        st_mine = (F.workspace_stats(ws)[:16].to(torch.int64).to(dev) if ws is not None else torch.zeros(16, dtype=torch.int64, device=dev))
         st_all = [torch.zeros_like(st_mine) for _ in range(world)]
         dist.all_gather(st_all, st_mine)
         rank_counters = {"rays_repaired": [int(t[0]) for t in st_all], "rays_marched_individually": [int(t[2]) for t in st_all],
+                         "rays_recomputed_sequentially": [int(t[15]) for t in st_all],
                          "wrong_hint_views": [int(t[8]) for t in st_all], "stale_workspace_backwards": [int(t[9]) for t in st_all]}
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(total_steps, op=dist.ReduceOp.SUM)
@@ -593,22 +663,12 @@ def main():
     if rank != 0:
         return
 
-    def roof(name, ms, bytes_per_step):
-        ach = steps_per_launch * bytes_per_step / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        # `bound` is what the counters show once they are in (set below from roofline_valu); `frac` stays the MODEL fraction
-        # north_star prices this path with (algorithmic bytes / time / HBM peak) and says so in `frac_kind`
-        return {"kernel": name, "bound": "valu-issue (as profiled in profiles/; not re-measured in this run)", "model_bound": "hbm",
-                "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 5), "frac_kind": "model: algorithmic bytes / time / HBM peak",
-                "traffic": None, "hbm_gbs_measured": None, "hbm_frac_measured": None,
-                "avg_launch_ms": round(ms, 4), "bytes_per_voxel_step": bytes_per_step,
-                "voxel_steps_per_launch": int(steps_per_launch),
-                "note": "achieved/frac price the ALGORITHMIC bytes (model); hbm_gbs_measured = traffic / avg_launch is what "
-                        "the memory-side counters saw"}
+    def roof(name, ms, bytes_per_step, evaluated_key):
+        return roofline_entry(name, ms, bytes_per_step, steps_per_launch, evaluated, evaluated_key)
 
     b_fwd, b_bwd_vol, b_bwd_tf = algorithmic_bytes(args.vol_dtype)
-    roof_fwd = roof("march_fwd", fwd_ms, b_fwd)
-    roof_bwd = roof("march_bwd", bwd_ms, b_bwd_vol if want_vol else b_bwd_tf) if want_bwd else None
+    roof_fwd = roof("march_fwd", fwd_ms, b_fwd, "march_fwd")
+    roof_bwd = roof("march_bwd", bwd_ms, b_bwd_vol if want_vol else b_bwd_tf, "march_bwd") if want_bwd else None
 
     # roofline.traffic: HBM-side bytes per launch of the dominant kernels
     pm, traffic_source = None, None
@@ -661,6 +721,10 @@ def main():
                    "passes_per_voxel_step": passes, "kernel_variant": args.variant, "tf": args.tf, "scene": args.scene},
         "voxel_steps_per_step": int(vsteps / max(args.steps, 1)),
         "planned_steps_per_step": int(int(planned_steps.item()) / max(args.steps, 1)),  # executed/planned < 1 = early termination
+        "evaluated_voxel_steps": evaluated,   # one untimed step under DR_COUNT_EVALUATED: marched samples vs samples whose taps were evaluated
+        "ms_per_step_sync": None if ms_per_step_sync is None else round(ms_per_step_sync, 4),   # N > 1: every step's all-reduce awaited before the next forward
+        "sync_steps": sync_steps or None,
+        "build_flags": int(F.N.lib().dr_build_flags()),   # 0 = the shipped kernels; 4 = built without a tuned compiler flag (csrc/Makefile)
         "ms_per_step_ranks": [round(v, 4) for v in rank_ms],
         "phase_ms_ranks": rank_phase_ms,   # N > 1: per-rank forward time with / without the gradient all-reduce in flight, backward
         "workspace_counters_ranks": rank_counters,   # N > 1: per-rank fallback counters (all zero / a few single-sample rays when healthy)
@@ -674,6 +738,7 @@ def main():
         "traffic_source": traffic_source,
         "rays_marched_individually": (int(stats[2]) if stats is not None else None),
         "rays_repaired": (int(stats[0]) if stats is not None else None),
+        "rays_recomputed_sequentially": (int(stats[15]) if stats is not None else None),   # ray_exact_kernel
         "cpu_baseline": cpu_baseline,
     }
     emit(line)

@@ -16,6 +16,7 @@ DR_F32, DR_F16 = 0, 1
 DR_MODE_DIFF, DR_MODE_NONDIFF = 0, 1
 DR_VARIANT_AUTO, DR_VARIANT_BASELINE = 0, 1
 DR_HINT_NO_EARLY_TERMINATION, DR_HINT_EARLY_TERMINATION = 0x100, 0x200   # OR-ed into `variant` of dr_march_fwd[_rows]
+DR_COUNT_EVALUATED = 0x400   # ... and of dr_march_bwd[_rows]: measurement only (workspace header words 58-63)
 
 _c = ctypes
 _P, _I, _L, _F, _D, _U, _Z = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_double, _c.c_uint32, _c.c_size_t
@@ -59,17 +60,28 @@ def lib():
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C differender_amd/csrc`). differender_amd has no CPU or PyTorch fallback.")
         handle = ctypes.CDLL(LIB_PATH)
+        rebuild = "rebuild it (`make -C differender_amd/csrc`), or unset DIFFERENDER_HIP_LIB"
+        # the version FIRST: a stale library lacks newer symbols, and the loop over SIGNATURES below would die on the first of
+        # them with a bare AttributeError before the "ABI version ..., rebuild it" hint was ever reached
+        try:
+            handle.dr_abi_version.restype = ctypes.c_int
+            version = handle.dr_abi_version()
+        except AttributeError as exc:
+            raise ImportError(f"{LIB_PATH} does not export dr_abi_version: not this package's library; {rebuild}") from exc
+        if abs(version) != ABI_VERSION:
+            raise ImportError(f"{LIB_PATH}: ABI version {version}, expected {ABI_VERSION}; {rebuild}")
         for name, (res, args) in SIGNATURES.items():
-            fn = getattr(handle, name)
+            try:
+                fn = getattr(handle, name)
+            except AttributeError as exc:
+                raise ImportError(f"{LIB_PATH} reports ABI version {version} but does not export `{name}`; {rebuild}") from exc
             fn.restype = res
             fn.argtypes = args
-        version, flags = handle.dr_abi_version(), handle.dr_build_flags()
+        flags = handle.dr_build_flags()
         if (version < 0 or flags & BUILD_WRONG_RESULTS) and os.environ.get("DIFFERENDER_ALLOW_EXPERIMENT") != "1":
             raise ImportError(
                 f"{LIB_PATH} is a what-if build whose kernels compute WRONG results on purpose (dr_build_flags() = {flags}); "
                 "it is for timing experiments only. Set DIFFERENDER_ALLOW_EXPERIMENT=1 to load it anyway.")
-        if abs(version) != ABI_VERSION:
-            raise ImportError(f"{LIB_PATH}: ABI version {version}, expected {ABI_VERSION}; rebuild it")
         if flags & BUILD_WRONG_RESULTS:
             import warnings
             warnings.warn(f"{LIB_PATH}: what-if build, results are WRONG by construction", RuntimeWarning)

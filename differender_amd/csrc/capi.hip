@@ -129,7 +129,7 @@ int dr_march_fwd_rows(const void *vol, int vol_dtype, int VX, int VY, int VZ, in
     const int hints = variant & ~0xff;
     variant &= 0xff;
     if (variant < DR_VARIANT_AUTO || variant > DR_VARIANT_BASELINE) return DR_EINVAL;
-    if (hints & ~(DR_HINT_NO_EARLY_TERMINATION | DR_HINT_EARLY_TERMINATION)) return DR_EINVAL;
+    if (hints & ~(DR_HINT_NO_EARLY_TERMINATION | DR_HINT_EARLY_TERMINATION | DR_COUNT_EVALUATED)) return DR_EINVAL;
     if ((hints & DR_HINT_NO_EARLY_TERMINATION) && (hints & DR_HINT_EARLY_TERMINATION)) return DR_EINVAL;
     DeviceOf guard(vol);
     if (guard.err != hipSuccess) return (int)guard.err;
@@ -181,12 +181,15 @@ int dr_march_bwd_rows(const void *vol, int vol_dtype, int VX, int VY, int VZ, in
     if (!grad_out || !out_rgba) return DR_EINVAL;
     if (row0 < 0 || img_W < W || row0 > img_W - W) return DR_EINVAL;
     a.img_W = img_W; a.row0 = row0;
+    const int bwd_flags = variant & ~0xff;
+    variant &= 0xff;
+    if (bwd_flags & ~DR_COUNT_EVALUATED) return DR_EINVAL;
     if (variant < DR_VARIANT_AUTO || variant > DR_VARIANT_BASELINE) return DR_EINVAL;
     if (dtf_view_stride % 4 != 0) return DR_EINVAL;
     if (!d_vol && !d_tf) return 0;  // nothing requested
     DeviceOf guard(vol);
     if (guard.err != hipSuccess) return (int)guard.err;
-    a.mode = DR_MODE_DIFF;
+    a.mode = DR_MODE_DIFF; a.hints = bwd_flags;
     a.grad_out = grad_out; a.out_fwd = out_rgba;
     a.d_vol = d_vol; a.dsx = dsx; a.dsy = dsy; a.dsz = dsz; a.dvol_vs = dvol_view_stride;
     a.d_tf = d_tf; a.dtf_vs = dtf_view_stride;

@@ -26,11 +26,17 @@ struct BrickParams {
     float near_, near_w, near_h;
     BrickGrid g;
     float4 *seg_rgba;    // [view][NL][NP]: F1 partial composite, then (F2) prefix before the segment
-    uint16_t *seg_cnt;   // [view][NL][NP]: samples of the ray inside the brick of that layer (saturating at 65535: a
+    uint16_t *seg_cnt;   // [view][NL][NP]: samples of the ray inside the brick of that layer (low 15 bits, saturating at 32767: a
                          // longer in-brick run -- sampling rates in the thousands -- fails the count check and the
-                         // ray is marched whole)
+                         // ray is marched whole) | SEG_CNT_TINY
+    uint16_t *seg_tiny;  // [view][NL][NP]: how many of those samples have a TINY opacity (0 < op < DR_D4_TINY_OP); valid where seg_cnt
+                         // carries SEG_CNT_TINY (never cleared: read only under that flag)
     uint8_t *rayflag;    // [view][NP]: 1 = irregular ray (marched whole by F2 / B2)
     int32_t *ws_steps;   // [view][NP]: live samples per ray (F2 -> B1)
+    float4 *fin;         // [view][NP]: the ray's composite as F2 put it together from the partials (differentiable march): the backward's
+                         //   tape-free identity needs a final value that is CONSISTENT with the stored prefixes -- the image itself may
+                         //   have been recomputed sample by sample (ray_exact_kernel)
+    unsigned int *exact_list;  // [view * NP]: rays F2 sent to ray_exact_kernel (stats[ST_EXACT_RAYS] of them)
     unsigned long long *unlit;  // [view][lm_words][NP]: non-differentiable renders with an alpha pre-pass -- bit l of a ray's mask: the pre-pass
     int lm_words;               //   marched the ray's segment of layer l and found NO sample with alpha > 1e-3 (the colour march
                                 //   skips it: its count and its zero partial are already in place). 0: feature off (NL > 128).
@@ -44,6 +50,7 @@ struct BrickParams {
     int nondiff;         // forward: non-differentiable march (a sample composites only if alpha > 1e-3, VR.py:334; differentiable: if alpha != 0)
     int hint_noterm;     // forward: the caller said no ray can terminate early and the pre-pass was not launched; F2 checks
     int use_live;        // forward: ws_steps holds each ray's exact live sample count (from the alpha pre-pass)
+    int count_eval;      // DR_COUNT_EVALUATED: the brick kernels add their evaluated samples to stats[ST_EVAL_*] (measurement only)
     int pp_l0, pp_l1, pp_first;  // alpha pre-pass phase: brick layers [pp_l0, pp_l1); later phases skip terminated rays
     const struct BrickCtxRec *ctx;  // [view][brick]: brick geometry + pixel rectangle, filled once per forward call
     BrickItem *items;               // overflow work items of heavy bricks
@@ -69,11 +76,16 @@ enum {
     ST_EMPTY_BRICKS = 13,  // ... and (view, brick) workgroups (all passes) that took the empty-brick path: both SAMPLED, every 64th workgroup reports
     ST_MASKS = 14,         // forward (differentiable): words per ray of "unlit" layer masks it left behind seg_cnt (0: none) -- read by the
                            // d_volume-only backward
+    ST_EXACT_RAYS = 15,    // forward: rays whose image value was recomputed in the reference's sequential float32 order (ray_exact_kernel:
+                           // contributions of the size of an ulp of the running composite)
     ST_STALE_BWD = 9,      // backward calls that did not find their forward's fingerprint here and marched every ray one by one
     ST_F64_BRICKS = 4,     // backward: (view, brick) pairs whose d_volume box accumulated in double (wide local range of |grad_out|)
+    ST_EVAL_PRE = 58, ST_EVAL_FWD = 60, ST_EVAL_BWD = 62,   // DR_COUNT_EVALUATED: u64 each -- samples whose taps the alpha pre-pass / the colour march / the backward evaluated
     ST_TIMING = 16,        // DR_PHASE_TIMING: u64 x3 forward phases, u64 x3 backward phases, u64 backward lifetime
     ST_WORDS = 512         // header size in words (2 KiB)
 };
+
+constexpr int SEG_CNT_MAX = 0x7fff, SEG_CNT_TINY = 0x8000;   // seg_cnt: count | "seg_tiny holds a count"
 
 struct BrickCtx {
     int bx, by, bz, layer;        // layer: camera-based (pre-pass phases only; see dr_brick.h)
@@ -282,7 +294,7 @@ static __global__ __launch_bounds__(256) void brick_ctx_kernel(BrickParams<VT> P
                 const float lim = 1.0f + 1e-3f;
                 P.vflags[view] = flag;
                 P.vflags[P.n_views + view] = (fabsf(cx) <= lim && fabsf(cy) <= lim && fabsf(cz) <= lim) ? 1u : 0u;
-                if (view == 0) { P.stats[ST_REPAIR] = 0u; P.stats[ST_BASELINE_RAYS] = 0u; P.stats[ST_HINT_BAD] = 0u; P.stats[ST_STALE_BWD] = 0u; P.stats[ST_F64_BRICKS] = 0u; P.stats[ST_TICKET] = 0u; P.stats[ST_DONE] = 0u; P.stats[ST_TICKET_MAIN] = 0u; P.stats[ST_DONE_MAIN] = 0u; P.stats[ST_UNLIT_SKIPPED] = 0u; P.stats[ST_EMPTY_BRICKS] = 0u; P.stats[ST_MASKS] = P.nondiff ? 0u : (unsigned int)P.lm_words; P.stats[ST_MARK] = P.mark; }
+                if (view == 0) { P.stats[ST_REPAIR] = 0u; P.stats[ST_BASELINE_RAYS] = 0u; P.stats[ST_HINT_BAD] = 0u; P.stats[ST_STALE_BWD] = 0u; P.stats[ST_F64_BRICKS] = 0u; P.stats[ST_TICKET] = 0u; P.stats[ST_DONE] = 0u; P.stats[ST_TICKET_MAIN] = 0u; P.stats[ST_DONE_MAIN] = 0u; P.stats[ST_UNLIT_SKIPPED] = 0u; P.stats[ST_EMPTY_BRICKS] = 0u; P.stats[ST_EXACT_RAYS] = 0u; for (int k = ST_EVAL_PRE; k < ST_EVAL_PRE + 6; ++k) P.stats[k] = 0u; P.stats[ST_MASKS] = P.nondiff ? 0u : (unsigned int)P.lm_words; P.stats[ST_MARK] = P.mark; }
             }
         }
     }
@@ -337,6 +349,77 @@ __device__ __forceinline__ bool segment_range(const BrickCtx &c, f3 cam, f3 vd, 
     sa = fminf(fmaxf(sa, 0.0f), (float)nmarch); sb = fminf(fmaxf(sb, 0.0f), (float)nmarch);
     s0 = (int)sa; s1 = (int)sb;
     return s1 > s0;
+}
+
+// ---- Sequential float32 compositing and the partials ----------------------------------------------------------
+// The reference composites one sample at a time, C <- fma(T, c_s, C) (VR.py:300-302): each contribution is rounded to a whole
+// number of ulps of the running composite -- dropped altogether below half an ulp. While consecutive contributions stay alike to
+// within a fraction of an ulp they are rounded the SAME way, sample after sample, and the errors add up linearly (a transparent
+// range at alpha 1e-6 behind an opaque structure: 1e-8 onto 0.8, all dropped; 0.67 ulp each: every one rounded UP to a whole ulp);
+// contributions that drift through several ulps from sample to sample round this way and that, and that random walk is what the
+// 1e-5 bar (and the crossing search's 2e-6 band) already absorb. The brick kernels sum a segment's samples among themselves first
+// and reproduce none of this. The per-ray passes therefore BOUND |sequential - partials| along each ray, from two things:
+//   (1) the brick passes count, per (ray, layer) segment, its samples of TINY opacity, 0 < op < DR_D4_TINY_OP (seg_tiny; flag
+//       SEG_CNT_TINY in seg_cnt) -- the samples whose contributions can be of the size of an ulp at all (T >= 0.01 before a ray
+//       terminates, an ulp of a composite below 1 is 6e-8: op >= 1e-4 contributes 17 ulps and more). Each may be off by half
+//       an ulp of the running value, in every channel: tiny * ulp / 2 -- linearly from DR_D4_TINY_RUN such samples in a segment
+//       on (a stretch of like samples), in quadrature below that (the foot of a TF ramp: opacities that sweep up from 0 round this
+//       way and that). (Segments of 50-180 samples MIX such stretches with lit samples: their means say nothing -- the first
+//       design of this bound, which looked at means only, missed exactly those.)
+//   (2) the segment's MEAN contribution per sample and how far it moved over the ray's last three segments: a mean of at least half
+//       an ulp that stays put to within half an ulp (a flat region: constant intensity, ambient lighting) is rounded the same way
+//       throughout: min(contribution, samples * ulp / 2), added linearly like (1). Two segments alone do not count: along a smooth
+//       ray the contributions pass through extrema, where neighbouring segments share a mean while their samples still vary by
+//       many ulps. (A mean that DRIFTS leaves a sawtooth of roundings that cancels but for a partial cycle of random sign; charging
+//       those remainders was tried and flagged thousands of rays whose true error was below 1e-6 -- a segment's sample count says
+//       nothing about how many of its samples contribute at all: profiles/r06_ab_experiments.txt. They belong to the random walk.)
+//   (3) rays of more than DR_D4_LONG_RAY live samples: the random walk of the sequential roundings alone (0.29 ulp per sample,
+//       3 sigma of 12 000 samples of a composite near 1: 5.7e-6) leaves no room under the 1e-5 bar -- recomputed whatever (1) and (2) say.
+// An error in alpha also moves every later contribution: bound(alpha) * later partial (the callers add that). A ray whose bound
+// exceeds DR_D4_BUDGET has its pixel recomputed sample by sample (ray_exact_kernel); in the crossing search the bound widens the
+// band inside which the early-termination decision is repeated exactly.
+// Not covered: colour contributions below half an ulp from samples of ORDINARY opacity (a nearly black TF colour behind a bright
+// structure): their number is not known per segment, and a small mean alone cannot tell them from a sparse segment.
+#ifdef DR_D4_BUDGET_OVERRIDE   // (what-if builds: a huge budget switches the exact pass off -- marked in dr_experiment.h)
+#define DR_D4_BUDGET DR_D4_BUDGET_OVERRIDE
+#else
+#define DR_D4_BUDGET 3.0e-6f
+#endif
+#define DR_D4_TINY_OP 1.0e-4f
+#define DR_D4_TINY_RUN 16.0f
+#define DR_D4_LONG_RAY 12000
+__device__ __forceinline__ float ulp_of(float x) {   // spacing of the floats at |x| (0 below 2^-100: nothing to lose there)
+    const unsigned int e = __float_as_uint(x) & 0x7f800000u;
+    return e > (27u << 23) ? __uint_as_float(e - (23u << 23)) : 0.0f;
+}
+// One channel's running bound: `lin` adds up linearly, `sq` is a sum of squares.
+struct D4Bound {
+    float lin, sq, mprev, dprev;   // mprev: the mean contribution per sample of the ray's previous segment; dprev: how far THAT had moved
+    __device__ __forceinline__ float total() const { return lin + 2.0f * __builtin_amdgcn_sqrtf(sq); }
+};
+__device__ __forceinline__ D4Bound d4_zero() { D4Bound b; b.lin = b.sq = b.mprev = 0.0f; b.dprev = 3.0e38f; return b; }
+// `contrib` = T * partial of the channel over `cnt` samples (rcnt = 1 / cnt), `tiny` of them of tiny opacity, onto the running
+// value `pre`.
+__device__ __forceinline__ void d4_risk(float pre, float contrib, float cnt, float rcnt, float tiny, D4Bound &b) {
+    const float hu = 0.5f * ulp_of(pre), c = fabsf(contrib);
+    const float m = c * rcnt;
+    // drift of the mean: the LARGER of the last two differences -- along a smooth ray the contributions pass through extrema, where two
+    // neighbouring segments have the same mean by coincidence while the samples inside them still vary by many ulps; only a run of
+    // three segments alike (a flat region, a constant tiny alpha) is taken for contributions that are rounded alike
+    const float d1 = fabsf(m - b.mprev);
+    const float d = fmaxf(d1, b.dprev);
+    b.mprev = m; b.dprev = d1;
+    const float worst = fminf(c, cnt * hu);          // every sample off by half an ulp, or dropped
+    // steady: the mean stays put AND is itself at least half an ulp -- a smaller mean is either a run of tiny samples (counted
+    // by `tiny`) or a SPARSE segment, a few ordinary samples among many that contribute nothing (a thin shell, the skipped samples
+    // of a non-differentiable march): nothing is rounded alike there
+    const bool steady = !(d > hu) && m >= hu;
+    // (a handful of tiny samples in a segment is the foot of a TF ramp -- opacities that sweep from 0 upwards round this way and that:
+    //  charged in quadrature; from D4_TINY_RUN on they count as a stretch of like samples: linearly)
+    const float tq = tiny * hu;
+    const bool run = tiny >= DR_D4_TINY_RUN;
+    b.lin += fmaxf(run ? tq : 0.0f, steady ? worst : 0.0f);
+    b.sq = fmaf(run ? 0.0f : tq, tq, b.sq);
 }
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
@@ -573,6 +656,7 @@ static __global__ __launch_bounds__(256) void clear_counts_if_prepass_kernel(uin
 // ------------------------------------------------------------------------------------------------ host
 struct Workspace {
     float4 *seg_rgba; uint16_t *seg_cnt; int32_t *ws_steps; uint8_t *rayflag; unsigned int *stats, *vflags, *n_items;
+    float4 *fin; unsigned int *exact_list; uint16_t *seg_tiny;
     unsigned long long *unlit; size_t unlit_bytes; int lm_words;   // right behind seg_cnt: one memset clears the counts and the masks
     BrickCtxRec *ctx;
     BrickItem *items;
@@ -607,6 +691,12 @@ static inline size_t ws_layout(void *base, int n_views, int NP, const BrickGrid 
     o += (size_t)n_views * g.NBx * g.NBy * g.NBz * sizeof(BrickCtxRec);
     if (w) w->items = reinterpret_cast<BrickItem *>(b + o);
     o += (size_t)ITEM_CAP * sizeof(BrickItem);
+    if (w) w->fin = reinterpret_cast<float4 *>(b + o);
+    o += (size_t)n_views * NP * 16;
+    if (w) w->exact_list = reinterpret_cast<unsigned int *>(b + o);
+    o += align16((size_t)n_views * NP * 4);
+    if (w) w->seg_tiny = reinterpret_cast<uint16_t *>(b + o);
+    o += align16(nseg * 2);
     return o;
 }
 
@@ -630,8 +720,9 @@ static inline BrickParams<VT> make_brick_params(const MarchArgs &a, const Worksp
     P.near_ = (float)a.near_plane; P.near_h = (float)near_h; P.near_w = (float)(near_h * ((double)P.imgW / (double)a.H));
     P.g = make_brick_grid(a.VX, a.VY, a.VZ);
 
-    P.seg_rgba = w.seg_rgba; P.seg_cnt = w.seg_cnt; P.rayflag = w.rayflag; P.stats = w.stats; P.vflags = w.vflags; P.n_views = a.n_views; P.ws_steps = w.ws_steps; P.unlit = w.unlit; P.lm_words = 0;
+    P.seg_rgba = w.seg_rgba; P.seg_cnt = w.seg_cnt; P.rayflag = w.rayflag; P.stats = w.stats; P.vflags = w.vflags; P.n_views = a.n_views; P.ws_steps = w.ws_steps; P.fin = w.fin; P.exact_list = w.exact_list; P.seg_tiny = w.seg_tiny; P.unlit = w.unlit; P.lm_words = 0;
     P.hint_noterm = (a.hints & DR_HINT_NO_EARLY_TERMINATION) ? 1 : 0;
+    P.count_eval = (a.hints & DR_COUNT_EVALUATED) ? 1 : 0;
     P.nondiff = a.mode == DR_MODE_NONDIFF ? 1 : 0;
     P.use_live = a.use_live; P.ctx = w.ctx; P.items = w.items; P.n_items = w.n_items;
     P.mark = ws_fingerprint(a);

@@ -37,7 +37,7 @@ __device__ __forceinline__ bool tile_pixel(int W, int H, int &i, int &j) {
     return i < W && j < H;
 }
 
-// TF_LDS: the transfer function is staged in LDS (R <= 10240 entries = 160 KiB); a larger one is read where it lies, through the
+// TF_LDS: the transfer function is staged in LDS (R <= 10176 entries = 159 KiB: what a workgroup is really granted, less headroom); a larger one is read where it lies, through the
 // caches -- the reference has no limit on the TF resolution, and neither have the plain kernels.
 template <typename VT, int MODE, bool TF_LDS>
 __global__ __launch_bounds__(256) void march_fwd_baseline_kernel(MarchParams<VT> P) {
@@ -91,8 +91,8 @@ __global__ __launch_bounds__(256) void march_fwd_baseline_kernel(MarchParams<VT>
 __device__ __forceinline__ float finite_or_zero(float x) { return (x == x) ? fminf(fmaxf(x, -1.0e30f), 1.0e30f) : 0.0f; }
 
 // TABLES: what the workgroup keeps in LDS --
-//   2: [R] TF + [R][4] d_tf accumulators in double (48 R bytes: R <= 3413);
-//   1: the TF only; d_tf contributions go straight to the caller's tensor with float atomics (16 R bytes: R <= 10240; at such
+//   2: [R] TF + [R][4] d_tf accumulators in double (48 R bytes: R <= 3392);
+//   1: the TF only; d_tf contributions go straight to the caller's tensor with float atomics (16 R bytes: R <= 10176; at such
 //      resolutions a texel collects few samples of a workgroup, so the summation noise the double table exists for -- below -- is
 //      not a concern);
 //   0: nothing: the TF is read where it lies (any R; the reference has no limit on the TF resolution).
@@ -239,7 +239,10 @@ static hipError_t big_lds(K kernel, size_t bytes) {  // dynamic LDS above 64 KB 
     return allow_lds_impl(reinterpret_cast<const void *>(kernel), bytes);
 }
 
-constexpr size_t LDS_PER_CU = 160 * 1024;
+// What one workgroup may really ask for: the runtime does not grant a CU's full 160 KiB (163 232 B launched, 163 616 B did not:
+// tools/lds_limit_probe.py, round 5) -- 1 KiB of headroom, as brick_path_supported keeps. A table that does not fit drops to the
+// next tier instead of failing at launch (R = 3409 .. 3413 and 10 227 .. 10 240 picked a tier the launch refused).
+constexpr size_t LDS_PER_CU = 159 * 1024;
 static dim3 tile_grid(const MarchArgs &a) {
     const int tiles = ((a.W + 7) / 8) * ((a.H + 7) / 8);
     return dim3((tiles + 3) / 4, a.n_views);
@@ -248,7 +251,7 @@ static dim3 tile_grid(const MarchArgs &a) {
 template <typename VT>
 static int fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     size_t lds = (size_t)a.R * sizeof(float4);
-    const bool tf_lds = lds <= LDS_PER_CU;   // (R <= 10240; a larger TF is read from global memory)
+    const bool tf_lds = lds <= LDS_PER_CU;   // (R <= 10176; a larger TF is read from global memory)
     if (!tf_lds) lds = 0;
     MarchParams<VT> P = make_params<VT>(a);
 #define DR_FWD_BASE(MODE_, LDS_)                                                                                             \
@@ -268,7 +271,7 @@ int launch_march_fwd_baseline(const MarchArgs &a, hipStream_t stream) {
 
 template <typename VT>
 static int bwd_dispatch(const MarchArgs &a, hipStream_t stream) {
-    // TF + its double-precision gradient table in LDS while they fit (R <= 3413), then the TF alone (R <= 10240), then nothing
+    // TF + its double-precision gradient table in LDS while they fit (R <= 3392), then the TF alone (R <= 10176), then nothing
     const size_t lds2 = (size_t)a.R * (sizeof(float4) + 4 * sizeof(double)), lds1 = (size_t)a.R * sizeof(float4);
     const int tables = lds2 <= LDS_PER_CU ? 2 : (lds1 <= LDS_PER_CU ? 1 : 0);
     const size_t lds = tables == 2 ? lds2 : (tables == 1 ? lds1 : 0);

@@ -135,6 +135,9 @@ struct FlatCfg {
 };
 
 constexpr int VALID_LIT = 1 << 30;   // FlatLds::valid, alpha pre-pass of a non-differentiable render: a piece of the segment held a lit sample
+// FlatLds::valid packs two counters of a segment: bits 0-15 its in-brick samples, bits 16-29 those among them whose opacity is TINY
+// (0 < op < DR_D4_TINY_OP: dr_brick_common.h, "Sequential float32 compositing") -- one LDS atomic per piece adds both
+constexpr int VALID_CNT_MASK = 0xffff, VALID_TINY_SHIFT = 16, VALID_TINY_MASK = 0x3fff;
 struct FlatLds {
     float4 *tf; float *box; unsigned long long *dbox; unsigned long long *dtf;
     float4 *ray0;   // (t0, exit, (float)(n-1), RN(1/(n-1)))
@@ -994,6 +997,8 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
     const f3 light = make_f3(cam.x + 0.0f, cam.y + 1.0f, cam.z + 0.0f);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     bool any = false;
+    unsigned int n_eval = 0u;   // backward: samples this wave evaluated (wave-uniform; reported under DR_COUNT_EVALUATED)
+    unsigned int n_eval_lane = 0u;   // forward passes: the same from the segment counts (per lane: one entry each)
 
     for (int cbase = r_lo; cbase < r_hi; cbase += ROUND) {
         int nE = nE0, M = M0;
@@ -1065,7 +1070,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                 const int plq = __float_as_int(r1.w);
                 pf_pre = P.seg_rgba[seg_view + L.segi[e]];
                 pf_go = reinterpret_cast<const float4 *>(P.grad_out)[(size_t)view * NP + plq];
-                pf_of = reinterpret_cast<const float4 *>(P.out_fwd)[(size_t)view * NP + plq];
+                pf_of = P.fin[(size_t)view * NP + plq];   // (F2's own final composite, not the image: ray_exact_kernel may have rewritten that)
             }
             if (ALPHA) {
                 // alpha pre-pass: position, centre cell, one tap, TF -> transmittance; nothing else.
@@ -1073,11 +1078,14 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                 const int slen = L.slen[e];
                 float Tl = 1.0f;
                 int cnt_lane = 0;  // in-brick samples of this lane
+                unsigned long long tmask[KS];  // ... lanes whose sub-sample j has a tiny opacity (D4; rare: counted only where some lane has one)
                 bool lit_lane = false;  // some sample of this lane composites (alpha > 1e-3 / opacity != 0)
 #pragma unroll
                 for (int j = 0; j < KS; ++j) {
+                    tmask[j] = 0ull;
                     if (j >= ks) continue;  // uniform
                     Sample sa;
+                    bool tiny_j = false;
                     int x0 = 0, y0 = 0, z0 = 0;
                     float fx = 0.f, fy = 0.f, fz = 0.f;
                     bool va = act && (f + j - eoff) < slen;
@@ -1097,6 +1105,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                             // sample's intensity adjoint vanishes (it carries the factor a_hi - a_lo next to terms with the factor op)
                             lit_lane = lit_lane || opj != 0.0f || L.tfa[sa.lo] != 0.0f || L.tfa[sa.hi] != 0.0f;
                             Tl *= 1.0f - opj;
+                            tiny_j = opj != 0.0f && opj < DR_D4_TINY_OP;
                         }
                         ++cnt_lane;
                     }
@@ -1106,9 +1115,10 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                         const bool vis = va && sa.a > 1e-3f;
                         lit_lane = lit_lane || vis;
                         if (__any(vis)) {
-                            if (vis) Tl *= 1.0f - opacity_of_alpha(sa.a, P.inv_sr);
+                            if (vis) { const float opj = opacity_of_alpha(sa.a, P.inv_sr); Tl *= 1.0f - opj; tiny_j = opj < DR_D4_TINY_OP; }
                         }
                     }
+                    tmask[j] = __ballot(tiny_j);   // (wave-uniform: taken where the lanes have reconverged)
                 }
                 Tl = seg_scan_prod(Tl, lane, sl);
                 const int e_first = __builtin_amdgcn_readfirstlane(e);
@@ -1121,13 +1131,24 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                 }
                 const bool seg_end = act && (f + ks >= offs[e + 1]);
                 // in-brick samples of the piece [sl, lane]: inclusive lane-sum of the per-lane counts
-                float cf[1] = {(float)cnt_lane};
-                seg_scan_sum<1>(cf, lane, sl);
+                float cf[2] = {(float)cnt_lane, 0.0f};
+                unsigned long long tany = 0ull;
+#pragma unroll
+                for (int j = 0; j < KS; ++j) tany |= tmask[j];
+                if (tany != 0ull) {   // wave-uniform, rare: the pass holds samples of tiny opacity -- count them per segment as well
+#pragma unroll
+                    for (int j = 0; j < KS; ++j) cf[1] += (float)((tmask[j] >> lane) & 1ull);
+                    seg_scan_sum<2>(cf, lane, sl);
+                } else {
+                    float c1[1] = {cf[0]};
+                    seg_scan_sum<1>(c1, lane, sl);
+                    cf[0] = c1[0];
+                }
                 const bool piece_end = act && (seg_end || lane == 63 || f + ks >= fb);
                 // nondiff: does the piece [sl, lane] hold a lit sample? (bit VALID_LIT of the segment's counter collects the pieces)
                 const unsigned long long litm = __ballot(lit_lane);
                 if (piece_end) {
-                    const int cntp = (int)cf[0];
+                    const int cntp = (int)cf[0] + ((int)cf[1] << VALID_TINY_SHIFT);   // (the tiny count rides in the upper bits)
                     int before = cntp ? atomicAdd(&L.valid[e], cntp) : L.valid[e];
                     bool seg_lit = true;
                     {
@@ -1137,7 +1158,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                         if (piece_lit && !(before & VALID_LIT)) atomicOr(&L.valid[e], VALID_LIT);
                         before &= VALID_LIT - 1;
                     }
-                    if (seg_end && before + cntp > 0) {
+                    if (seg_end && ((before + cntp) & VALID_CNT_MASK) > 0) {
                         const int sgi = L.segi[e];
                         P.seg_rgba[seg_view + sgi] = make_float4(0.f, 0.f, 0.f, 1.0f - Tl);
                         {
@@ -1181,6 +1202,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                         vj = sample_coords_at(vol, c, sm, t);
                     }
                     Over2 ej = {0.f, 0.f};
+                    n_eval += (unsigned int)__popcll(__ballot(vj));
                     if (vj) {
                         float dx, dy, dz;
                         CentreLerps cl;
@@ -1290,6 +1312,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
             Over el = {0.f, 0.f, 0.f, 0.f};
             Over2 el2 = {0.f, 0.f};  // backward
             unsigned long long vm_fwd[KS];  // forward: which lanes hold an in-brick sample, per sub-sample
+            unsigned long long tm_fwd[KS];  // ... and a sample of tiny opacity (D4)
             // Lighting only matters where the sample has opacity: c = L*rgb*op is exactly 0 for op == 0 whatever L
             // is (the nondiff path skips alpha <= 1e-3 by definition, VR.py:334). Lanes are consecutive samples of a
             // ray, so empty stretches of the transfer function are wave-uniform: skip the six normal taps (48 of the
@@ -1323,14 +1346,19 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                         else { el.c0 = sm.L * sm.r * sm.op; el.c1 = sm.L * sm.g * sm.op; el.c2 = sm.L * sm.b * sm.op; el.a = sm.op; }
                     }
                 }
-                vm_fwd[0] = BWD ? 0ull : __ballot(valid);
+                {
+                    const unsigned long long vmask = __ballot(valid);
+                    if (BWD) n_eval += (unsigned int)__popcll(vmask);   // (the forward passes count from their segment counts, below)
+                    vm_fwd[0] = BWD ? 0ull : vmask;
+                    tm_fwd[0] = BWD ? 0ull : __ballot(lit && sm.op < DR_D4_TINY_OP);
+                }
             } else {
                 // forward, KS consecutive samples per lane: composited in registers, so that the cross-lane scan and
                 // the per-chunk bookkeeping below are paid once per KS*64 samples
                 const int slen = L.slen[e];
 #pragma unroll
                 for (int j = 0; j < KS; ++j) {
-                    if (j >= ks) { vm_fwd[j] = 0ull; continue; }  // uniform
+                    if (j >= ks) { vm_fwd[j] = 0ull; tm_fwd[j] = 0ull; continue; }  // uniform
                     const bool actj = act && (f + j - eoff) < slen;
                     bool vj = false;
                     if (actj) {
@@ -1354,6 +1382,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                         }
                     }
                     vm_fwd[j] = __ballot(vj);
+                    tm_fwd[j] = __ballot(lit && ej.a < DR_D4_TINY_OP);   // (ej.a = the opacity of a lit sample)
 #ifdef DR_LANE_STATS
                     if (lane == 0 && j < ks) {  // lane slots issued / holding a listed sample / holding an in-brick sample
                         atomicAdd(reinterpret_cast<unsigned long long *>(P.stats + ST_TIMING + 32), 64ull);
@@ -1390,16 +1419,23 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
             if (!BWD) {
                 // count the in-brick samples of each segment piece, store finished segments
                 const bool piece_end = act && (seg_end || lane == 63 || f + ks >= fb);
+                unsigned long long tany = 0ull;
+#pragma unroll
+                for (int j = 0; j < KS; ++j) tany |= tm_fwd[j];
                 if (piece_end) {
                     const unsigned long long below = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
                     const unsigned long long from = ~((1ull << sl) - 1ull);
                     int cntp = 0;
 #pragma unroll
                     for (int j = 0; j < KS; ++j) cntp += __popcll(vm_fwd[j] & below & from);
+                    if (tany != 0ull) {   // wave-uniform, rare
+#pragma unroll
+                        for (int j = 0; j < KS; ++j) cntp += __popcll(tm_fwd[j] & below & from) << VALID_TINY_SHIFT;
+                    }
                     const int before = cntp ? atomicAdd(&L.valid[e], cntp) : L.valid[e];
                     // a (ray, layer) slot belongs to the one brick that holds samples of the ray: a candidate
                     // segment without any in-brick sample must not touch it
-                    if (seg_end && before + cntp > 0)
+                    if (seg_end && ((before + cntp) & VALID_CNT_MASK) > 0)
                         P.seg_rgba[seg_view + L.segi[e]] = make_float4(inc.c0, inc.c1, inc.c2, inc.a);
                 }
             } else {
@@ -1527,12 +1563,25 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
             // sample counts of the segments this wave owns (only this wave added to them)
             bool some = false;
             for (int e = ea + lane; e < eb; e += 64) {
-                const int v = L.valid[e] & (VALID_LIT - 1);
-                if (v > 0) { P.seg_cnt[seg_view + L.segi[e]] = (uint16_t)min(v, 65535); some = true; }
+                const int vv = L.valid[e];
+                const int v = vv & VALID_CNT_MASK, tn = (vv >> VALID_TINY_SHIFT) & VALID_TINY_MASK;
+                // (15 bits of count -- a longer in-brick run fails F2's count check and the ray is marched whole -- and the flag "some of
+                //  them have a tiny opacity: their number is in seg_tiny")
+                if (v > 0) {
+                    P.seg_cnt[seg_view + L.segi[e]] = (uint16_t)(min(v, SEG_CNT_MAX) | (tn ? SEG_CNT_TINY : 0));
+                    if (tn) P.seg_tiny[seg_view + L.segi[e]] = (uint16_t)tn;
+                    some = true;
+                    if (!skip_loop) n_eval_lane += (unsigned int)v;   // (an empty brick's segments are counted, not evaluated)
+                }
             }
             if (!ALPHA && __any(some) && lane == 0)  // tell the backward that this brick holds live samples of the view
                 *live_flag = 1;
         }
+    }
+    if (P.count_eval) {   // uniform (measurement only: bench.py's evaluated_voxel_steps)
+        if (!BWD) { n_eval = n_eval_lane; for (int o = 32; o > 0; o >>= 1) n_eval += __shfl_xor(n_eval, o); }
+        if (n_eval != 0u && lane == 0)
+            atomicAdd(reinterpret_cast<unsigned long long *>(P.stats + (BWD ? ST_EVAL_BWD : (ALPHA ? ST_EVAL_PRE : ST_EVAL_FWD))), (unsigned long long)n_eval);
     }
 #if DR_PHASE_TIMING == 2
     if (BWD && lane == 0)  // sample-loop time of each of the workgroup's waves (slot = wave)
@@ -1857,7 +1906,9 @@ static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     else { if (k_hi) DR_LAUNCH_F1(DR_MODE_NONDIFF, DR_FWD_K_HI) else DR_LAUNCH_F1(DR_MODE_NONDIFF, DR_FWD_K) }
 #undef DR_LAUNCH_F1
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
-    return launch_ray_compose(b, stream);
+    const int rc3 = launch_ray_compose(b, stream);
+    if (rc3) return rc3;
+    return launch_ray_exact(b, stream);
 }
 
 hipError_t flat_invalidate_workspace(void *workspace, size_t workspace_bytes, hipStream_t stream) {

@@ -52,6 +52,7 @@ __global__ __launch_bounds__(256) void ray_compose_kernel(BrickParams<VT> P) {
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, A = 0.f;
     int steps = 0;
     uint8_t flag = 0;
+    bool want_exact = false;   // the pixel is recomputed sample by sample (ray_exact_kernel)
     if (pl == 0 && P.hint_noterm && P.vflags[view] != 0u) atomicAdd(&P.stats[ST_HINT_BAD], 1u);  // (see below)
     if (rg.n > 0) {
         VolView<VT> vol = P.vol;
@@ -81,6 +82,7 @@ __global__ __launch_bounds__(256) void ray_compose_kernel(BrickParams<VT> P) {
             // for. Safety net: the segments must account for every sample, else this ray is marched whole below.
             // (four layers per step, their loads issued together: the walk is a chain of memory latencies otherwise)
             int total = 0;
+            D4Bound b0 = d4_zero(), b1 = d4_zero(), b2 = d4_zero(), b3 = d4_zero();   // D4 bounds of the four channels (dr_brick_common.h)
 #ifndef DR_F2_WIDE
 #define DR_F2_WIDE 4   // layers per step of the walk
 #endif
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(256) void ray_compose_kernel(BrickParams<VT> P) {
                 int cnt[FW];
                 float4 sg[FW];
 #pragma unroll
-                for (int k = 0; k < FW; ++k) cnt[k] = (l + k <= l_hi) ? (int)P.seg_cnt[seg0 + (size_t)(l + k) * NP] : 0;
+                for (int k = 0; k < FW; ++k) cnt[k] = (l + k <= l_hi) ? (int)P.seg_cnt[seg0 + (size_t)(l + k) * NP] : 0;   // (count | SEG_CNT_TINY)
                 // (the partials are requested together with the counts, not after them: one memory round trip per step instead
                 // of two -- 80.5 -> 73.9 us at 512^2; nearly every layer between a ray's first and last brick holds samples, so
                 // little is read in vain. The kernel moves 330 MB in 74 us: it is HBM-bound, wider steps change nothing.)
@@ -99,8 +101,23 @@ __global__ __launch_bounds__(256) void ray_compose_kernel(BrickParams<VT> P) {
 #pragma unroll
                 for (int k = 0; k < FW; ++k) {
                     if (cnt[k] == 0) continue;
+                    // (samples of tiny opacity in this segment: rare -- a divergent load)
+                    const float tiny = (cnt[k] & SEG_CNT_TINY) ? (float)P.seg_tiny[seg0 + (size_t)(l + k) * NP] : 0.0f;
+                    cnt[k] &= SEG_CNT_MAX;
                     if (MODE == DR_MODE_DIFF) P.seg_rgba[seg0 + (size_t)(l + k) * NP] = make_float4(C0, C1, C2, A);  // prefix for the backward
                     const float T = 1.0f - A;
+                    // (D4: how far can the reference's sample-by-sample rounding have taken this segment from its partial? -- dr_brick_common.h;
+                    //  what the alpha bound so far does to this segment's colours first: d C_after / d A = -partial)
+                    const float cf = (float)cnt[k], rcf = __builtin_amdgcn_rcpf(cf);
+                    {
+                        const float ea = b3.total();
+                        b0.lin = fmaf(ea, fabsf(sg[k].x), b0.lin); b1.lin = fmaf(ea, fabsf(sg[k].y), b1.lin); b2.lin = fmaf(ea, fabsf(sg[k].z), b2.lin);
+                    }
+                    d4_risk(C0, T * sg[k].x, cf, rcf, tiny, b0); d4_risk(C1, T * sg[k].y, cf, rcf, tiny, b1);
+                    d4_risk(C2, T * sg[k].z, cf, rcf, tiny, b2); d4_risk(A, T * sg[k].w, cf, rcf, tiny, b3);
+#ifdef DR_D4_DEBUG   // (the pixel to trace: workspace header word ST_TIMING, set by tools/d4_terms_probe.py; -1 = none)
+                    if (pl == (int)P.stats[ST_TIMING] && view == 0) printf("l %d cnt %d tiny %g sg %g %g %g %g pre %g %g %g %g lin %g %g %g %g sq %g %g %g %g\n", l + k, cnt[k], tiny, sg[k].x, sg[k].y, sg[k].z, sg[k].w, C0, C1, C2, A, b0.lin, b1.lin, b2.lin, b3.lin, b0.sq, b1.sq, b2.sq, b3.sq);
+#endif
                     C0 = fmaf(T, sg[k].x, C0); C1 = fmaf(T, sg[k].y, C1); C2 = fmaf(T, sg[k].z, C2);
                     A = fmaf(T, sg[k].w, A);
                     total += cnt[k];
@@ -108,6 +125,20 @@ __global__ __launch_bounds__(256) void ray_compose_kernel(BrickParams<VT> P) {
             }
             steps = nmarch;
             if (total != nmarch) { regular = false; nmarch = nfull; atomicAdd(&P.stats[ST_REPAIR], 1u); }
+            else {
+                if (MODE == DR_MODE_DIFF) P.fin[p] = make_float4(C0, C1, C2, A);   // what the stored prefixes add up to: the backward's "final"
+                const float e0 = b0.total(), e1 = b1.total(), e2 = b2.total(), e3 = b3.total();
+                want_exact = fmaxf(fmaxf(e0, e1), fmaxf(e2, e3)) > DR_D4_BUDGET || nmarch > DR_D4_LONG_RAY;
+#ifdef DR_D4_DEBUG   // (tools/d4_bound_probe.py: the image holds the four bounds instead of the composite, nothing is recomputed)
+                want_exact = false;
+                {   // the channel with the largest bound: (linear part, quadrature part, total, channel)
+                    const D4Bound *bb[4] = {&b0, &b1, &b2, &b3};
+                    int km = 0;
+                    for (int q = 1; q < 4; ++q) if (bb[q]->total() > bb[km]->total()) km = q;
+                    C0 = bb[km]->lin; C1 = 2.0f * sqrtf(bb[km]->sq); C2 = bb[km]->total(); A = (float)km;
+                }
+#endif
+            }
         }
         if (!regular) {
             // single-sample rays (and repaired ones): the sequential march of the baseline kernels
@@ -138,6 +169,15 @@ __global__ __launch_bounds__(256) void ray_compose_kernel(BrickParams<VT> P) {
     if (P.steps) P.steps[p] = steps;
     P.ws_steps[p] = steps;
     P.rayflag[p] = flag;
+    // rays for ray_exact_kernel: one list for all views, one atomic per wave
+    const unsigned long long xm = __ballot(want_exact);
+    if (xm != 0ull) {   // wave-uniform
+        const int lane = threadIdx.x & 63;
+        unsigned int base = 0u;
+        if (lane == __ffsll((long long)xm) - 1) base = atomicAdd(&P.stats[ST_EXACT_RAYS], (unsigned int)__popcll(xm));
+        base = (unsigned int)__shfl((int)base, __ffsll((long long)xm) - 1);
+        if (want_exact) P.exact_list[base + (unsigned int)__popcll(xm & ((1ull << lane) - 1ull))] = (unsigned int)p;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ P2
@@ -164,8 +204,11 @@ __global__ __launch_bounds__(256) void ray_alpha_kernel(BrickParams<VT> P) {
         // state carried from phase to phase in the (not yet written) output buffer: alpha so far, samples so far
         float4 *park = reinterpret_cast<float4 *>(P.out) + p;
         float A = 0.f;
+        D4Bound bA = d4_zero();   // how far the reference's sequential alpha may be from this one (D4, dr_brick_common.h)
         int sacc = 0;
-        if (!P.pp_first) { const float4 st = *park; A = st.x; sacc = __float_as_int(st.y); }
+        // (between the phases of the pre-pass the bound travels as ONE number, its total so far: the quadrature part is folded in and
+        //  the drift history starts afresh -- a phase's first two segments are then not charged for standing still)
+        if (!P.pp_first) { const float4 st = *park; A = st.x; sacc = __float_as_int(st.y); bA.lin = st.z; }
         const size_t seg0 = (size_t)view * P.g.NL * NP + pl;
         const f3 cam = make_f3(P.cam[3 * view], P.cam[3 * view + 1], P.cam[3 * view + 2]);
         // this phase's bricks have camera-based layers [pp_l0, pp_l1); along a ray from a camera outside the volume
@@ -180,19 +223,25 @@ __global__ __launch_bounds__(256) void ray_alpha_kernel(BrickParams<VT> P) {
         }
         for (int l = l_lo; l <= l_hi; ++l) {
             const size_t si = seg0 + (size_t)l * NP;
-            const int cnt = P.seg_cnt[si];
+            const int c16 = P.seg_cnt[si];
+            const int cnt = c16 & SEG_CNT_MAX;
             if (cnt == 0) continue;
-            const float A_after = fmaf(1.0f - A, P.seg_rgba[si].w, A);
-            if (!(A_after < 0.99f - 1e-5f)) {  // the crossing segment (with a margin for the re-associated partials)
-                                              // starts at sample sacc: resolved by ray_cross_kernel
-                *park = make_float4(A, __int_as_float(sacc), 0.f, 0.f);
+            const float tiny = (c16 & SEG_CNT_TINY) ? (float)P.seg_tiny[si] : 0.0f;
+            const float sa = P.seg_rgba[si].w;
+            const float A_after = fmaf(1.0f - A, sa, A);
+            D4Bound b2 = bA;
+            d4_risk(A, (1.0f - A) * sa, (float)cnt, __builtin_amdgcn_rcpf((float)cnt), tiny, b2);
+            if (!(A_after < 0.99f - 1e-5f - b2.total())) {  // the crossing segment (with a margin for the re-associated partials and for what
+                                                           // sequential rounding may have done so far) starts at sample sacc: resolved by ray_cross_kernel
+                *park = make_float4(A, __int_as_float(sacc), bA.total(), 0.f);
                 P.ws_steps[p] = -1;
                 return;
             }
             A = A_after;
+            bA = b2;
             sacc += cnt;
         }
-        *park = make_float4(A, __int_as_float(sacc), 0.f, 0.f);
+        *park = make_float4(A, __int_as_float(sacc), bA.total(), 0.f);
     }
     if (P.pp_first) P.ws_steps[p] = nmarch;  // alive (so far): every planned sample is live
 }
@@ -339,12 +388,16 @@ __global__ __launch_bounds__(256) void ray_cross_kernel(BrickParams<VT> P) {
         rg.inv_nm1 = 1.0f / (float)(rg.n - 1);   // (n >= 2: a crossing ray is regular)
         const int nmarch = (MODE == DR_MODE_DIFF && rg.n > P.S) ? P.S : rg.n;
         float A = parked.x, A_prev = A;
+        // D4: bound on |sequential alpha - this one| up to the crossing segment (ray_alpha_kernel); from there on the samples of tiny
+        // opacity are counted pass by pass (each may be off by half an ulp of an alpha below 1: 3e-8)
+        int n_tiny = 0;
         int s = __float_as_int(parked.y);
         // ---- round 0: re-associated alphas of 64 samples per pass
         for (int base = s; base < nmarch && A < 0.99f; base += 64) {  // uniform
             const float op = cross_opacity<VT, MODE>(P, vol, lds_tf, rg, cam, nmarch, base + lane);
             // alpha after every sample of the pass: A_i = A + (1 - A) (1 - prod_{j <= i} (1 - op_j))
             const float Ai = fmaf(1.0f - A, 1.0f - wave_incl_prod(1.0f - op), A);
+            n_tiny += __popcll(__ballot(op != 0.0f && op < DR_D4_TINY_OP));   // uniform (scalar unit)
             const unsigned long long over = __ballot(!(Ai < 0.99f));
             if (over == 0ull) { A_prev = A = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Ai), 63)); s += min(64, nmarch - base); continue; }
             const int ix = __ffsll((long long)over) - 1;  // first sample at or above the threshold: the last live one
@@ -354,7 +407,8 @@ __global__ __launch_bounds__(256) void ray_cross_kernel(BrickParams<VT> P) {
             break;
         }
         // decided at A (>= 0.99, or the ray ran out of samples) with A_prev (< 0.99) before it
-        bool ambiguous = fabsf(A - 0.99f) < 2e-6f || fabsf(A_prev - 0.99f) < 2e-6f;
+        const float band = 2e-6f + parked.z + (float)n_tiny * 3.0e-8f;
+        bool ambiguous = fabsf(A - 0.99f) < band || fabsf(A_prev - 0.99f) < band;
 #ifdef DR_CROSS_STATS
         if (lane == 0) {  // diagnostics (tools/cross_stats.py): rays resolved, rays that needed the exact restart, samples walked
             atomicAdd(&P.stats[ST_TIMING + 16], 1u);
@@ -409,6 +463,7 @@ __global__ __launch_bounds__(256) void ray_cross_quad_kernel(BrickParams<VT> P) 
         if (actm == 0ull) continue;  // wave-uniform: none of the four rays crosses
         const int nmarch = (MODE == DR_MODE_DIFF && rg.n > P.S) ? P.S : rg.n;
         float A = parked.x, A_prev = A;
+        int n_tiny = 0;   // (D4: samples of tiny opacity seen by this row's search, as in ray_cross_kernel)
         int s = __float_as_int(parked.y);
         bool open = act;  // the row is still looking for its crossing
         // ---- round 0: re-associated alphas of 16 samples per ray and pass
@@ -418,17 +473,20 @@ __global__ __launch_bounds__(256) void ray_cross_quad_kernel(BrickParams<VT> P) 
             const float op = cross_opacity<VT, MODE>(P, vol, lds_tf, rg, cam, go ? nmarch : 0, s + rl);
             const float Ai = fmaf(1.0f - A, 1.0f - row_incl_prod(1.0f - op), A);
             const unsigned long long over = __ballot(go && !(Ai < 0.99f));
+            const unsigned long long tinym = __ballot(go && op != 0.0f && op < DR_D4_TINY_OP);
             const unsigned int m = (unsigned int)(over >> (16 * row)) & 0xffffu;
             const int ix = m ? __ffs((int)m) - 1 : 15;   // first sample of the row at or above the threshold (15: none -- the row's last)
             const float a_ix = __shfl(Ai, 16 * row + ix);
             const float a_before = __shfl(Ai, 16 * row + max(ix - 1, 0));
             if (go) {
+                n_tiny += __popc((unsigned int)(tinym >> (16 * row)) & 0xffffu);
                 if (m == 0u) { A_prev = A = a_ix; s += min(16, nmarch - s); }
                 else { A_prev = ix > 0 ? a_before : A; A = a_ix; s += ix + 1; open = false; }
             }
         }
         // decided at A (>= 0.99, or the ray ran out of samples) with A_prev (< 0.99) before it
-        bool ambiguous = act && (fabsf(A - 0.99f) < 2e-6f || fabsf(A_prev - 0.99f) < 2e-6f);
+        const float band = 2e-6f + parked.z + (float)n_tiny * 3.0e-8f;
+        bool ambiguous = act && (fabsf(A - 0.99f) < band || fabsf(A_prev - 0.99f) < band);
 #ifdef DR_CROSS_STATS
         if (act && rl == 0) {
             atomicAdd(&P.stats[ST_TIMING + 16], 1u);
@@ -453,6 +511,77 @@ __global__ __launch_bounds__(256) void ray_cross_quad_kernel(BrickParams<VT> P) 
             }
         }
         if (act && rl == 0) P.ws_steps[p] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ F3
+// The rays F2 listed (runs of contributions that sequential float32 rounding treats alike, where the reference's
+// sample-by-sample result and the partials part company): their pixels once more, in the reference's order --
+// tape[s] = (1 - tape[s-1].w) * shaded + tape[s-1], one rounding per sample and channel (VR.py:300-302) -- with the sequential
+// kernels' arithmetic bit for bit (classify / shade of dr_device.h: exact normalisations, taps from global memory). One
+// four-wave WORKGROUP per ray: 256 samples at a time are evaluated side by side and parked in LDS (two buffers), and the first
+// wave composites them one after the other while the others already evaluate the next 256 -- the chain (about 20 cycles per
+// sample: it cannot be parallelised, the roundings are the point) of one ray hides behind the evaluations of the other
+// workgroups of its CU. The ray's live sample count is F2's (exact: D3),
+// so no sample is evaluated in vain and no threshold is looked at. The transfer function is read where it lies (the list mixes
+// views). Only the image changes: sample counts, ray flags, the stored prefixes and `fin` stay -- the backward's tape-free
+// identity wants a final value consistent with its prefixes, and gets it from `fin`.
+// Two shapes, both launched, one of them leaves at once: up to EXACT_FEW rays are a matter of LATENCY (a ray of 3 500 samples in
+// 256-sample rounds takes 14 of them one after the other) and get 1024 threads each; more are a matter of throughput and get
+// four-wave workgroups, five to a CU.
+constexpr unsigned int EXACT_FEW = 768;
+template <typename VT, int MODE, int EXACT_NT>
+__global__ __launch_bounds__(EXACT_NT) void ray_exact_kernel(BrickParams<VT> P) {
+    __shared__ float4 park[2][EXACT_NT];
+    const unsigned int count = P.stats[ST_EXACT_RAYS];   // uniform
+    if (count == 0u || (count <= EXACT_FEW) != (EXACT_NT == 1024)) return;
+    const int NP = P.W * P.H;
+    const int wave = threadIdx.x >> 6;
+    for (unsigned int i = blockIdx.x; i < count; i += gridDim.x) {   // uniform
+        const size_t p = P.exact_list[i];
+        const int view = (int)(p / (size_t)NP);
+        const float4 *tfg = P.tf + view * P.tf_vs;
+        VolView<VT> vol = P.vol;
+        vol.p += view * P.vol_vs;
+        RayGeom rg;
+        load_ray(P.entry, P.exit_, P.rays, P.nsamp, p, rg);
+        const f3 cam = make_f3(P.cam[3 * view], P.cam[3 * view + 1], P.cam[3 * view + 2]);
+        const f3 light = make_f3(cam.x + 0.0f, cam.y + 1.0f, cam.z + 0.0f);
+        const f3 vd = make_f3(rg.vx, rg.vy, rg.vz);
+        const int nmarch = P.ws_steps[p];   // live samples (F2)
+        float C0 = 0.f, C1 = 0.f, C2 = 0.f, A = 0.f;   // (first wave)
+        int it = 0;
+        for (int base = 0; base < nmarch; base += EXACT_NT, ++it) {   // uniform
+            const int s = base + (int)threadIdx.x;
+            float4 c = make_float4(0.f, 0.f, 0.f, 0.f);   // (a sample the nondiff march skips leaves the composite as it is: fma(T, 0, C) == C)
+            if (s < nmarch) {
+                Sample sm;
+                sample_pos(rg, cam.x, cam.y, cam.z, s, sm.px, sm.py, sm.pz);
+                classify(vol, tfg, P.R, P.tf_len, P.inv_sr, sm);
+                if (MODE != DR_MODE_NONDIFF || sm.a > 1e-3f) {
+                    shade(vol, light, vd, MODE == DR_MODE_DIFF, sm);
+                    c = make_float4(sm.L * sm.r * sm.op, sm.L * sm.g * sm.op, sm.L * sm.b * sm.op, sm.op);
+                }
+            }
+            float4 *buf = park[it & 1];
+            buf[threadIdx.x] = c;
+            __syncthreads();   // (the buffer written two rounds ago is free again: the first wave finished with it before it got here)
+            if (wave == 0) {
+                // the sequential recurrence, one sample after the other: every lane reads the same LDS word (a broadcast) and
+                // carries the same composite -- one load, one subtraction and four fused multiply-adds per sample
+                const int cnt = min(EXACT_NT, nmarch - base);
+#pragma unroll 8
+                for (int k = 0; k < cnt; ++k) {   // uniform
+                    const float4 v = buf[k];
+                    const float T = 1.0f - A;
+                    C0 = fmaf(T, v.x, C0); C1 = fmaf(T, v.y, C1); C2 = fmaf(T, v.z, C2);
+                    A = fmaf(T, v.w, A);
+                }
+            }
+        }
+        if (MODE == DR_MODE_NONDIFF) { C0 = fminf(1.0f, C0); C1 = fminf(1.0f, C1); C2 = fminf(1.0f, C2); A = fminf(1.0f, A); }
+        if (threadIdx.x == 0) reinterpret_cast<float4 *>(P.out)[p] = make_float4(C0, C1, C2, A);
+        __syncthreads();   // the next ray starts in park[0] again
     }
 }
 
@@ -481,6 +610,30 @@ static int ray_compose_dispatch(const MarchArgs &a, hipStream_t stream) {
 
 int launch_ray_compose(const MarchArgs &a, hipStream_t stream) {
     return a.vol_dtype == DR_F16 ? ray_compose_dispatch<__half>(a, stream) : ray_compose_dispatch<float>(a, stream);
+}
+
+// F3: the rays F2 listed, if any -- a resident grid that reads the count from the workspace header and leaves at once when it is 0
+// (what every forward pays: one small launch)
+#ifndef DR_EXACT_GRID
+#define DR_EXACT_GRID 1280   // five four-wave workgroups per CU
+#endif
+template <typename VT>
+static int ray_exact_dispatch(const MarchArgs &a, hipStream_t stream) {
+    const BrickGrid g = make_brick_grid(a.VX, a.VY, a.VZ);
+    Workspace w;
+    ws_layout(a.workspace, a.n_views, a.W * a.H, g, &w);
+    BrickParams<VT> P = make_brick_params<VT>(a, w);
+    if (a.mode == DR_MODE_DIFF) {
+        hipLaunchKernelGGL((ray_exact_kernel<VT, DR_MODE_DIFF, 1024>), dim3(EXACT_FEW), dim3(1024), 0, stream, P);
+        hipLaunchKernelGGL((ray_exact_kernel<VT, DR_MODE_DIFF, 256>), dim3(DR_EXACT_GRID), dim3(256), 0, stream, P);
+    } else {
+        hipLaunchKernelGGL((ray_exact_kernel<VT, DR_MODE_NONDIFF, 1024>), dim3(EXACT_FEW), dim3(1024), 0, stream, P);
+        hipLaunchKernelGGL((ray_exact_kernel<VT, DR_MODE_NONDIFF, 256>), dim3(DR_EXACT_GRID), dim3(256), 0, stream, P);
+    }
+    return (int)hipGetLastError();
+}
+int launch_ray_exact(const MarchArgs &a, hipStream_t stream) {
+    return a.vol_dtype == DR_F16 ? ray_exact_dispatch<__half>(a, stream) : ray_exact_dispatch<float>(a, stream);
 }
 
 template <typename VT>

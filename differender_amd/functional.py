@@ -13,7 +13,7 @@ import torch
 
 from . import _native as N
 
-__all__ = ["ray_setup", "march_fwd", "march_bwd", "new_jitter_seed", "alloc_workspace", "workspace_stats",
+__all__ = ["ray_setup", "march_fwd", "march_bwd", "new_jitter_seed", "alloc_workspace", "workspace_stats", "evaluated_samples",
            "mse_loss_grad", "tf_momentum_step", "as_volume", "bwd_is_sanitised", "termination_hints"]
 
 
@@ -105,8 +105,18 @@ def workspace_stats(workspace):
     fingerprint in this workspace and marched every ray one by one, [3] = the forward's fingerprint (0: nobody's),
     [12] = (ray, layer) segments the colour march skipped because the alpha pre-pass had found them unlit, [13] = brick workgroups
     (of all forward passes) that took the empty-brick path -- both SAMPLED (every 64th workgroup reports), 0 when the mechanisms have
-    nothing to do."""
+    nothing to do; [15] = rays whose pixel was recomputed sample by sample in the reference's sequential float32 order
+    (ray_exact_kernel, DESIGN.md D4: runs of contributions of the size of an ulp of the running composite)."""
     return workspace[:64].view(torch.int32).cpu()
+
+
+def evaluated_samples(workspace):
+    """(alpha pre-pass, colour march, backward): samples whose taps the brick kernels actually EVALUATED in the calls that were
+    given DR_COUNT_EVALUATED (march_fwd(hints=... | N.DR_COUNT_EVALUATED), march_bwd(count_evaluated=True)) since the last forward
+    -- the work-skipping paths (empty bricks, unlit segments) evaluate nothing for samples that still count as marched. bench.py
+    prices its roofline with these, not with the marched count. Synchronises."""
+    w = workspace[58 * 4:64 * 4].view(torch.int64).cpu()
+    return int(w[0]), int(w[1]), int(w[2])
 
 
 def _ws_args(workspace):
@@ -330,10 +340,11 @@ def march_fwd(vol, tf, cam, entry, exit_, rays, n, max_samples, sampling_rate, m
 
 
 def march_bwd(vol, tf, cam, entry, exit_, rays, n, max_samples, sampling_rate, grad_out, out, want_vol=True,
-              want_tf=True, variant=N.DR_VARIANT_AUTO, fov_deg=30.0, near=0.1, workspace=None, rows=None):
+              want_tf=True, variant=N.DR_VARIANT_AUTO, fov_deg=30.0, near=0.1, workspace=None, rows=None, count_evaluated=False):
     """Adjoint of the differentiable march w.r.t. vol and tf (replaces raycast.grad, VR.py:460-461,470-471).
     Shared (un-batched) vol / tf receive one gradient accumulated over all views.
-    workspace: the buffer the matching march_fwd filled (fast path); None runs the baseline kernels."""
+    workspace: the buffer the matching march_fwd filled (fast path); None runs the baseline kernels.
+    count_evaluated: measurement only (DR_COUNT_EVALUATED; see evaluated_samples())."""
     _require_gpu(vol, "volume")
     V, W, H = n.shape
     cam = cam.to(torch.float32).contiguous()
@@ -358,7 +369,8 @@ def march_bwd(vol, tf, cam, entry, exit_, rays, n, max_samples, sampling_rate, g
     with torch.cuda.device(vol.device):
         rc = N.lib().dr_march_bwd_rows(*vargs, targs[0], targs[1], targs[2], cam.data_ptr(), entry.data_ptr(),
                                        exit_.data_ptr(), rays.data_ptr(), n.data_ptr(), V, W, H, int(max_samples),
-                                       float(sampling_rate), float(np.radians(fov_deg)), float(near), int(variant),
+                                       float(sampling_rate), float(np.radians(fov_deg)), float(near),
+                                       int(variant) | (N.DR_COUNT_EVALUATED if count_evaluated else 0),
                                        grad_out.data_ptr(), out.data_ptr(), *dv, *dt, *_ws_args(workspace),
                                        *_rows(rows, W), _stream())
     N.check(rc, "dr_march_bwd_rows")

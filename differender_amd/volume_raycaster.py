@@ -110,22 +110,26 @@ class VolumeRaycaster:
         self.last_stats = None         # workspace header of the most recent forward whose snapshot has arrived (int32 x32)
         self._warned_fallback = False
         self._warned_stale = False
-        self._reported_mark = None
+        self._fwd_seq, self._snap_seq, self._reported_seq = 0, 0, -1   # forwards issued / the one a snapshot shows / the one last reported
 
-    def _watch_workspace(self, workspace, n_rays):
+    def _watch_workspace(self, workspace, n_rays, forward=False):
         """Keeps an eye on the fast path's fallback counters without ever synchronising: a 128-byte snapshot of the
         workspace header is copied to pinned memory after a forward or a backward, and looked at when a LATER call finds it
         complete. Warns once if more than 1 % of the rays had to be marched one by one (single-sample rays or rays whose
         segments failed the count check: correct, but the 10-40x slower kernels)."""
+        if forward:
+            self._fwd_seq += 1
         if workspace is None:
             return
         if self._stats_event is not None and self._stats_event.query():
             self.last_stats = self._stats_host.clone()
             slow = int(self.last_stats[2])
-            # the device found a "no early termination" hint wrong: once per forward (its backward's snapshot shows the same
-            # header: same fingerprint in word 3), the TFs that were given the hint lose it for a while
-            if int(self.last_stats[8]) and int(self.last_stats[3]) != self._reported_mark:
-                self._reported_mark = int(self.last_stats[3])
+            # the device found a "no early termination" hint wrong: reported once per FORWARD (its backward's snapshot shows the
+            # same header). Keyed on a count of the forwards issued here, not on the header's fingerprint: a training loop renders
+            # the same volume into the same recycled buffers, so every iteration's fingerprint is the same and all wrong-hint
+            # reports after the first would be dropped (ADVICE r05)
+            if int(self.last_stats[8]) and self._snap_seq != self._reported_seq:
+                self._reported_seq = self._snap_seq
                 F._hints.report_wrong_hint()
             if int(self.last_stats[9]) and not self._warned_stale:
                 self._warned_stale = True
@@ -147,6 +151,7 @@ class VolumeRaycaster:
                 self._stats_event = torch.cuda.Event()
                 self._stats_event.record()
             self._stats_rays = int(n_rays)
+            self._snap_seq = self._fwd_seq
 
     def _field_shape(self, name):
         if name.startswith("volume"):
@@ -259,7 +264,7 @@ class RaycastFunction(torch.autograd.Function):
         ctx.workspace = ws  # coarse tape of the forward (per-segment prefixes), consumed by backward
         ctx.vr, ctx.sampling_rate, ctx.batched, ctx.jitter_seed = vr, sampling_rate, is_batched, seed
         vr._steps = steps if is_batched else steps[0]
-        vr._watch_workspace(ws, n.numel())
+        vr._watch_workspace(ws, n.numel(), forward=True)
         return out if is_batched else out[0]
 
     @staticmethod

@@ -49,8 +49,13 @@ enum { DR_VARIANT_AUTO = 0, DR_VARIANT_BASELINE = 1 };
  *       10-40 x slower) and workspace header word 8 counts the views it happened to.
  *   DR_HINT_EARLY_TERMINATION     "many rays terminate early": the alpha pre-pass runs front to back in groups of brick
  *       layers also below sampling rate 3, so that later groups skip the rays that are already opaque.
- * differender_amd.functional derives both from the TF tensor (largest alpha, cached per tensor version, no host sync). */
-enum { DR_HINT_NO_EARLY_TERMINATION = 0x100, DR_HINT_EARLY_TERMINATION = 0x200 };
+ * differender_amd.functional derives both from the TF tensor (largest alpha, cached per tensor version, no host sync).
+ *   DR_COUNT_EVALUATED (dr_march_fwd[_rows] AND dr_march_bwd[_rows]; measurement only, bench.py): the brick kernels add up the
+ *       samples whose taps they actually EVALUATED -- the work-skipping paths (empty bricks, unlit segments, dead samples behind a
+ *       termination point) evaluate nothing for samples that still count as marched -- in 64-bit words of the workspace header:
+ *       words 58/59 alpha pre-pass, 60/61 colour march (zeroed by the forward), 62/63 backward (accumulates until the next
+ *       forward). One atomic per wave: measurably slower on scenes with many short workgroups, so never set in a timed step. */
+enum { DR_HINT_NO_EARLY_TERMINATION = 0x100, DR_HINT_EARLY_TERMINATION = 0x200, DR_COUNT_EVALUATED = 0x400 };
 
 enum {
     DR_EINVAL = -1,      /* bad argument (null pointer, non-positive extent, unknown enum) */
@@ -63,7 +68,9 @@ enum {
  * loader that checks the version cannot take it for the product by accident. */
 int dr_abi_version(void);
 /* Bit mask of how this library was built: 0 = the shipped kernels; 1 = a what-if build with wrong results;
- * 2 = diagnostic instrumentation (per-phase clocks / counters in the workspace header; results unchanged, slower). */
+ * 2 = diagnostic instrumentation (per-phase clocks / counters in the workspace header; results unchanged, slower);
+ * 4 = built WITHOUT one of the two tuned -mllvm compiler flags because this compiler does not know it (csrc/Makefile's probe:
+ *     results unchanged, kernels a few per cent slower -- a bench line from such a build says so). */
 int dr_build_flags(void);
 const char *dr_error_string(int code);
 
@@ -85,7 +92,7 @@ int dr_ray_setup(const float *cam, int n_views, int W, int H, int VX, int VY, in
  * problem is only served by the baseline kernels (volume edge > 2000 voxels, or a TF of more than 2030 entries: the
  * brick kernels keep the TF, 16 B per entry, and its double-precision gradient table, 32 B per entry, in LDS beside the
  * brick). The baseline kernels have NO limit on the TF resolution (like the reference): they stage the TF and the
- * double-precision d_tf table in LDS up to 3413 entries, the TF alone up to 10240 (d_tf then accumulates with float
+ * double-precision d_tf table in LDS up to 3392 entries, the TF alone up to 10176 (d_tf then accumulates with float
  * atomics on the caller's tensor), and read a larger TF where it lies.
  * The caller allocates it (device memory, 256-byte aligned), passes it to dr_march_fwd and, unchanged,
  * to the dr_march_bwd of the same inputs: the forward leaves the per-segment composite prefixes and the

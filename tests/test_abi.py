@@ -153,3 +153,22 @@ def test_what_if_build_is_refused_by_the_loader(hiplib, tmp_path):
     assert r.returncode == 0 and "loaded 1" in r.stdout, r.stderr
     # the shipped library is clean
     assert hiplib.dr_abi_version() == 8 and hiplib.dr_build_flags() == 0
+
+
+def test_stale_library_raises_import_error_with_the_rebuild_hint(tmp_path):
+    """a library of an older ABI (or a foreign one named by DIFFERENDER_HIP_LIB) lacks newer symbols; the loader used to
+    die on the first of them with a bare AttributeError before its version check ran. It asks for the version first now, and every
+    failure on the way is an ImportError that says what to do."""
+    import subprocess
+    import sys
+    probe = "from differender_amd import _native as N; N.lib()"
+    for body, expect in (("int dr_abi_version(void) { return 7; }", "ABI version 7"),
+                         ("int something_else(void) { return 0; }", "does not export dr_abi_version"),
+                         ("int dr_abi_version(void) { return 8; }", "does not export `dr_build_flags`")):
+        src = tmp_path / "stale.c"
+        src.write_text(body + "\n")
+        so = str(tmp_path / "libstale.so")
+        subprocess.check_call(["gcc", "-shared", "-fPIC", "-o", so, str(src)])
+        r = subprocess.run([sys.executable, "-c", probe], env=dict(os.environ, DIFFERENDER_HIP_LIB=so, PYTHONPATH=ROOT),
+                           capture_output=True, text=True)
+        assert r.returncode != 0 and "ImportError" in r.stderr and expect in r.stderr and "rebuild it" in r.stderr, r.stderr

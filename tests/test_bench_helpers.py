@@ -83,3 +83,21 @@ def test_roofline_bound_is_named_from_the_counters():
     assert B.observed_bound(d["roofline_valu_bwd"], d["roofline_bwd"]["hbm_frac_measured"]) == "valu-issue+lds-atomics"
     idle = dict(d["roofline_valu_fwd"], issue_slot_utilisation=0.3, lds_array_busy=0.1)
     assert B.observed_bound(idle, 0.85) == "hbm" and B.observed_bound(idle, 0.2).startswith("latency")
+
+
+def test_roofline_entry_prices_evaluated_samples_and_refuses_fractions_above_one():
+    """a bench line must not claim work its kernels skipped. `frac` is priced with the samples the brick
+    kernels EVALUATED (one untimed counting step), says so in `frac_kind`, and a fraction above 1 is refused, not printed;
+    `bound` is null until counters of the same run name it (it used to assert a profile of another configuration)."""
+    B = _bench()
+    # the headline: every marched sample is evaluated (a few single-sample rays go through the per-ray fallback)
+    e = B.roofline_entry("march_bwd", 6.4, 96.0, 2.55e8, {"marched": 255029417, "march_fwd": 255029319, "march_bwd": 255029319}, "march_bwd")
+    assert e["bound"] is None and e["model_bound"] == "hbm"
+    assert abs(e["frac"] - 2.55e8 * 96 / 6.4e-3 / 1e9 / 8000.0) < 1e-3 and "EVALUATED" in e["frac_kind"] and "work-skipping" not in e["frac_kind"]
+    # CT-like scene, d_volume only: 0.34 ms for 9.5e7 marched samples of which 3 % were evaluated (r05 printed frac = 8.93 here)
+    e = B.roofline_entry("march_bwd", 0.34, 96.0, 9.5e7, {"marched": 95000000, "march_fwd": 40000000, "march_bwd": 2850000}, "march_bwd")
+    assert e["frac"] is not None and e["frac"] < 0.2 and "work-skipping active: 0.030" in e["frac_kind"]
+    assert e["evaluated_voxel_steps_per_launch"] == int(9.5e7 * 0.03) and e["voxel_steps_per_launch"] == int(9.5e7)
+    # no counting step (baseline kernels): the marched count, and the guard
+    e = B.roofline_entry("march_bwd", 0.34, 96.0, 2.55e8, None, "march_bwd")
+    assert e["frac"] is None and e["achieved"] is None and "> 1" in e["frac_refused"] and "marched" in e["frac_kind"]

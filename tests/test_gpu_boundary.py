@@ -313,6 +313,30 @@ def test_wrong_hint_reports_are_scoped_and_expire(oracle, hiplib):
     assert H._seen[H._key(tf_b)]["host"] is host0 and host0 is not None
 
 
+def test_every_wrong_hint_forward_is_reported(oracle, hiplib, monkeypatch):
+    """the wrong-hint report was de-duplicated on the workspace fingerprint, which a training loop repeats on every
+    iteration (same volume, recycled ray buffers) -- every report after the first was dropped and the distrust never escalated.
+    Keyed on the forwards issued by the raycaster now: N forwards under a wrong explicit hint make N reports (one each, although
+    the forward's and the backward's snapshots both show the flag), a clean forward in between makes none."""
+    from differender_amd import functional as Fn
+    from differender_amd.volume_raycaster import Raycaster
+    vol_h = oracle.synth_volume(32)
+    rc = Raycaster(vol_h.shape, (16, 16), 32, jitter=False, max_samples=4096)
+    vol = T(vol_h)[None].requires_grad_(True)
+    tf_opaque = T(oracle.bench_tf(32, 0.9))           # (R, 4): RaycastFunction's layout
+    lf = T(oracle.in_circles(0.3))
+    reports = []
+    monkeypatch.setattr(Fn._hints, "report_wrong_hint", lambda: reports.append(1) or 0)
+    from differender_amd.volume_raycaster import RaycastFunction
+    for it in range(4):
+        hint = Fn.N.DR_HINT_NO_EARLY_TERMINATION if it != 2 else 0     # iteration 2 renders without the (wrong) hint
+        out = RaycastFunction.apply(rc.vr, vol[0].permute(2, 0, 1), tf_opaque, lf, 1.0, (False, 0), False, hint)
+        out.sum().backward()
+        torch.cuda.synchronize()
+    rc.vr._watch_workspace(torch.empty(256, dtype=torch.uint8, device=vol.device), 1)   # collect the last snapshot
+    assert len(reports) == 3, reports
+
+
 def test_trainable_tf_is_read_on_first_sight(oracle, hiplib):
     """A TF that requires grad is a parameter somebody optimises: its largest alpha is read the first time it is seen (a plain
     tensor: the second time), so a training loop that rewrites it every iteration gets the harmless "many rays terminate" hint

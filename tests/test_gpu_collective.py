@@ -29,6 +29,32 @@ def test_one_rank_allreduce_through_the_c_abi(hiplib):
     N.check(hiplib.dr_comm_destroy(comm), "dr_comm_destroy")
 
 
+def test_single_process_init_all_with_one_device(hiplib):
+    """dr_comm_init_all -- ONE process driving N devices (ncclCommInitAll), the set-up SURVEY 8(e) names first -- had never
+    executed, not even with N = 1. One device: both spellings of the device list (NULL = devices 0..N-1, and an
+    explicit list), then the grouped gradient all-reduce on the communicator it returns."""
+    from differender_amd import _native as N
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    s = torch.cuda.current_stream().cuda_stream
+    for devices in (None, (ctypes.c_int * 1)(0)):
+        comms = (ctypes.c_void_p * 1)()
+        N.check(hiplib.dr_comm_init_all(comms, 1, devices), "dr_comm_init_all")
+        assert comms[0]
+        d_vol = torch.randn(40, 32, 24, device=dev)
+        d_tf = torch.randn(128, 4, device=dev)
+        want_vol, want_tf = d_vol.clone(), d_tf.clone()
+        N.check(hiplib.dr_allreduce_gradients_f32(comms[0], d_vol.data_ptr(), d_vol.numel(), d_tf.data_ptr(), d_tf.numel(), s),
+                "dr_allreduce_gradients_f32")
+        N.check(hiplib.dr_allreduce_gradients_f32(comms[0], None, 0, d_tf.data_ptr(), d_tf.numel(), s), "dr_allreduce_gradients_f32 (TF only)")
+        torch.cuda.synchronize()
+        assert torch.equal(d_vol, want_vol) and torch.equal(d_tf, want_tf)
+        N.check(hiplib.dr_comm_destroy(comms[0]), "dr_comm_destroy")
+    # argument errors are reported, not crashed on
+    assert hiplib.dr_comm_init_all(None, 1, None) != 0
+    assert hiplib.dr_comm_init_all((ctypes.c_void_p * 1)(), 0, None) != 0
+
+
 def test_calls_run_on_the_device_of_their_buffers(hiplib, oracle):
     """The library switches to the device that owns the buffers (and back): with one GPU this can only be checked for
     being harmless -- a render issued while another thread-local 'current device' state is in effect still matches."""

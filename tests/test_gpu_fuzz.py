@@ -62,3 +62,18 @@ def test_fuzz_block_of_fresh_seeds(fuzz):
     # The "ill-conditioned" branch of the fuzzer (a gradient judged against the baseline kernels' own distance from the
     # oracle instead of the flat 1e-4) must stay the exception: a regression must not be able to hide there.
     assert len(illcond) <= 0.02 * n, f"{len(illcond)} of {n} cases took the ill-conditioned branch: seeds {illcond}"
+
+
+def test_fuzz_block_under_the_d4_profile(fuzz, monkeypatch):
+    """FUZZ_PROFILE=d4 (transparent ranges at alpha 1e-6 around an opaque spike, sampling rates 2-8, every kind of volume): sub-ulp
+    contributions behind opaque structures. Until round 6 this profile had an escape hatch (up to 5e-5 from the float32 oracle
+    where float64 sided with the fast path); it is gone -- every case holds the ordinary bars, termination decisions included.
+    4000502 is the noise volume at rate 8 that sat at 1.09e-5."""
+    monkeypatch.setattr(fuzz, "PROFILE", "d4")
+    bad = []
+    for seed in [4000502] + list(range(4000000, 4000090)):
+        case = fuzz.make_case(seed)
+        fails = fuzz.run_case(case)
+        if fails:
+            bad.append((seed, fails, fuzz.describe(case)))
+    assert not bad, bad

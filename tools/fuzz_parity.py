@@ -72,8 +72,9 @@ def make_case(seed):
         tf[: R // 2, 3] = 0.0
         tf[rng.integers(R // 2, R), 3] = 0.95
     # PROFILE "d4" (round 5): transparent ranges at alpha 1e-6 instead of 0 around an opaque structure, rates >= 2 -- sub-ulp
-    # contributions behind opaque samples, which sequential float32 compositing drops and the brick kernels keep. Drawn
-    # from a generator of its own and only under that profile, so that the other fields of a seed stay what they were.
+    # contributions behind opaque samples, which sequential float32 compositing drops and the brick kernels' partials keep (DESIGN.md
+    # D4; since round 6 such rays are recomputed sample by sample). Drawn from a generator of its own and only under that profile, so
+    # that the other fields of a seed stay what they were.
     d4 = PROFILE == "d4" and R > 4
     if d4:
         r4 = np.random.default_rng(770000 + seed)
@@ -173,27 +174,10 @@ def run_case(c):
         ok = ~diff
         err = float(np.abs(out_h[v] - ref)[ok].max()) if ok.any() else 0.0
         if not err <= 1e-5:
-            d4_ok = False
-            if c.get("d4") and variant == 0 and err <= 5e-5:
-                # D4: beyond the bar, the same march in float64 must side with the fast path -- it is the closer of the two on at
-                # least nine such pixels in ten (where float32 and float64 take the same termination decision), and in the worst case
-                f8 = np.float64
-                r64, _ = O.march_fwd(vol_v[v].astype(f8), tf_v[v].astype(f8), cam_h[v].astype(f8), eh[v].astype(f8), xh[v].astype(f8),
-                                     rh[v].astype(f8), nh[v], S, sr, mode)
-                d = np.abs(out_h[v] - ref).max(-1)
-                chk = ok & (d > 1e-5) & (np.abs(ref - r64).max(-1) < 1e-4)
-                if chk.any():
-                    ef, e32 = np.abs(out_h[v] - r64).max(-1)[chk], np.abs(ref - r64).max(-1)[chk]
-                    d4_ok = (ef < e32).mean() >= 0.9 and ef.max() < e32.max()
-                    # ... or the two float32 evaluations differ by less than half of what the float32 oracle itself differs from
-                    # float64 on the image (noise volumes at rate 8: seed 4000502 -- 1.09e-5 against 3.6e-5)
-                    d4_ok = d4_ok or err <= 0.5 * float(np.abs(ref - r64)[ok].max())
-                else:
-                    d4_ok = True   # (every pixel beyond the bar sits on a termination decision float32 and float64 take differently)
-            if d4_ok:
-                c["_d4"] = True
-            else:
-                fails.append(f"forward error {err:.3e} (view {v})")
+            # (no excuse under any profile: until round 6 the "d4" profile let the fast path sit up to 5e-5 from the float32 oracle where
+            #  float64 sided with it -- the bar is the reference's sequential float32 result, and the per-ray passes now hold it:
+            #  d4_risk / ray_exact_kernel)
+            fails.append(f"forward error {err:.3e} (view {v})")
     if mode == 0:
         dv_ref = np.zeros(src.shape, np.float32); dt_ref = np.zeros_like(tf_h_dev)
         for v in range(c["n_views"]):
@@ -277,7 +261,7 @@ def run_case(c):
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    t0 = time.time(); n_run = 0; n_bad = 0; last = t0; n_undef = 0; n_ill = 0; n_d4 = 0
+    t0 = time.time(); n_run = 0; n_bad = 0; last = t0; n_undef = 0; n_ill = 0
     while time.time() - t0 < budget:
         c = make_case(seed)
         try:
@@ -287,12 +271,11 @@ def main():
         if fails:
             n_bad += 1
             print("FAIL seed", seed, fails, describe(c), flush=True)
-        n_run += 1; seed += 1; n_undef += bool(c.get("_undefined")); n_ill += bool(c.get("_illcond")); n_d4 += bool(c.get("_d4"))
+        n_run += 1; seed += 1; n_undef += bool(c.get("_undefined")); n_ill += bool(c.get("_illcond"))
         if time.time() - last > 30:
             last = time.time(); print(f"... {n_run} cases, {n_bad} failing, next seed {seed}", flush=True)
     print(f"fuzz done: {n_run} cases in {time.time() - t0:.0f} s, {n_bad} failing, seeds up to {seed - 1}; "
-          f"{n_undef} cases with an infinite reference gradient, {n_ill} ill-conditioned cases judged against the baseline kernels' noise"
-          + (f"; {n_d4} cases beyond the forward bar where float64 sides with the fast path (D4)" if n_d4 else ""))
+          f"{n_undef} cases with an infinite reference gradient, {n_ill} ill-conditioned cases judged against the baseline kernels' noise")
     sys.exit(1 if n_bad else 0)
 
 
