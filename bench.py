@@ -120,6 +120,7 @@ def parse_args(argv=None):
                          "convolutions outside the raycasting path. Default: MSE only, as every round measured the loop")
     ap.add_argument("--no-dssim", action="store_true", help="(default; kept for tools/abn_opt.sh)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tape", action="store_true", help="--grads tf: the brick-centric TF-only backward instead of the per-sample tape (DR_TAPE_TF)")
     ap.add_argument("--cpu-img", type=int, default=None,
                     help="image edge of the CPU-baseline sample (default: the whole view, capped at 512: ~20 s on 16 cores)")
     ap.add_argument("--pmc", default="auto", choices=["auto", "live", "off"],
@@ -484,7 +485,11 @@ def main():
     planned_steps = torch.zeros((), dtype=torch.int64, device=dev)  # sum of sample_step_nums (VR.py:259)
     ev = {"fwd": [], "bwd": []}
     # scratch of the brick-centric kernels (coarse tape); allocated once, reused by every step
-    ws = F.alloc_workspace(V, (ROWS, IMG), (N, N, N), R, dev) if args.variant == 0 else None
+    # C3 (--grads tf): the forward leaves a per-sample tape of (intensity, lighting), the TF-only backward is a per-ray pass over it
+    # (DR_TAPE_TF, csrc/tf_tape.hip) -- what RaycastFunction does when only the TF requires grad; --no-tape: the brick-centric backward
+    use_tape = want_tf and not want_vol and args.variant == 0 and not args.no_tape
+    ws = F.alloc_workspace(V, (ROWS, IMG), (N, N, N), R, dev, tape=(S, sr) if use_tape else None) if args.variant == 0 else None
+    use_tape = use_tape and ws is not None
 
     # all camera positions are uploaded before the timed region (a host->device copy inside the loop would
     # synchronise the stream every step)
@@ -510,7 +515,7 @@ def main():
         a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a0.record()
         out, steps = F.march_fwd(vol, tf, cam, e, x, r, n, S, sr, variant=args.variant, workspace=ws, rows=rows_arg,
-                                 hints=(F.N.DR_COUNT_EVALUATED if count else ("auto" if args.hints == "auto" else 0)))
+                                 hints=(F.N.DR_COUNT_EVALUATED if count else ("auto" if args.hints == "auto" else 0)), tape=use_tape)
         a1.record()
         if timed:
             ev["fwd"].append((a0, a1))
@@ -520,7 +525,7 @@ def main():
             b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             b0.record()
             dv, dt = F.march_bwd(vol, tf, cam, e, x, r, n, S, sr, grad_out, out, want_vol=want_vol, want_tf=want_tf,
-                                 variant=args.variant, workspace=ws, rows=rows_arg, count_evaluated=count)
+                                 variant=args.variant, workspace=ws, rows=rows_arg, count_evaluated=count, tape=use_tape)
             b1.record()
             if timed:
                 ev["bwd"].append((b0, b1))
@@ -582,6 +587,8 @@ def main():
             reducer.wait()
             torch.cuda.synchronize()
             ev_pre, ev_fwd, ev_bwd = F.evaluated_samples(ws)
+            if use_tape:
+                ev_bwd = marched_one   # (the pass over the tape evaluates every live sample, by construction; it keeps no counter)
             evaluated = {"marched": marched_one, "alpha_prepass": ev_pre, "march_fwd": ev_fwd,
                          "march_bwd": (ev_bwd if want_bwd else None)}
         except RuntimeError as exc:   # (a library of an earlier round named by DIFFERENDER_HIP_LIB for an A/B run: no such flag)
@@ -614,7 +621,7 @@ def main():
             a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a0.record()
             F.march_fwd(vol, tf, cam, e, x, r, n, S, sr, variant=args.variant, workspace=ws, rows=rows_arg,
-                        hints=("auto" if args.hints == "auto" else 0))
+                        hints=("auto" if args.hints == "auto" else 0), tape=use_tape)
             a1.record()
             pairs.append((a0, a1))
         barrier()
@@ -718,7 +725,8 @@ def main():
                                   (" + all-reduce(d_vol,d_tf)" if world > 1 else ""),
                    "backend": ({"nccl": "RCCL (nccl) over xGMI", "gloo": "gloo REHEARSAL: ranks share the card(s)"}.get(backend, backend)
                                if world > 1 else None),
-                   "passes_per_voxel_step": passes, "kernel_variant": args.variant, "tf": args.tf, "scene": args.scene},
+                   "passes_per_voxel_step": passes, "kernel_variant": args.variant, "tf": args.tf, "scene": args.scene,
+                   "tf_only_backward": (("per-sample tape (DR_TAPE_TF)" if use_tape else "brick-centric") if (want_tf and not want_vol) else None)},
         "voxel_steps_per_step": int(vsteps / max(args.steps, 1)),
         "planned_steps_per_step": int(int(planned_steps.item()) / max(args.steps, 1)),  # executed/planned < 1 = early termination
         "evaluated_voxel_steps": evaluated,   # one untimed step under DR_COUNT_EVALUATED: marched samples vs samples whose taps were evaluated

@@ -10,13 +10,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # (kernels that compute wrong results on purpose, csrc/dr_experiment.h) is refused unless DIFFERENDER_ALLOW_EXPERIMENT=1.
 LIB_PATH = os.environ.get("DIFFERENDER_HIP_LIB") or os.path.join(_HERE, "libdifferender_hip.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 BUILD_WRONG_RESULTS, BUILD_DIAGNOSTIC = 1, 2   # dr_build_flags()
 DR_F32, DR_F16 = 0, 1
 DR_MODE_DIFF, DR_MODE_NONDIFF = 0, 1
 DR_VARIANT_AUTO, DR_VARIANT_BASELINE = 0, 1
 DR_HINT_NO_EARLY_TERMINATION, DR_HINT_EARLY_TERMINATION = 0x100, 0x200   # OR-ed into `variant` of dr_march_fwd[_rows]
 DR_COUNT_EVALUATED = 0x400   # ... and of dr_march_bwd[_rows]: measurement only (workspace header words 58-63)
+DR_TAPE_TF = 0x800           # forward (DIFF) + the TF-only backward of the same inputs: per-sample tape of (intensity, lighting)
 
 _c = ctypes
 _P, _I, _L, _F, _D, _U, _Z = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_double, _c.c_uint32, _c.c_size_t
@@ -28,6 +29,7 @@ SIGNATURES = {
     "dr_error_string": (_c.c_char_p, [_I]),
     "dr_ray_setup": (_I, [_P, _I, _I, _I, _I, _I, _I, _D, _D, _F, _U, _U, _P, _P, _P, _P, _P]),
     "dr_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I, _I]),
+    "dr_workspace_bytes_tape": (_Z, [_I, _I, _I, _I, _I, _I, _I, _I, _F]),
     "dr_march_fwd": (_I, [_P, _I, _I, _I, _I, _L, _L, _L, _L, _P, _I, _L, _P, _P, _P, _P, _P,
                           _I, _I, _I, _I, _F, _D, _D, _I, _I, _P, _P, _P, _Z, _P]),
     "dr_march_bwd": (_I, [_P, _I, _I, _I, _I, _L, _L, _L, _L, _P, _I, _L, _P, _P, _P, _P, _P,

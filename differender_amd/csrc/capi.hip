@@ -74,6 +74,11 @@ size_t dr_workspace_bytes(int n_views, int W, int H, int VX, int VY, int VZ, int
     return brick_workspace_bytes(n_views, W, H, VX, VY, VZ);
 }
 
+size_t dr_workspace_bytes_tape(int n_views, int W, int H, int VX, int VY, int VZ, int R, int max_samples, float sampling_rate) {
+    if (dr_workspace_bytes(n_views, W, H, VX, VY, VZ, R) == 0 || max_samples < 0 || !(sampling_rate > 0.0f)) return 0;
+    return brick_workspace_bytes_tape(n_views, W, H, VX, VY, VZ, max_samples, sampling_rate);
+}
+
 int dr_ray_setup_rows(const float *cam, int n_views, int W, int H, int img_W, int row0, int VX, int VY, int VZ,
                       double fov_rad, double near_plane, float sampling_rate, uint32_t jitter_seed, uint32_t view_base,
                       float *entry, float *exit_, float *rays, int32_t *nsamp, void *stream) {
@@ -129,7 +134,8 @@ int dr_march_fwd_rows(const void *vol, int vol_dtype, int VX, int VY, int VZ, in
     const int hints = variant & ~0xff;
     variant &= 0xff;
     if (variant < DR_VARIANT_AUTO || variant > DR_VARIANT_BASELINE) return DR_EINVAL;
-    if (hints & ~(DR_HINT_NO_EARLY_TERMINATION | DR_HINT_EARLY_TERMINATION | DR_COUNT_EVALUATED)) return DR_EINVAL;
+    if (hints & ~(DR_HINT_NO_EARLY_TERMINATION | DR_HINT_EARLY_TERMINATION | DR_COUNT_EVALUATED | DR_TAPE_TF)) return DR_EINVAL;
+    if ((hints & DR_TAPE_TF) && mode != DR_MODE_DIFF) return DR_EINVAL;
     if ((hints & DR_HINT_NO_EARLY_TERMINATION) && (hints & DR_HINT_EARLY_TERMINATION)) return DR_EINVAL;
     DeviceOf guard(vol);
     if (guard.err != hipSuccess) return (int)guard.err;
@@ -137,7 +143,8 @@ int dr_march_fwd_rows(const void *vol, int vol_dtype, int VX, int VY, int VZ, in
     a.fov_rad = fov_rad; a.near_plane = near_plane; a.workspace = workspace; a.workspace_bytes = workspace_bytes;
     if (variant != DR_VARIANT_BASELINE && workspace && brick_path_supported(VX, VY, VZ, R) &&
         brick_image_supported(W, H, VX, VY, VZ)) {
-        if (workspace_bytes < brick_workspace_bytes(n_views, W, H, VX, VY, VZ)) return DR_EINVAL;
+        if (workspace_bytes < ((hints & DR_TAPE_TF) ? brick_workspace_bytes_tape(n_views, W, H, VX, VY, VZ, max_samples, sampling_rate)
+                                                    : brick_workspace_bytes(n_views, W, H, VX, VY, VZ))) return DR_EINVAL;
         if (flat_strides_ok(sx, sy, sz)) return launch_march_fwd_flat(a, (hipStream_t)stream);
     }
     // served by the plain kernels: whatever coarse tape the workspace still holds is not this call's
@@ -183,7 +190,8 @@ int dr_march_bwd_rows(const void *vol, int vol_dtype, int VX, int VY, int VZ, in
     a.img_W = img_W; a.row0 = row0;
     const int bwd_flags = variant & ~0xff;
     variant &= 0xff;
-    if (bwd_flags & ~DR_COUNT_EVALUATED) return DR_EINVAL;
+    if (bwd_flags & ~(DR_COUNT_EVALUATED | DR_TAPE_TF)) return DR_EINVAL;
+    if ((bwd_flags & DR_TAPE_TF) && d_vol) return DR_EINVAL;   // the tape serves the TF-only backward
     if (variant < DR_VARIANT_AUTO || variant > DR_VARIANT_BASELINE) return DR_EINVAL;
     if (dtf_view_stride % 4 != 0) return DR_EINVAL;
     if (!d_vol && !d_tf) return 0;  // nothing requested
@@ -196,7 +204,8 @@ int dr_march_bwd_rows(const void *vol, int vol_dtype, int VX, int VY, int VZ, in
     a.fov_rad = fov_rad; a.near_plane = near_plane; a.workspace = workspace; a.workspace_bytes = workspace_bytes;
     if (dr_march_bwd_variant(n_views, W, H, VX, VY, VZ, R, sx, sy, sz, dsx, dsy, dsz, d_vol != nullptr, variant,
                              workspace != nullptr) == DR_VARIANT_AUTO) {
-        if (workspace_bytes < brick_workspace_bytes(n_views, W, H, VX, VY, VZ)) return DR_EINVAL;
+        if (workspace_bytes < ((bwd_flags & DR_TAPE_TF) ? brick_workspace_bytes_tape(n_views, W, H, VX, VY, VZ, max_samples, sampling_rate)
+                                                        : brick_workspace_bytes(n_views, W, H, VX, VY, VZ))) return DR_EINVAL;
         return launch_march_bwd_flat(a, (hipStream_t)stream);
     }
     return launch_march_bwd_baseline(a, (hipStream_t)stream);

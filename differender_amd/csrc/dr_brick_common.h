@@ -37,6 +37,8 @@ struct BrickParams {
                          //   tape-free identity needs a final value that is CONSISTENT with the stored prefixes -- the image itself may
                          //   have been recomputed sample by sample (ray_exact_kernel)
     unsigned int *exact_list;  // [view * NP]: rays F2 sent to ray_exact_kernel (stats[ST_EXACT_RAYS] of them)
+    float2 *tape;        // DR_TAPE_TF: [view][NP][tape_stride] (intensity, lighting term) of every marched sample (forward -> tf_tape.hip)
+    int tape_stride;     //   samples reserved per ray (0: no tape)
     unsigned long long *unlit;  // [view][lm_words][NP]: non-differentiable renders with an alpha pre-pass -- bit l of a ray's mask: the pre-pass
     int lm_words;               //   marched the ray's segment of layer l and found NO sample with alpha > 1e-3 (the colour march
                                 //   skips it: its count and its zero partial are already in place). 0: feature off (NL > 128).
@@ -80,6 +82,7 @@ enum {
                            // contributions of the size of an ulp of the running composite)
     ST_STALE_BWD = 9,      // backward calls that did not find their forward's fingerprint here and marched every ray one by one
     ST_F64_BRICKS = 4,     // backward: (view, brick) pairs whose d_volume box accumulated in double (wide local range of |grad_out|)
+    ST_TAPE_STRIDE = 56,   // forward: samples per ray of the DR_TAPE_TF tape it left behind the workspace (0: none)
     ST_EVAL_PRE = 58, ST_EVAL_FWD = 60, ST_EVAL_BWD = 62,   // DR_COUNT_EVALUATED: u64 each -- samples whose taps the alpha pre-pass / the colour march / the backward evaluated
     ST_TIMING = 16,        // DR_PHASE_TIMING: u64 x3 forward phases, u64 x3 backward phases, u64 backward lifetime
     ST_WORDS = 512         // header size in words (2 KiB)
@@ -294,7 +297,7 @@ static __global__ __launch_bounds__(256) void brick_ctx_kernel(BrickParams<VT> P
                 const float lim = 1.0f + 1e-3f;
                 P.vflags[view] = flag;
                 P.vflags[P.n_views + view] = (fabsf(cx) <= lim && fabsf(cy) <= lim && fabsf(cz) <= lim) ? 1u : 0u;
-                if (view == 0) { P.stats[ST_REPAIR] = 0u; P.stats[ST_BASELINE_RAYS] = 0u; P.stats[ST_HINT_BAD] = 0u; P.stats[ST_STALE_BWD] = 0u; P.stats[ST_F64_BRICKS] = 0u; P.stats[ST_TICKET] = 0u; P.stats[ST_DONE] = 0u; P.stats[ST_TICKET_MAIN] = 0u; P.stats[ST_DONE_MAIN] = 0u; P.stats[ST_UNLIT_SKIPPED] = 0u; P.stats[ST_EMPTY_BRICKS] = 0u; P.stats[ST_EXACT_RAYS] = 0u; for (int k = ST_EVAL_PRE; k < ST_EVAL_PRE + 6; ++k) P.stats[k] = 0u; P.stats[ST_MASKS] = P.nondiff ? 0u : (unsigned int)P.lm_words; P.stats[ST_MARK] = P.mark; }
+                if (view == 0) { P.stats[ST_REPAIR] = 0u; P.stats[ST_BASELINE_RAYS] = 0u; P.stats[ST_HINT_BAD] = 0u; P.stats[ST_STALE_BWD] = 0u; P.stats[ST_F64_BRICKS] = 0u; P.stats[ST_TICKET] = 0u; P.stats[ST_DONE] = 0u; P.stats[ST_TICKET_MAIN] = 0u; P.stats[ST_DONE_MAIN] = 0u; P.stats[ST_UNLIT_SKIPPED] = 0u; P.stats[ST_EMPTY_BRICKS] = 0u; P.stats[ST_EXACT_RAYS] = 0u; P.stats[ST_TAPE_STRIDE] = P.tape ? (unsigned int)P.tape_stride : 0u; for (int k = ST_EVAL_PRE; k < ST_EVAL_PRE + 6; ++k) P.stats[k] = 0u; P.stats[ST_MASKS] = P.nondiff ? 0u : (unsigned int)P.lm_words; P.stats[ST_MARK] = P.mark; }
             }
         }
     }
@@ -656,13 +659,14 @@ static __global__ __launch_bounds__(256) void clear_counts_if_prepass_kernel(uin
 // ------------------------------------------------------------------------------------------------ host
 struct Workspace {
     float4 *seg_rgba; uint16_t *seg_cnt; int32_t *ws_steps; uint8_t *rayflag; unsigned int *stats, *vflags, *n_items;
-    float4 *fin; unsigned int *exact_list; uint16_t *seg_tiny;
+    float4 *fin; unsigned int *exact_list; uint16_t *seg_tiny; float2 *tape;
     unsigned long long *unlit; size_t unlit_bytes; int lm_words;   // right behind seg_cnt: one memset clears the counts and the masks
     BrickCtxRec *ctx;
     BrickItem *items;
     size_t cnt_bytes;
 };
-static inline size_t ws_layout(void *base, int n_views, int NP, const BrickGrid &g, Workspace *w) {
+// tape_stride > 0: the DR_TAPE_TF tape follows the ordinary workspace
+static inline size_t ws_layout(void *base, int n_views, int NP, const BrickGrid &g, Workspace *w, int tape_stride = 0) {
     size_t o = 0;
     const int NL = g.NL;
     const size_t nseg = (size_t)n_views * NL * NP;
@@ -697,6 +701,9 @@ static inline size_t ws_layout(void *base, int n_views, int NP, const BrickGrid 
     o += align16((size_t)n_views * NP * 4);
     if (w) w->seg_tiny = reinterpret_cast<uint16_t *>(b + o);
     o += align16(nseg * 2);
+    o = (o + 255) & ~(size_t)255;
+    if (w) w->tape = tape_stride > 0 ? reinterpret_cast<float2 *>(b + o) : nullptr;
+    o += (size_t)n_views * NP * (size_t)tape_stride * 8;
     return o;
 }
 
@@ -720,7 +727,7 @@ static inline BrickParams<VT> make_brick_params(const MarchArgs &a, const Worksp
     P.near_ = (float)a.near_plane; P.near_h = (float)near_h; P.near_w = (float)(near_h * ((double)P.imgW / (double)a.H));
     P.g = make_brick_grid(a.VX, a.VY, a.VZ);
 
-    P.seg_rgba = w.seg_rgba; P.seg_cnt = w.seg_cnt; P.rayflag = w.rayflag; P.stats = w.stats; P.vflags = w.vflags; P.n_views = a.n_views; P.ws_steps = w.ws_steps; P.fin = w.fin; P.exact_list = w.exact_list; P.seg_tiny = w.seg_tiny; P.unlit = w.unlit; P.lm_words = 0;
+    P.seg_rgba = w.seg_rgba; P.seg_cnt = w.seg_cnt; P.rayflag = w.rayflag; P.stats = w.stats; P.vflags = w.vflags; P.n_views = a.n_views; P.ws_steps = w.ws_steps; P.fin = w.fin; P.exact_list = w.exact_list; P.seg_tiny = w.seg_tiny; P.tape = nullptr; P.tape_stride = 0; P.unlit = w.unlit; P.lm_words = 0;
     P.hint_noterm = (a.hints & DR_HINT_NO_EARLY_TERMINATION) ? 1 : 0;
     P.count_eval = (a.hints & DR_COUNT_EVALUATED) ? 1 : 0;
     P.nondiff = a.mode == DR_MODE_NONDIFF ? 1 : 0;

@@ -24,6 +24,8 @@ struct MarchArgs {
     const uint8_t *only_flagged;  // baseline backward: restrict to rays with a non-zero flag (may be null)
     const unsigned int *ws_mark;  // ... unless *ws_mark != ws_mark_expect (the workspace is not this call's forward's: the
     unsigned int ws_mark_expect;  //     flags are garbage, every ray is marched); may be null
+    const unsigned int *ws_aux;   // ... or *ws_aux != ws_aux_expect (the TF-only backward over the tape: the forward left no tape of
+    unsigned int ws_aux_expect;   //     this stride); may be null
     int hints;                    // DR_HINT_* bits of the forward call
     int use_live;                 // forward: per-ray live sample counts are available (alpha pre-pass)
     int pp_l0, pp_l1, pp_first;   // alpha pre-pass phase: brick layers [pp_l0, pp_l1); pp_first: no earlier phase
@@ -41,6 +43,9 @@ int launch_march_bwd_baseline(const MarchArgs &a, hipStream_t stream);
 bool brick_path_supported(int VX, int VY, int VZ, int R);
 bool brick_image_supported(int W, int H, int VX, int VY, int VZ);  // [layer][pixel] slot indices stay below 2^31
 size_t brick_workspace_bytes(int n_views, int W, int H, int VX, int VY, int VZ);
+int tape_stride_for(int VX, int VY, int VZ, float sr, int max_samples);   // samples per ray the DR_TAPE_TF tape reserves
+size_t brick_workspace_bytes_tape(int n_views, int W, int H, int VX, int VY, int VZ, int max_samples, float sr);
+int launch_tf_tape_bwd(const MarchArgs &a, hipStream_t stream);     // TF-only backward over the per-sample tape (tf_tape.hip)
 int launch_ray_compose(const MarchArgs &a, hipStream_t stream);      // F2
 int launch_ray_exact(const MarchArgs &a, hipStream_t stream);        // F3: the rays F2 listed, sample by sample
 int launch_ray_alpha(const MarchArgs &a, hipStream_t stream);        // alpha pre-pass: per-ray composition of one phase

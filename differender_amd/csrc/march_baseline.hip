@@ -26,6 +26,7 @@ struct MarchParams {
     float *d_tf; int64_t dtf_vs;
     const uint8_t *only_flagged;
     const unsigned int *ws_mark; unsigned int ws_mark_expect;  // see MarchArgs
+    const unsigned int *ws_aux; unsigned int ws_aux_expect;
 };
 
 __device__ __forceinline__ bool tile_pixel(int W, int H, int &i, int &j) {
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256) void march_bwd_baseline_kernel(MarchParams<VT>
     bool active = tile_pixel(P.W, P.H, i, j);
     // second pass of the brick-centric backward: only the rays the forward flagged -- unless the workspace is not that
     // forward's (uniform): then the flags mean nothing, B1 has done nothing, and every ray is marched here
-    const bool stale_ws = P.ws_mark != nullptr && *P.ws_mark != P.ws_mark_expect;
+    const bool stale_ws = (P.ws_mark != nullptr && *P.ws_mark != P.ws_mark_expect) || (P.ws_aux != nullptr && *P.ws_aux != P.ws_aux_expect);
     if (stale_ws && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
         atomicAdd(const_cast<unsigned int *>(P.ws_mark) + 6, 1u);   // header word 9 (ST_STALE_BWD): the host layer warns
     if (active && P.only_flagged && !stale_ws) active = P.only_flagged[((size_t)view * P.W + i) * P.H + j] != 0;
@@ -229,6 +230,7 @@ static MarchParams<VT> make_params(const MarchArgs &a) {
     P.d_tf = a.d_tf; P.dtf_vs = a.dtf_vs / 4;
     P.only_flagged = a.only_flagged;
     P.ws_mark = a.ws_mark; P.ws_mark_expect = a.ws_mark_expect;
+    P.ws_aux = a.ws_aux; P.ws_aux_expect = a.ws_aux_expect;
     return P;
 }
 

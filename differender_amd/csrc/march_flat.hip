@@ -19,6 +19,7 @@
 // add/mul/fma, v_mov and v_add_u32 issue in 2 cycles, everything else in 4 (rcp/rsq 8).
 // Reference functions replaced: VR.py:261-372 and the autodiff twins VR.py:460-461,470-471.
 #include "dr_brick_common.h"
+#include "dr_wave.h"
 
 namespace dr {
 
@@ -445,17 +446,6 @@ __device__ __forceinline__ void cand_load(const BrickParams<VT> &P, const BrickC
                                         //  backward kernel is register-bound and they would be held across the box staging)
 }
 
-// inclusive sum of an int over the wave (DPP; lanes without a source add 0)
-__device__ __forceinline__ int wave_incl_sum(int v) {
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
-    return v;
-}
-
 // List the ray segments of this WAVE's candidates of the round and their flat offsets: every wave keeps its own
 // segment table (entries [wave*CW, wave*CW + nE), offsets at index entry + wave so that each table has its end
 // marker) and its own flat sample space [0, M). No workgroup barrier, no serial phase: the compaction is a ballot,
@@ -535,159 +525,6 @@ __device__ __forceinline__ void flat_build_entries(const BrickParams<VT> &P, con
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-struct Over { float c0, c1, c2, a; };  // premultiplied composite element
-__device__ __forceinline__ Over over(const Over &front, const Over &back) {  // front-to-back "over"
-    const float T = 1.0f - front.a;
-    Over r;
-    r.c0 = fmaf(T, back.c0, front.c0); r.c1 = fmaf(T, back.c1, front.c1); r.c2 = fmaf(T, back.c2, front.c2);
-    r.a = fmaf(T, back.a, front.a);
-    return r;
-}
-// ---- cross-lane plumbing: DPP moves (no LDS traffic, a few cycles of latency) ---------------------------
-// ctrl: 0x111/0x112/0x114/0x118 = row_shr:1/2/4/8 (within a 16-lane row), 0x142 = row_bcast:15 (lane 15 of a
-// row to the next row), 0x143 = row_bcast:31 (lane 31 to the upper half). Lanes without a source keep `old`.
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
-}
-template <int CTRL>
-__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
-template <int CTRL>
-__device__ __forceinline__ Over dpp_over(const Over &v) {
-    Over r;
-    r.c0 = dpp_f<CTRL>(v.c0); r.c1 = dpp_f<CTRL>(v.c1); r.c2 = dpp_f<CTRL>(v.c2); r.a = dpp_f<CTRL>(v.a);
-    return r;
-}
-// Does the DPP source lane of step K exist and lie at or after lane `sl` (the first lane of this lane's segment)?
-template <int K>
-__device__ __forceinline__ bool scan_src_ok(int lane, int sl) {
-    if (K < 4) return (lane & 15) >= (1 << K) && lane - (1 << K) >= sl;
-    if (K == 4) return (lane & 16) && ((lane & ~15) - 1) >= sl;
-    return lane >= 32 && 31 >= sl;
-}
-// DPP move whose lanes without a source read 0 (bound_ctrl): the destination needs no initial value, so the
-// compiler does not spend a v_mov on it. Every use below ignores what such lanes receive.
-template <int CTRL>
-__device__ __forceinline__ float dpp0_f(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
-template <int CTRL>
-__device__ __forceinline__ Over dpp0_over(const Over &v) {
-    Over r;
-    r.c0 = dpp0_f<CTRL>(v.c0); r.c1 = dpp0_f<CTRL>(v.c1); r.c2 = dpp0_f<CTRL>(v.c2); r.a = dpp0_f<CTRL>(v.a);
-    return r;
-}
-// x = T*x + o in x's own register (the compiler's choice, v_fmac into the DPP temporary, needs a move back per channel)
-__device__ __forceinline__ void fma_into(float &x, float T, float o) {
-    asm("v_fma_f32 %0, %1, %0, %2" : "+v"(x) : "v"(T), "v"(o));
-}
-// segmented inclusive scan of "over": segments are runs of lanes sharing sl
-__device__ __forceinline__ Over seg_scan_over(Over v, int lane, int sl) {
-#define DR_OVER_STEP(CTRL, K)                                                                       \
-    {                                                                                               \
-        const Over o = dpp0_over<CTRL>(v);                                                          \
-        if (scan_src_ok<K>(lane, sl)) {                                                             \
-            const float T = 1.0f - o.a;                                                             \
-            fma_into(v.c0, T, o.c0); fma_into(v.c1, T, o.c1); fma_into(v.c2, T, o.c2); fma_into(v.a, T, o.a); \
-        }                                                                                           \
-    }
-    DR_OVER_STEP(0x111, 0) DR_OVER_STEP(0x112, 1) DR_OVER_STEP(0x114, 2) DR_OVER_STEP(0x118, 3)
-    DR_OVER_STEP(0x142, 4) DR_OVER_STEP(0x143, 5)
-#undef DR_OVER_STEP
-    return v;
-}
-// The backward needs the composites only through gC . C and A (the tape-free identity's suffix term): it scans the PAIR
-// (w, a), w = gC . c with the lane's own upstream colour gradient (constant over a segment = one ray), under the same
-// "over" -- half the scan of the forward's four channels.
-struct Over2 { float w, a; };
-__device__ __forceinline__ Over2 over2(const Over2 &front, const Over2 &back) {
-    const float T = 1.0f - front.a;
-    Over2 r;
-    r.w = fmaf(T, back.w, front.w); r.a = fmaf(T, back.a, front.a);
-    return r;
-}
-__device__ __forceinline__ Over2 seg_scan_over2(Over2 v, int lane, int sl) {
-#define DR_OVER2_STEP(CTRL, K)                                                    \
-    {                                                                             \
-        const float ow = dpp0_f<CTRL>(v.w), oa = dpp0_f<CTRL>(v.a);               \
-        if (scan_src_ok<K>(lane, sl)) {                                           \
-            const float T = 1.0f - oa;                                            \
-            fma_into(v.w, T, ow); fma_into(v.a, T, oa);                           \
-        }                                                                         \
-    }
-    DR_OVER2_STEP(0x111, 0) DR_OVER2_STEP(0x112, 1) DR_OVER2_STEP(0x114, 2) DR_OVER2_STEP(0x118, 3)
-    DR_OVER2_STEP(0x142, 4) DR_OVER2_STEP(0x143, 5)
-#undef DR_OVER2_STEP
-    return v;
-}
-// segmented inclusive SUM of NV values (same segment convention)
-template <int NV>
-__device__ __forceinline__ void seg_scan_sum(float (&v)[NV], int lane, int sl) {
-#define DR_SUM_STEP(CTRL, K)                                             \
-    {                                                                    \
-        const bool ok = scan_src_ok<K>(lane, sl);                        \
-        _Pragma("unroll") for (int i = 0; i < NV; ++i) {                 \
-            const float t = v[i] + dpp_f<CTRL>(v[i]);                    \
-            v[i] = ok ? t : v[i];                                        \
-        }                                                                \
-    }
-    DR_SUM_STEP(0x111, 0) DR_SUM_STEP(0x112, 1) DR_SUM_STEP(0x114, 2) DR_SUM_STEP(0x118, 3)
-    DR_SUM_STEP(0x142, 4) DR_SUM_STEP(0x143, 5)
-#undef DR_SUM_STEP
-}
-// segmented inclusive PRODUCT of one value (transmittance of the alpha pre-pass)
-__device__ __forceinline__ float seg_scan_prod(float v, int lane, int sl) {
-    { const float o = dpp_f<0x111>(v); if (scan_src_ok<0>(lane, sl)) v *= o; }
-    { const float o = dpp_f<0x112>(v); if (scan_src_ok<1>(lane, sl)) v *= o; }
-    { const float o = dpp_f<0x114>(v); if (scan_src_ok<2>(lane, sl)) v *= o; }
-    { const float o = dpp_f<0x118>(v); if (scan_src_ok<3>(lane, sl)) v *= o; }
-    { const float o = dpp_f<0x142>(v); if (scan_src_ok<4>(lane, sl)) v *= o; }
-    { const float o = dpp_f<0x143>(v); if (scan_src_ok<5>(lane, sl)) v *= o; }
-    return v;
-}
-// inclusive max scan of an int (used to propagate run starts)
-__device__ __forceinline__ int scan_max(int v, int lane) {
-    { const int o = dpp_i<0x111>(v); if ((lane & 15) >= 1) v = max(v, o); }
-    { const int o = dpp_i<0x112>(v); if ((lane & 15) >= 2) v = max(v, o); }
-    { const int o = dpp_i<0x114>(v); if ((lane & 15) >= 4) v = max(v, o); }
-    { const int o = dpp_i<0x118>(v); if ((lane & 15) >= 8) v = max(v, o); }
-    { const int o = dpp_i<0x142>(v); if (lane & 16) v = max(v, o); }
-    { const int o = dpp_i<0x143>(v); if (lane >= 32) v = max(v, o); }
-    return v;
-}
-// largest of a non-negative float over the wave, wave-uniform (DPP; non-negative floats order like their bit patterns)
-__device__ __forceinline__ float wave_max_nonneg(float x) {
-    // unsigned max: 0 (what a lane without a DPP source reads) is its identity, so each step folds into one v_max_u32_dpp
-    unsigned int v = __float_as_uint(x);
-    v = max(v, (unsigned int)dpp_i<0x111>((int)v));   // row_shr:1
-    v = max(v, (unsigned int)dpp_i<0x112>((int)v));
-    v = max(v, (unsigned int)dpp_i<0x114>((int)v));
-    v = max(v, (unsigned int)dpp_i<0x118>((int)v));   // lane 15 of every row: the row's maximum
-    v = max(v, (unsigned int)dpp_i<0x142>((int)v));   // row_bcast:15
-    v = max(v, (unsigned int)dpp_i<0x143>((int)v));   // row_bcast:31 -> lane 63: the wave's maximum
-    return __uint_as_float((unsigned int)__builtin_amdgcn_readlane((int)v, 63));
-}
-__device__ __forceinline__ Over readlane_over(const Over &v, int lane) {
-    Over r;
-    r.c0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.c0), lane));
-    r.c1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.c1), lane));
-    r.c2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.c2), lane));
-    r.a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.a), lane));
-    return r;
-}
-// whole-wave shifts by one lane with DPP (wave_shr:1 = 0x138, wave_shl:1 = 0x130; gfx9 family): lane 0 / lane 63
-// keep the `edge` value. No LDS crossbar traffic, unlike __shfl_up/__shfl_down (ds_bpermute).
-__device__ __forceinline__ float wave_up1(float v, float edge) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), 0x138, 0xf, 0xf, false));
-}
-__device__ __forceinline__ int wave_up1(int v, int edge) { return __builtin_amdgcn_update_dpp(edge, v, 0x138, 0xf, 0xf, false); }
-__device__ __forceinline__ int wave_down1(int v, int edge) { return __builtin_amdgcn_update_dpp(edge, v, 0x130, 0xf, 0xf, false); }
-__device__ __forceinline__ Over shfl_up1_over(const Over &v) {
-    Over r;
-    r.c0 = wave_up1(v.c0, 0.f); r.c1 = wave_up1(v.c1, 0.f); r.c2 = wave_up1(v.c2, 0.f); r.a = wave_up1(v.a, 0.f);
-    return r;
 }
 
 // How a d_volume contribution reaches its LDS accumulator (dr_brick_common.h, "LDS gradient accumulators")
@@ -822,7 +659,9 @@ __device__ __forceinline__ float wave_min_f(float v) {
 // inside the volume: the brick around the eye is a candidate of every pixel -- had the rest cut into items of ITEM_CAND
 // candidates by brick_ctx_kernel, which a second, small launch works off (brick_flat_items_kernel). Without that, the few
 // bricks next to the camera would each be one workgroup's job: 61 ms instead of 6 for a 512^2 view from inside a 512^3 volume.
-template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, int ALPHA, int KF, bool HEAVY, bool NARROW>
+// TAPE (colour march of a differentiable render only): DR_TAPE_TF -- every marched sample is shaded (the TF gradient of a transparent
+// sample needs its lighting term too) and leaves (intensity, lighting) on the per-sample tape; nothing is skipped.
+template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, int ALPHA, int KF, bool HEAVY, bool NARROW, bool TAPE = false>
 __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsigned char *smem, const int slot, const int view,
                                                 const int c_lo, const int c_hi, int &box_valid) {   // box_valid: 0 no box staged, 1 staged, 2 staged and EMPTY
     if (ALPHA && P.vflags[view] == 0u) return;  // uniform: no ray of this view can terminate early
@@ -947,7 +786,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
     const long long tq2 = clock64();   // candidates loaded and listed
 #endif
     if (!reuse_box) box_commit<VT, FNT, ALPHA != 0>(P, vol, c, P.tf + view * P.tf_vs, stage, L);
-    const bool test_empty = !BWD && !reuse_box && (c.maybe_empty & 1) != 0;  // uniform
+    const bool test_empty = !BWD && !TAPE && !reuse_box && (c.maybe_empty & 1) != 0;  // uniform
     if constexpr (!BWD) { if (test_empty) brick_empty_publish<FNT>(stage, L); }
     if (!reuse_box) box_valid = 1;
 #if DR_PHASE_TIMING == 3
@@ -1370,7 +1209,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                         tf_lookup_from_I(L.tf, P.R, P.tf_len, sm);
                         if (MODE != DR_MODE_NONDIFF) sm.op = opacity_of_alpha(sm.a, P.inv_sr);
                     }
-                    const bool lit = vj && (MODE == DR_MODE_NONDIFF ? (sm.a > 1e-3f) : (sm.op != 0.0f));
+                    const bool lit = vj && (MODE == DR_MODE_NONDIFF ? (sm.a > 1e-3f) : (TAPE || sm.op != 0.0f));
                     Over ej = {0.f, 0.f, 0.f, 0.f};
                     if (__any(lit)) {
                         if (lit) {
@@ -1379,10 +1218,12 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                             sample_normal_taps_shared_lds<NARROW>(L.box, t, cl, dx, dy, dz);
                             shade_from_grad<true>(dx, dy, dz, light, vd, MODE == DR_MODE_DIFF, sm);
                             ej.c0 = sm.L * sm.r * sm.op; ej.c1 = sm.L * sm.g * sm.op; ej.c2 = sm.L * sm.b * sm.op; ej.a = sm.op;
+                            if constexpr (TAPE)   // (lanes are consecutive samples of a ray: 512 contiguous bytes per wave and ray)
+                                P.tape[((size_t)view * NP + (size_t)__float_as_int(r1.w)) * (size_t)P.tape_stride + (size_t)(s + j)] = make_float2(sm.I, sm.L);
                         }
                     }
                     vm_fwd[j] = __ballot(vj);
-                    tm_fwd[j] = __ballot(lit && ej.a < DR_D4_TINY_OP);   // (ej.a = the opacity of a lit sample)
+                    tm_fwd[j] = __ballot(lit && (!TAPE || ej.a != 0.0f) && ej.a < DR_D4_TINY_OP);   // (ej.a = the opacity of a lit sample)
 #ifdef DR_LANE_STATS
                     if (lane == 0 && j < ks) {  // lane slots issued / holding a listed sample / holding an in-brick sample
                         atomicAdd(reinterpret_cast<unsigned long long *>(P.stats + ST_TIMING + 32), 64ull);
@@ -1659,7 +1500,7 @@ constexpr int ITEM_GRID_FWD = DR_ITEM_GRID_FWD, ITEM_GRID_BWD = DR_ITEM_GRID_BWD
 #endif
 constexpr int ITEM_RUN = DR_ITEM_RUN;   // consecutive items a workgroup takes at a time
 
-template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, int ALPHA = 0, int KF = 1, bool NARROW = true>
+template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, int ALPHA = 0, int KF = 1, bool NARROW = true, bool TAPE = false>
 __global__ __launch_bounds__((FlatCfg<BWD, WANT_VOL, ALPHA>::FNT), (FlatCfg<BWD, WANT_VOL, ALPHA>::WAVES)) void brick_flat_kernel(BrickParams<VT> P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef DR_VIEW_FASTEST
@@ -1670,8 +1511,8 @@ __global__ __launch_bounds__((FlatCfg<BWD, WANT_VOL, ALPHA>::FNT), (FlatCfg<BWD,
     brick_flat_body<VT, MODE, BWD, WANT_VOL, WANT_TF, ALPHA, KF, false, NARROW>(P, smem, blockIdx.x / nv, blockIdx.x % nv, 0, MAIN_CAND, bv);
 #else
     int bv = 0;
-    brick_flat_body<VT, MODE, BWD, WANT_VOL, WANT_TF, ALPHA, KF, false, NARROW>(P, smem, blockIdx.x, blockIdx.y,
-                                                                               0, MAIN_CAND, bv);
+    brick_flat_body<VT, MODE, BWD, WANT_VOL, WANT_TF, ALPHA, KF, false, NARROW, TAPE>(P, smem, blockIdx.x, blockIdx.y,
+                                                                                     0, MAIN_CAND, bv);
 #endif
 }
 // Tuning experiment (right results): the main launch as a RESIDENT grid -- DR_F1_RESIDENT workgroups that draw
@@ -1695,7 +1536,7 @@ __global__ __launch_bounds__((FlatCfg<false, false>::FNT), (FlatCfg<false, false
     if (threadIdx.x == 0 && atomicAdd(&P.stats[ST_DONE_MAIN], 1u) == gridDim.x - 1) { P.stats[ST_TICKET_MAIN] = 0u; P.stats[ST_DONE_MAIN] = 0u; }
 }
 // the overflow items of heavy bricks (all views), worked off by a fixed, small grid
-template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, int ALPHA = 0, int KF = 1, bool NARROW = true>
+template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, int ALPHA = 0, int KF = 1, bool NARROW = true, bool TAPE = false>
 __global__ __launch_bounds__((FlatCfg<BWD, WANT_VOL, ALPHA>::FNT), (FlatCfg<BWD, WANT_VOL, ALPHA>::WAVES)) void brick_flat_items_kernel(BrickParams<VT> P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     if (BWD && P.stats[ST_MARK] != P.mark) return;  // uniform over the grid: not this call's workspace, the item list is garbage
@@ -1720,7 +1561,7 @@ __global__ __launch_bounds__((FlatCfg<BWD, WANT_VOL, ALPHA>::FNT), (FlatCfg<BWD,
         for (int it = first; it < min(first + ITEM_RUN, n_items); ++it) {
             const BrickItem item = P.items[it];
             if (item.view != pv || item.brick != ps) { box_valid = 0; pv = item.view; ps = item.brick; }
-            brick_flat_body<VT, MODE, BWD, WANT_VOL, WANT_TF, ALPHA, KF, true, NARROW>(P, smem, item.brick, item.view, item.c0, item.c1, box_valid);
+            brick_flat_body<VT, MODE, BWD, WANT_VOL, WANT_TF, ALPHA, KF, true, NARROW, TAPE>(P, smem, item.brick, item.view, item.c0, item.c1, box_valid);
             __syncthreads();  // the next item reuses the LDS
         }
     }
@@ -1819,9 +1660,13 @@ static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     const BrickGrid g = make_brick_grid(a.VX, a.VY, a.VZ);
     const int NP = a.W * a.H;
     Workspace w;
-    const size_t need = ws_layout(a.workspace, a.n_views, NP, g, &w);
+    // DR_TAPE_TF: a per-sample tape of (intensity, lighting) for the TF-only backward (tf_tape.hip) behind the ordinary workspace
+    const bool tape = (a.hints & DR_TAPE_TF) && a.mode == DR_MODE_DIFF;
+    const int tstride = tape ? tape_stride_for(a.VX, a.VY, a.VZ, a.sr, a.S) : 0;
+    const size_t need = ws_layout(a.workspace, a.n_views, NP, g, &w, tstride);
     if (!a.workspace || a.workspace_bytes < need) return DR_EINVAL;
     BrickParams<VT> P = make_brick_params<VT>(a, w);
+    P.tape = w.tape; P.tape_stride = tstride;
     hipError_t e;
 #if DR_PHASE_TIMING
     if ((e = hipMemsetAsync(w.stats + ST_TIMING, 0, 64, stream)) != hipSuccess) return (int)e;  // the timing slots
@@ -1833,7 +1678,8 @@ static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     // Non-differentiable render with an alpha pre-pass: the pre-pass tells the colour march which (ray, layer) segments hold no
     // sample with alpha > 1e-3 ("unlit" masks behind seg_cnt, BrickParams::unlit); such segments keep the pre-pass's count and
     // zero partial, so seg_cnt is NOT cleared between the two passes (see below).
-    const bool unlit_masks = (a.mode == DR_MODE_NONDIFF || DR_UNLIT_SKIP > 1) && !(a.hints & DR_HINT_NO_EARLY_TERMINATION) && w.lm_words > 0 && DR_UNLIT_SKIP;
+    // (not with a tape: a sample without opacity still has a TF gradient -- alpha = 0 has a slope -- and must leave its lighting term)
+    const bool unlit_masks = !tape && (a.mode == DR_MODE_NONDIFF || DR_UNLIT_SKIP > 1) && !(a.hints & DR_HINT_NO_EARLY_TERMINATION) && w.lm_words > 0 && DR_UNLIT_SKIP;
     P.lm_words = unlit_masks ? w.lm_words : 0;
     // the item counter (brick_ctx_kernel appends) and seg_cnt behind it (and the masks behind that)
     e = hipMemsetAsync(w.n_items, 0, 16 + (unlit_masks ? align16(w.cnt_bytes) + w.unlit_bytes : w.cnt_bytes), stream);
@@ -1902,7 +1748,20 @@ static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     MarchArgs b = a;
     b.use_live = prepass ? 1 : 0;
     P.use_live = b.use_live;
-    if (a.mode == DR_MODE_DIFF) { if (k_hi) DR_LAUNCH_F1(DR_MODE_DIFF, DR_FWD_K_HI) else DR_LAUNCH_F1(DR_MODE_DIFF, DR_FWD_K) }
+    if (tape) {
+        // the same march with TAPE = true: main launch + work items, both tap flavours
+#define DR_LAUNCH_F1_TAPE(K_, NARROW_)                                                                                                   \
+        {                                                                                                                                \
+            if ((e = allow_lds(brick_flat_kernel<VT, DR_MODE_DIFF, false, false, false, 0, K_, NARROW_, true>, lds)) != hipSuccess) return (int)e;   \
+            if ((e = allow_lds(brick_flat_items_kernel<VT, DR_MODE_DIFF, false, false, false, 0, K_, NARROW_, true>, align16(lds) + ITEM_EXTRA_LDS)) != hipSuccess) return (int)e; \
+            hipLaunchKernelGGL((brick_flat_kernel<VT, DR_MODE_DIFF, false, false, false, 0, K_, NARROW_, true>), grid1, dim3(FlatCfg<false, false>::FNT), lds, stream, P); \
+            hipLaunchKernelGGL((brick_flat_items_kernel<VT, DR_MODE_DIFF, false, false, false, 0, K_, NARROW_, true>), dim3(ITEM_GRID_FWD), dim3(FlatCfg<false, false>::FNT), align16(lds) + ITEM_EXTRA_LDS, stream, P); \
+        }
+        const bool narrow = taps_narrow(a);
+        if (k_hi) { if (narrow) DR_LAUNCH_F1_TAPE(DR_FWD_K_HI, true) else DR_LAUNCH_F1_TAPE(DR_FWD_K_HI, false) }
+        else { if (narrow) DR_LAUNCH_F1_TAPE(DR_FWD_K, true) else DR_LAUNCH_F1_TAPE(DR_FWD_K, false) }
+#undef DR_LAUNCH_F1_TAPE
+    } else if (a.mode == DR_MODE_DIFF) { if (k_hi) DR_LAUNCH_F1(DR_MODE_DIFF, DR_FWD_K_HI) else DR_LAUNCH_F1(DR_MODE_DIFF, DR_FWD_K) }
     else { if (k_hi) DR_LAUNCH_F1(DR_MODE_NONDIFF, DR_FWD_K_HI) else DR_LAUNCH_F1(DR_MODE_NONDIFF, DR_FWD_K) }
 #undef DR_LAUNCH_F1
     if ((e = hipGetLastError()) != hipSuccess) return (int)e;
@@ -1925,10 +1784,24 @@ static int flat_bwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     const BrickGrid g = make_brick_grid(a.VX, a.VY, a.VZ);
     const int NP = a.W * a.H;
     Workspace w;
+    const bool wv = a.d_vol != nullptr, wt = a.d_tf != nullptr;
+    // DR_TAPE_TF: the TF-only backward as a per-ray pass over the forward's per-sample tape (tf_tape.hip), B2 for the flagged rays --
+    // or for all of them, should the workspace turn out not to hold this call's tape (checked on the device)
+    if ((a.hints & DR_TAPE_TF) && !wv && wt) {
+        const int tstride = tape_stride_for(a.VX, a.VY, a.VZ, a.sr, a.S);
+        const size_t need_t = ws_layout(a.workspace, a.n_views, NP, g, &w, tstride);
+        if (!a.workspace || a.workspace_bytes < need_t) return DR_EINVAL;
+        const int rc = launch_tf_tape_bwd(a, stream);
+        if (rc) return rc;
+        MarchArgs b = a;
+        b.only_flagged = w.rayflag;
+        b.ws_mark = w.stats + ST_MARK; b.ws_mark_expect = ws_fingerprint(a);
+        b.ws_aux = w.stats + ST_TAPE_STRIDE; b.ws_aux_expect = (unsigned int)tstride;
+        return launch_march_bwd_baseline(b, stream);
+    }
     const size_t need = ws_layout(a.workspace, a.n_views, NP, g, &w);
     if (!a.workspace || a.workspace_bytes < need) return DR_EINVAL;
     BrickParams<VT> P = make_brick_params<VT>(a, w);
-    const bool wv = a.d_vol != nullptr, wt = a.d_tf != nullptr;
     P.lm_words = (wv && !wt && DR_UNLIT_SKIP > 1) ? w.lm_words : 0;   // the d_volume-only backward may skip unlit segments (if the forward left masks)
     const size_t lds = flat_lds_bytes<true>(a.R, wv, wt) + DR_ABL_EXTRA_LDS_BWD;
     const dim3 grid1(g.NBx * g.NBy * g.NBz, a.n_views);

@@ -590,6 +590,21 @@ size_t brick_workspace_bytes(int n_views, int W, int H, int VX, int VY, int VZ) 
     const BrickGrid g = make_brick_grid(VX, VY, VZ);
     return ws_layout(nullptr, n_views, W * H, g, nullptr);
 }
+// Samples per ray the DR_TAPE_TF tape reserves: the longest chord of the box at this sampling rate (VR.py:251-253: n = floor(sr * len *
+// |shape - 1|) + 1, len <= 2 sqrt 3), cut at max_samples like the march itself (VR.py:268); even, so that a lane's two samples share
+// one 16-byte load.
+int tape_stride_for(int VX, int VY, int VZ, float sr, int max_samples) {
+    const double diag = sqrt((double)(VX - 1) * (VX - 1) + (double)(VY - 1) * (VY - 1) + (double)(VZ - 1) * (VZ - 1));
+    double n_max = floor((double)sr * 2.0 * sqrt(3.0) * diag) + 2.0;
+    if (n_max > (double)max_samples) n_max = (double)max_samples;
+    if (n_max < 2.0) n_max = 2.0;
+    if (n_max > 1.0e9) n_max = 1.0e9;
+    return ((int)n_max + 1) & ~1;
+}
+size_t brick_workspace_bytes_tape(int n_views, int W, int H, int VX, int VY, int VZ, int max_samples, float sr) {
+    const BrickGrid g = make_brick_grid(VX, VY, VZ);
+    return ws_layout(nullptr, n_views, W * H, g, nullptr, tape_stride_for(VX, VY, VZ, sr, max_samples));
+}
 
 // F2: the workspace must hold the F1 output of the same call.
 template <typename VT>

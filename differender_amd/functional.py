@@ -84,13 +84,18 @@ def new_jitter_seed():
     return int(torch.randint(1, 2 ** 31 - 1, (1,)).item())
 
 
-def alloc_workspace(n_views, out_shape, vol_shape, R, device):
+def alloc_workspace(n_views, out_shape, vol_shape, R, device, tape=None):
     """Scratch buffer of the fast (brick-centric) kernels for one forward(+backward) pair, or None when only
     the baseline kernels can serve this problem (dr_workspace_bytes() == 0). The forward leaves its coarse
-    tape here; hand the same buffer to march_bwd."""
+    tape here; hand the same buffer to march_bwd.
+    tape=(max_samples, sampling_rate): room for the per-sample tape of a DR_TAPE_TF forward as well (march_fwd(tape=True) /
+    march_bwd(tape=True): the backward w.r.t. the transfer function alone) -- 8 B per ray and possible sample."""
     W, H = int(out_shape[0]), int(out_shape[1])
     VX, VY, VZ = (int(s) for s in vol_shape)
-    nbytes = N.lib().dr_workspace_bytes(int(n_views), W, H, VX, VY, VZ, int(R))
+    if tape is not None:
+        nbytes = N.lib().dr_workspace_bytes_tape(int(n_views), W, H, VX, VY, VZ, int(R), int(tape[0]), float(tape[1]))
+    else:
+        nbytes = N.lib().dr_workspace_bytes(int(n_views), W, H, VX, VY, VZ, int(R))
     if nbytes == 0:
         return None
     return torch.empty(nbytes, dtype=torch.uint8, device=device)
@@ -311,12 +316,14 @@ def termination_hints(tf, vol_shape, sampling_rate, max_samples, mode, alpha=lam
 
 def march_fwd(vol, tf, cam, entry, exit_, rays, n, max_samples, sampling_rate, mode=N.DR_MODE_DIFF,
               variant=N.DR_VARIANT_AUTO, want_steps=True, fov_deg=30.0, near=0.1, workspace="auto", rows=None,
-              hints="auto"):
+              hints="auto", tape=False):
     """raycast + get_final_image (VR.py:261-306,363-372) or the nondiff pair (VR.py:308-361).
     Returns out (views,W,H,4) and steps (views,W,H) int32 (or None).
     workspace: a buffer from alloc_workspace() (keep it for march_bwd), "auto" to allocate a throw-away one,
     or None to force the baseline kernels.
-    hints: "auto" (DR_HINT_* from the TF's largest alpha once it is known, see _TerminationHints), 0 / None, or explicit bits."""
+    hints: "auto" (DR_HINT_* from the TF's largest alpha once it is known, see _TerminationHints), 0 / None, or explicit bits.
+    tape: DR_TAPE_TF -- the caller will ask for the TF gradient only (march_bwd(want_vol=False, tape=True)); the workspace must come
+    from alloc_workspace(..., tape=(max_samples, sampling_rate)). Differentiable mode only; same image."""
     _require_gpu(vol, "volume")
     V, W, H = n.shape
     dev = vol.device
@@ -333,18 +340,23 @@ def march_fwd(vol, tf, cam, entry, exit_, rays, n, max_samples, sampling_rate, m
         rc = N.lib().dr_march_fwd_rows(*vargs, targs[0], targs[1], targs[2], cam.data_ptr(), entry.data_ptr(),
                                        exit_.data_ptr(), rays.data_ptr(), n.data_ptr(), V, W, H, int(max_samples),
                                        float(sampling_rate), float(np.radians(fov_deg)), float(near), int(mode),
-                                       int(variant) | int(hints or 0), out.data_ptr(), steps.data_ptr() if want_steps else None,
+                                       int(variant) | int(hints or 0) | (N.DR_TAPE_TF if tape else 0), out.data_ptr(),
+                                       steps.data_ptr() if want_steps else None,
                                        *_ws_args(workspace), *_rows(rows, W), _stream())
     N.check(rc, "dr_march_fwd_rows")
     return out, steps
 
 
 def march_bwd(vol, tf, cam, entry, exit_, rays, n, max_samples, sampling_rate, grad_out, out, want_vol=True,
-              want_tf=True, variant=N.DR_VARIANT_AUTO, fov_deg=30.0, near=0.1, workspace=None, rows=None, count_evaluated=False):
+              want_tf=True, variant=N.DR_VARIANT_AUTO, fov_deg=30.0, near=0.1, workspace=None, rows=None, count_evaluated=False,
+              tape=False):
     """Adjoint of the differentiable march w.r.t. vol and tf (replaces raycast.grad, VR.py:460-461,470-471).
     Shared (un-batched) vol / tf receive one gradient accumulated over all views.
     workspace: the buffer the matching march_fwd filled (fast path); None runs the baseline kernels.
-    count_evaluated: measurement only (DR_COUNT_EVALUATED; see evaluated_samples())."""
+    count_evaluated: measurement only (DR_COUNT_EVALUATED; see evaluated_samples()).
+    tape: the forward was run with tape=True and only d_tf is wanted: the per-ray pass over the tape (csrc/tf_tape.hip)."""
+    if tape and want_vol:
+        raise ValueError("tape=True serves the backward w.r.t. the transfer function alone (want_vol=False)")
     _require_gpu(vol, "volume")
     V, W, H = n.shape
     cam = cam.to(torch.float32).contiguous()
@@ -370,7 +382,7 @@ def march_bwd(vol, tf, cam, entry, exit_, rays, n, max_samples, sampling_rate, g
         rc = N.lib().dr_march_bwd_rows(*vargs, targs[0], targs[1], targs[2], cam.data_ptr(), entry.data_ptr(),
                                        exit_.data_ptr(), rays.data_ptr(), n.data_ptr(), V, W, H, int(max_samples),
                                        float(sampling_rate), float(np.radians(fov_deg)), float(near),
-                                       int(variant) | (N.DR_COUNT_EVALUATED if count_evaluated else 0),
+                                       int(variant) | (N.DR_COUNT_EVALUATED if count_evaluated else 0) | (N.DR_TAPE_TF if tape else 0),
                                        grad_out.data_ptr(), out.data_ptr(), *dv, *dt, *_ws_args(workspace),
                                        *_rows(rows, W), _stream())
     N.check(rc, "dr_march_bwd_rows")

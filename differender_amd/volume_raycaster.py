@@ -257,11 +257,17 @@ class RaycastFunction(torch.autograd.Function):
         tf = tf.float().contiguous()          # set_tf_tex's .float() (VR.py:122)
         seed = F.new_jitter_seed() if jitter else 0
         e, x, r, n = F.ray_setup(cam, vr.resolution, volume.shape[-3:], sampling_rate, vr.fov_deg, vr.near, seed)
-        ws = F.alloc_workspace(cam.shape[0], vr.resolution, volume.shape[-3:], tf.shape[-2], volume.device)
+        # only the transfer function is being optimised (the reference's TF demo; BASELINE config C3): the forward leaves a
+        # per-sample tape of (intensity, lighting) and the backward never touches the volume again (csrc/tf_tape.hip)
+        tape = bool(ctx.needs_input_grad[2] and not ctx.needs_input_grad[1])
+        ws = F.alloc_workspace(cam.shape[0], vr.resolution, volume.shape[-3:], tf.shape[-2], volume.device,
+                               tape=(vr.max_samples, sampling_rate) if tape else None)
+        tape = tape and ws is not None
         out, steps = F.march_fwd(volume, tf, cam, e, x, r, n, vr.max_samples, sampling_rate, N.DR_MODE_DIFF,
-                                 fov_deg=vr.fov_deg, near=vr.near, workspace=ws, hints=hints)
+                                 fov_deg=vr.fov_deg, near=vr.near, workspace=ws, hints=hints, tape=tape)
         ctx.save_for_backward(volume, tf, cam, e, x, r, n, out)
         ctx.workspace = ws  # coarse tape of the forward (per-segment prefixes), consumed by backward
+        ctx.tape = tape
         ctx.vr, ctx.sampling_rate, ctx.batched, ctx.jitter_seed = vr, sampling_rate, is_batched, seed
         vr._steps = steps if is_batched else steps[0]
         vr._watch_workspace(ws, n.numel(), forward=True)
@@ -275,7 +281,7 @@ class RaycastFunction(torch.autograd.Function):
         want_vol, want_tf = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         dv, dt = F.march_bwd(volume, tf, cam, e, x, r, n, ctx.vr.max_samples, ctx.sampling_rate, g, out,
                              want_vol=want_vol, want_tf=want_tf, fov_deg=ctx.vr.fov_deg, near=ctx.vr.near,
-                             workspace=ctx.workspace)
+                             workspace=ctx.workspace, tape=ctx.tape and not want_vol)
         ctx.vr._watch_workspace(ctx.workspace, n.numel())
         # VR.py:463-464,474-475: nan_to_num. The fast kernels drop NaN adjoints and clamp infinite ones themselves
         # ("non-finite upstream gradients"), so the two full passes over d_volume are only run when the

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DR_ABI_VERSION 8
+#define DR_ABI_VERSION 9
 
 enum { DR_F32 = 0, DR_F16 = 1 };
 enum { DR_MODE_DIFF = 0, DR_MODE_NONDIFF = 1 };
@@ -55,7 +55,14 @@ enum { DR_VARIANT_AUTO = 0, DR_VARIANT_BASELINE = 1 };
  *       termination point) evaluate nothing for samples that still count as marched -- in 64-bit words of the workspace header:
  *       words 58/59 alpha pre-pass, 60/61 colour march (zeroed by the forward), 62/63 backward (accumulates until the next
  *       forward). One atomic per wave: measurably slower on scenes with many short workgroups, so never set in a timed step. */
-enum { DR_HINT_NO_EARLY_TERMINATION = 0x100, DR_HINT_EARLY_TERMINATION = 0x200, DR_COUNT_EVALUATED = 0x400 };
+/*   DR_TAPE_TF (dr_march_fwd[_rows] with mode DR_MODE_DIFF, and the dr_march_bwd[_rows] of the same inputs with d_vol == NULL):
+ *       the caller wants the gradient w.r.t. the transfer function ONLY (BASELINE config C3; the reference's TF optimisation,
+ *       examples/taichi_volume_raycaster.py). The forward then leaves a per-SAMPLE tape of (intensity, lighting term) -- 8 B
+ *       per marched sample, the two things of a sample the TF gradient needs from the volume -- behind the ordinary workspace
+ *       (dr_workspace_bytes_tape), and the backward is a per-ray pass over that tape: no brick is staged, no tap is taken
+ *       again. Same results as without the flag (a choice between ways of computing the same thing); the backward checks on
+ *       the device that the workspace holds this forward's tape and marches the rays one by one if it does not. */
+enum { DR_HINT_NO_EARLY_TERMINATION = 0x100, DR_HINT_EARLY_TERMINATION = 0x200, DR_COUNT_EVALUATED = 0x400, DR_TAPE_TF = 0x800 };
 
 enum {
     DR_EINVAL = -1,      /* bad argument (null pointer, non-positive extent, unknown enum) */
@@ -99,6 +106,10 @@ int dr_ray_setup(const float *cam, int n_views, int W, int H, int VX, int VY, in
  * per-ray live sample counts there (the "coarse tape", ~20 B per ray per brick layer). Replaces the
  * reference's render_tape field (VR.py:82,102-103: 16 B per ray per SAMPLE, twice with its gradient). */
 size_t dr_workspace_bytes(int n_views, int W, int H, int VX, int VY, int VZ, int R);
+/* ... the same plus the per-sample tape of a DR_TAPE_TF forward: 8 B x min(max_samples, longest possible ray at this sampling
+ * rate) per ray (fixed stride: 6.4 GB for a 512^2 view of a 512^3 volume at rate 1 -- the reference's render_tape is 16 B per
+ * sample, twice with its gradient: VR.py:82,102-103,116). 0 where dr_workspace_bytes() is 0. */
+size_t dr_workspace_bytes_tape(int n_views, int W, int H, int VX, int VY, int VZ, int R, int max_samples, float sampling_rate);
 
 /* Forward march: trilinear sampling, 1-D TF lookup, Phong shading, front-to-back compositing with
  * early termination at A >= 0.99.

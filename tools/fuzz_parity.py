@@ -148,13 +148,17 @@ def run_case(c):
     for row0, nr in bands:
         rows = None if cut == 0 else (row0, W)
         eb, xb, rb, nb = Fn.ray_setup(cam, (nr, WH[1]), vshape, sr, jitter_seed=c["jitter"], rows=rows)
-        wsb = Fn.alloc_workspace(c["n_views"], (nr, WH[1]), vshape, c["R"], dev) if variant == 0 else None
+        # the TF-only backward of the fast path runs over the per-sample tape (DR_TAPE_TF) on every second such case
+        use_tape = variant == 0 and mode == 0 and tuple(c["want"]) == (False, True) and c["seed"] % 2 == 0
+        c["tape"] = use_tape
+        wsb = Fn.alloc_workspace(c["n_views"], (nr, WH[1]), vshape, c["R"], dev, tape=(S, sr) if use_tape else None) if variant == 0 else None
+        use_tape = use_tape and wsb is not None
         # caller hints (include/differender_hip.h), right or WRONG, must never change a result: every third fast-path case
         # claims "no ray terminates early" (false for most of the opaque TFs: the device repairs the view), every third
         # claims "many rays terminate" (the grouped pre-pass also below sampling rate 3)
         hint = 0 if variant != 0 else (0, 0x100, 0x200)[c["seed"] % 3]
-        ob, sb = Fn.march_fwd(vol, tf, cam, eb, xb, rb, nb, S, sr, mode, variant=variant, workspace=wsb, rows=rows, hints=hint)
-        pieces.append((rows, row0, nr, eb, xb, rb, nb, wsb, ob, sb))
+        ob, sb = Fn.march_fwd(vol, tf, cam, eb, xb, rb, nb, S, sr, mode, variant=variant, workspace=wsb, rows=rows, hints=hint, tape=use_tape)
+        pieces.append((rows, row0, nr, eb, xb, rb, nb, wsb, ob, sb, use_tape))
     e, x, r, n, out, steps = (torch.cat([p[k] for p in pieces], dim=1) for k in (3, 4, 5, 6, 8, 9))
     eh, xh, rh, nh = (t.cpu().numpy() for t in (e, x, r, n))
     out_h, steps_h = out.cpu().numpy(), steps.cpu().numpy()
@@ -190,9 +194,9 @@ def run_case(c):
         base = None
         dv = dt = None
         gt = T(g)
-        for rows, row0, nr, eb, xb, rb, nb, wsb, ob, sb in pieces:
+        for rows, row0, nr, eb, xb, rb, nb, wsb, ob, sb, tp in pieces:
             dvb, dtb = Fn.march_bwd(vol, tf, cam, eb, xb, rb, nb, S, sr, gt[:, row0:row0 + nr].contiguous(), ob, wv, wt,
-                                    variant=variant, workspace=wsb, rows=rows)
+                                    variant=variant, workspace=wsb, rows=rows, tape=tp)
             dv = dvb if dv is None or dvb is None else dv + dvb
             dt = dtb if dt is None or dtb is None else dt + dtb
         for name, got, ref in (("d_vol", dv, dv_ref), ("d_tf", dt, dt_ref)):

@@ -10,7 +10,7 @@ mkdir -p $out
 COMMON="$(make -s -C $src print-common)"
 if [ -n "${NO_LICM_FLAG+x}" ]; then COMMON="${COMMON//-mllvm -disable-machine-licm/}"; fi
 pids=()
-for f in capi ray_setup march_baseline ray_passes march_flat epilogue collective; do
+for f in capi ray_setup march_baseline ray_passes march_flat tf_tape epilogue collective; do
   /opt/rocm/bin/hipcc $COMMON "$@" -c $src/$f.hip -o $out/$f.o & pids+=($!)
 done
 # B1 in its own translation unit, with its own scheduler strategy (Makefile); BWDVOL_SCHED=default builds it like the rest;
