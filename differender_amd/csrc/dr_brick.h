@@ -93,19 +93,6 @@ __device__ __forceinline__ int camera_layer(int bx, int by, int bz, f3 cam, floa
 
 // trilinear tap from the LDS box; identical arithmetic to tri_sample (x -> y -> z lerps)
 __device__ __forceinline__ float tri_lds(const float *box, int base, float fx, float fy, float fz) {
-#ifdef DR_ABL_HALFREADS
-    // what-if (WRONG results): the z-neighbour of every corner comes from the same LDS word as the corner itself -- four LDS
-    // reads per tap instead of eight, all arithmetic kept: the bound for any scheme that fetches the two z-neighbours of a
-    // half-precision box with ONE 32-bit read (profiles/r04_ab_experiments.txt)
-    {
-        const float v00 = box[base], v10 = box[base + BOX_SX], v01 = box[base + BOX_SY], v11 = box[base + BOX_SX + BOX_SY];
-        const float w00 = __int_as_float(__float_as_int(v00) ^ 1), w10 = __int_as_float(__float_as_int(v10) ^ 1);
-        const float w01 = __int_as_float(__float_as_int(v01) ^ 1), w11 = __int_as_float(__float_as_int(v11) ^ 1);
-        const float zl_ = mixf(mixf(v00, v10, fx), mixf(v01, v11, fx), fy);
-        const float zh_ = mixf(mixf(w00, w10, fx), mixf(w01, w11, fx), fy);
-        return mixf(zl_, zh_, fz);
-    }
-#endif
     float a = mixf(box[base], box[base + BOX_SX], fx);
     float b = mixf(box[base + BOX_SY], box[base + BOX_SX + BOX_SY], fx);
     float zl = mixf(a, b, fy);

@@ -72,8 +72,6 @@ enum {
     ST_DONE = 7,
     ST_NITEMS = 5,         // diagnostic copy of the number of overflow work items of the last forward (heavy bricks: BrickItem)
     ST_HINT_BAD = 8,       // forward: views for which DR_HINT_NO_EARLY_TERMINATION was wrong (their rays were marched one by one)
-    ST_TICKET_MAIN = 10,   // resident-grid main launch (DR_F1_RESIDENT): next slot to hand out / workgroups done
-    ST_DONE_MAIN = 11,
     ST_UNLIT_SKIPPED = 12, // forward: (ray, layer) segments the colour march dropped because the alpha pre-pass had found them unlit ...
     ST_EMPTY_BRICKS = 13,  // ... and (view, brick) workgroups (all passes) that took the empty-brick path: both SAMPLED, every 64th workgroup reports
     ST_MASKS = 14,         // forward (differentiable): words per ray of "unlit" layer masks it left behind seg_cnt (0: none) -- read by the
@@ -84,7 +82,7 @@ enum {
     ST_F64_BRICKS = 4,     // backward: (view, brick) pairs whose d_volume box accumulated in double (wide local range of |grad_out|)
     ST_TAPE_STRIDE = 56,   // forward: samples per ray of the DR_TAPE_TF tape it left behind the workspace (0: none)
     ST_EVAL_PRE = 58, ST_EVAL_FWD = 60, ST_EVAL_BWD = 62,   // DR_COUNT_EVALUATED: u64 each -- samples whose taps the alpha pre-pass / the colour march / the backward evaluated
-    ST_TIMING = 16,        // DR_PHASE_TIMING: u64 x3 forward phases, u64 x3 backward phases, u64 backward lifetime
+    ST_TIMING = 16,        // words 16-55: clocks / counters of diagnostic builds (tools/patches/closed_experiments.patch), the pixel to trace of a D4 debug build
     ST_WORDS = 512         // header size in words (2 KiB)
 };
 
@@ -197,21 +195,14 @@ __device__ __forceinline__ void brick_setup(const BrickParams<VT> &P, int b, f3 
 // Dispatch order: workgroup i of a view takes the i-th brick counted from the corner of the volume NEAREST the camera
 // (perspective puts the most rays, hence the most samples, into the bricks close to the eye: with the plain index order
 // an orbit camera on the +x side had its heaviest bricks dispatched last, and the launch ended on a few long workgroups).
-#ifndef DR_NEAR_FIRST
-#define DR_NEAR_FIRST 1
-#endif
 template <typename VT>
 __device__ __forceinline__ int near_first_brick(const BrickParams<VT> &P, int i, int view) {
-#if DR_NEAR_FIRST
     const int NBx = P.g.NBx, NBy = P.g.NBy, NBz = P.g.NBz;
     int iz = i % NBz, iy = (i / NBz) % NBy, ix = i / (NBz * NBy);
     if (P.cam[3 * view] > 0.0f) ix = NBx - 1 - ix;
     if (P.cam[3 * view + 1] > 0.0f) iy = NBy - 1 - iy;
     if (P.cam[3 * view + 2] > 0.0f) iz = NBz - 1 - iz;
     return (ix * NBy + iy) * NBz + iz;
-#else
-    return i;
-#endif
 }
 
 // The records are STORED in that order (record i of a view = the brick dispatched i-th), so that a workgroup's first load
@@ -297,7 +288,7 @@ static __global__ __launch_bounds__(256) void brick_ctx_kernel(BrickParams<VT> P
                 const float lim = 1.0f + 1e-3f;
                 P.vflags[view] = flag;
                 P.vflags[P.n_views + view] = (fabsf(cx) <= lim && fabsf(cy) <= lim && fabsf(cz) <= lim) ? 1u : 0u;
-                if (view == 0) { P.stats[ST_REPAIR] = 0u; P.stats[ST_BASELINE_RAYS] = 0u; P.stats[ST_HINT_BAD] = 0u; P.stats[ST_STALE_BWD] = 0u; P.stats[ST_F64_BRICKS] = 0u; P.stats[ST_TICKET] = 0u; P.stats[ST_DONE] = 0u; P.stats[ST_TICKET_MAIN] = 0u; P.stats[ST_DONE_MAIN] = 0u; P.stats[ST_UNLIT_SKIPPED] = 0u; P.stats[ST_EMPTY_BRICKS] = 0u; P.stats[ST_EXACT_RAYS] = 0u; P.stats[ST_TAPE_STRIDE] = P.tape ? (unsigned int)P.tape_stride : 0u; for (int k = ST_EVAL_PRE; k < ST_EVAL_PRE + 6; ++k) P.stats[k] = 0u; P.stats[ST_MASKS] = P.nondiff ? 0u : (unsigned int)P.lm_words; P.stats[ST_MARK] = P.mark; }
+                if (view == 0) { P.stats[ST_REPAIR] = 0u; P.stats[ST_BASELINE_RAYS] = 0u; P.stats[ST_HINT_BAD] = 0u; P.stats[ST_STALE_BWD] = 0u; P.stats[ST_F64_BRICKS] = 0u; P.stats[ST_TICKET] = 0u; P.stats[ST_DONE] = 0u; P.stats[ST_UNLIT_SKIPPED] = 0u; P.stats[ST_EMPTY_BRICKS] = 0u; P.stats[ST_EXACT_RAYS] = 0u; P.stats[ST_TAPE_STRIDE] = P.tape ? (unsigned int)P.tape_stride : 0u; for (int k = ST_EVAL_PRE; k < ST_EVAL_PRE + 6; ++k) P.stats[k] = 0u; P.stats[ST_MASKS] = P.nondiff ? 0u : (unsigned int)P.lm_words; P.stats[ST_MARK] = P.mark; }
             }
         }
     }
@@ -468,17 +459,8 @@ __device__ __forceinline__ void sample_normal_taps_shared_lds(const float *box, 
     // (delta < 1 voxel), so a select + an add replaces the multiply-add chain per tap
     const int base = t.lx * BOX_SX + t.ly * BOX_SY + t.lz;
     {   // x: two whole taps (their first lerp has its own fraction: nothing of the centre's is reusable but the voxels)
-#ifdef DR_ABL_XREUSE
-        // what-if (WRONG results): both x taps from ONE set of eight voxels, no select -- the bound for reusing the centre's voxels
-        const float v000 = box[base], v100 = box[base + BOX_SX], v010 = box[base + BOX_SY], v110 = box[base + BOX_SX + BOX_SY];
-        const float v001 = box[base + 1], v101 = box[base + BOX_SX + 1], v011 = box[base + BOX_SY + 1], v111 = box[base + BOX_SX + BOX_SY + 1];
-        const float p = mixf(mixf(mixf(v000, v100, t.fxp), mixf(v010, v110, t.fxp), t.fy), mixf(mixf(v001, v101, t.fxp), mixf(v011, v111, t.fxp), t.fy), t.fz);
-        const float m = mixf(mixf(mixf(v000, v100, t.fxm), mixf(v010, v110, t.fxm), t.fy), mixf(mixf(v001, v101, t.fxm), mixf(v011, v111, t.fxm), t.fy), t.fz);
-        dx = p - m;
-#else
         const int ip = base + ((t.lxp != t.lx) ? BOX_SX : 0), im = base - ((t.lxm != t.lx) ? BOX_SX : 0);
         dx = tri_lds(box, ip, t.fxp, t.fy, t.fz) - tri_lds(box, im, t.fxm, t.fy, t.fz);
-#endif
     }
     {   // y: the x-lerps of row ly+2 (for a +delta tap in the cell above) and of row ly-1 (a -delta tap in the cell below)
         const bool up = t.lyp != t.ly, dn = t.lym != t.ly;
@@ -566,11 +548,7 @@ __device__ __forceinline__ void load_ray(const float *entry, const float *exit_,
 constexpr float ACC_LIM = 1.0e30f;  // DOUBLE: adjoints beyond this (an overflowed loss) are clamped, NaN adjoints dropped
 __device__ __forceinline__ float acc_sanitise(float x) { return (x == x) ? fminf(fmaxf(x, -ACC_LIM), ACC_LIM) : 0.0f; }
 __device__ __forceinline__ void acc_add_f64(unsigned long long *p, float x) {
-#ifdef DR_ABL_NOATOMIC
-    asm volatile("" :: "v"(p), "v"((double)x));
-#else
     atomicAdd(reinterpret_cast<double *>(p), (double)x);  // ds_add_f64
-#endif
 }
 __device__ __forceinline__ float acc_f64_to_float(unsigned long long v) {
     return fminf(fmaxf((float)__longlong_as_double((long long)v), -3.0e38f), 3.0e38f);
@@ -637,11 +615,7 @@ __device__ __forceinline__ void fix_add_scaled(unsigned long long *p, float x, c
     // (spelled in assembly: from C the compiler turns the multiplication by 2^sh back into a sign extension + a 64-bit shift)
     unsigned long long v, carry_unused;
     asm("v_mad_i64_i32 %0, %1, %2, %3, 0" : "=v"(v), "=s"(carry_unused) : "v"(q), "s"(f.pw));
-#ifdef DR_ABL_NOATOMIC
-    asm volatile("" :: "v"(p), "v"(v));
-#else
     atomicAdd(p, v);  // ds_add_u64
-#endif
 }
 __device__ __forceinline__ float fix_to_float(unsigned long long v, const FixScale &f) {
     return (float)((double)(long long)v * f.inv);

@@ -20,111 +20,14 @@
 // Reference functions replaced: VR.py:261-372 and the autodiff twins VR.py:460-461,470-471.
 #include "dr_brick_common.h"
 #include "dr_wave.h"
+#include "dr_tuning.h"
 
 namespace dr {
 
-// What-if (WRONG results, timing only): B1 as FOUR-wave workgroups, four per CU -- the shape that was worth 15 %
-// to the TF-only backward -- with the per-brick work unchanged. The LDS it would need (<= 40 KB) is faked: the gradient box is
-// aliased into 8 KB and the d_tf table into 2 KB (addresses masked; same instructions, same number of atomics, same flush
-// traffic). An upper bound for any real small-box design, which pays for its extra bricks / passes on top.
-#ifdef DR_ABL_SMALLBOX
-#define DR_FNT_BWD 256
-#define DR_FEC_BWD 128
-#define DR_BWD_UNEVEN 0
-#define DR_DBOX_WORDS 1024
-#define DR_DBOX_IDX(i) (256 + ((i) & 255))
-#define DR_DBOX_FLUSH_IDX(i) ((i) & 1023)
-#define DR_DTF_TEXEL(t) ((t) & 63)
-#define DR_DTF_BYTES(R) ((size_t)64 * 32)
-#define DR_DTF_FLUSH_IDX(k) ((k) & 255)
-#else
-#define DR_DBOX_WORDS BOX_LDS
-#define DR_DBOX_IDX(i) (i)
-#define DR_DBOX_FLUSH_IDX(i) (i)
-#define DR_DTF_TEXEL(t) (t)
-#define DR_DTF_BYTES(R) ((size_t)(R) * 32)
-#define DR_DTF_FLUSH_IDX(k) (k)
-#endif
-#ifndef DR_FNT_BWD
-#define DR_FNT_BWD 512
-#endif
-#ifndef DR_UNLIT_SKIP
-#define DR_UNLIT_SKIP 2   // the colour march skips the segments the alpha pre-pass found unlit: 1 = non-differentiable renders, 2 = all (round 5)
-#endif
-#ifndef DR_ABL_EXTRA_LDS_BWD
-#define DR_ABL_EXTRA_LDS_BWD 0   // what-if: bytes of unused LDS per backward workgroup (fewer workgroups per CU)
-#endif
-
-#ifndef DR_BWD_WAVES
-#define DR_BWD_WAVES 4
-#endif
-#ifndef DR_FWD_WAVES
-#define DR_FWD_WAVES 5
-#endif
-#ifndef DR_FNT_FWD
-#define DR_FNT_FWD 256
-#endif
-// DR_FNT_*: threads per workgroup (forward: 30 KB of LDS, 96 VGPRs -> 5 four-wave workgroups per CU; backward with a gradient
-// box: 67 KB of LDS, 128 VGPRs -> two 8-wave workgroups per CU); gathered in FlatCfg below
-#ifndef DR_FEC_FWD
-#define DR_FEC_FWD 256
-#endif
-#ifndef DR_FEC_BWD
-#define DR_FEC_BWD 256
-#endif
-#ifndef DR_PHASE_TIMING
-#define DR_PHASE_TIMING 0
-#endif
-#ifndef DR_FWD_K
-#define DR_FWD_K 2      // forward: samples per lane at sampling rates below 1.75
-#endif
-#ifndef DR_SETPRIO
-#define DR_SETPRIO 1
-#endif
-#ifndef DR_PP_GROUPS
-#define DR_PP_GROUPS 6   // layer groups of the alpha pre-pass at sampling rates >= 3
-#endif
-#ifndef DR_PP_GROUPS_LO
-#define DR_PP_GROUPS_LO 3   // ... and below 3 under DR_HINT_EARLY_TERMINATION (round 5: 2 / 3 / 4 / 6 / 9 groups at rate 1 -- demo forward
-                            // 1.75 / 1.63 / 1.63 / 1.68 / 1.80 ms, 512^3 tf1 forward 1.54 / 1.42 / 1.43 / 1.45 / 1.51, CT-like 1.35 / 1.40 / 1.44 / 1.50 / 1.62)
-#endif
-#ifndef DR_ALPHA_K
-#define DR_ALPHA_K 4    // alpha pre-pass
-#endif
-#ifndef DR_FWD_K_HI
-#define DR_FWD_K_HI 4   // ... and at 1.75 and above
-#endif
-#ifndef DR_BWDTF_K
-#define DR_BWDTF_K 2    // backward w.r.t. the TF only (C3): consecutive samples per lane (no gradient box to feed: the
-#endif                  // per-sample state that must survive the scan is six registers)
-#ifndef DR_BWD_UNEVEN
-#define DR_BWD_UNEVEN 7   // backward: candidates dealt to a later wave for every 8 of an earlier one (0: even); 7: -1.1 %, 6: -0.5 %, 5: +2 %
-#endif
-// DR_FEC_*: ray segments listed per round (<= threads: one candidate per thread)
-// The backward w.r.t. the TF only (C3) has no gradient box, 33 KB of LDS instead of 67: FOUR-wave workgroups, four per CU
-// (the same 4 waves per SIMD its 127 VGPRs allow, but from four workgroups in different phases instead of two): 3.22 ms
-// against 3.80 with the 8-wave shape at 512^3 (same device, profiles/r03_ab_experiments.txt); 96 VGPRs for a fifth
-// workgroup spill 132 bytes per lane: 4.08 ms.
-#ifndef DR_FNT_BWDTF
-#define DR_FNT_BWDTF 256
-#endif
-#ifndef DR_FEC_BWDTF
-#define DR_FEC_BWDTF 128
-#endif
-#ifndef DR_BWDTF_WAVES
-#define DR_BWDTF_WAVES 4
-#endif
+// Workgroup shapes, samples per lane and launch grids: dr_tuning.h (every value is the measured optimum, each with its A/B row).
 // Workgroup configuration of a brick kernel: forward / alpha pre-pass / backward with a gradient box / backward w.r.t. the TF only.
 // ALPHA: 0 = not the pre-pass; 1 = the pre-pass in the forward's shape (256-entry tables, five workgroups per CU); 2 = the pre-pass
-// of HIGH sampling rates (>= 3): 192-entry tables, an alpha-only TF table (4 B per entry) and 80 VGPRs put SIX workgroups on a CU -- at rate 8 a segment holds ~400
-// samples and occupancy is what the short, latency-bound workgroups lack (demo loop 10.35 -> 10.14 ms); at rate 1 a brick's ~196
-// candidates would take two listing rounds (512^3 tf1 forward +2.5 %): same-device rows in profiles/r05_ab_experiments.txt.
-#ifndef DR_FEC_ALPHA_HI
-#define DR_FEC_ALPHA_HI 192   // (with the pre-pass's alpha-only TF table: 25.3 KB at R = 256; 160 and 208 entries within 0.4 %)
-#endif
-#ifndef DR_ALPHA_WAVES_HI
-#define DR_ALPHA_WAVES_HI 6
-#endif
+// of HIGH sampling rates (>= 3): 192-entry tables, an alpha-only TF table (4 B per entry) and 80 VGPRs put SIX workgroups on a CU.
 template <bool BWD, bool WANT_VOL, int ALPHA = 0>
 struct FlatCfg {
     static constexpr int FNT = BWD ? (WANT_VOL ? DR_FNT_BWD : DR_FNT_BWDTF) : DR_FNT_FWD;      // threads per workgroup
@@ -159,7 +62,7 @@ template <bool BWD>
 __host__ __device__ constexpr size_t flat_fixed_bytes(bool want_vol, int alpha = 0) {
     const int EC = want_vol ? FlatCfg<BWD, true>::EC : (alpha == 2 ? FlatCfg<BWD, false, 2>::EC : FlatCfg<BWD, false>::EC);
     size_t s = ((size_t)BOX_LDS * 4 + 15) / 16 * 16;
-    if (BWD && want_vol) s += ((size_t)DR_DBOX_WORDS * 8 + 15) / 16 * 16;
+    if (BWD && want_vol) s += ((size_t)BOX_LDS * 8 + 15) / 16 * 16;
     s += (size_t)EC * 32;
     s += (size_t)EC * 4 + (((size_t)EC + 8) * 4 + 15) / 16 * 16 + (size_t)EC * 4 + (size_t)EC * 4;  // s_rel, offs, valid, slen
     s += (size_t)EC * 4;  // segi
@@ -169,7 +72,7 @@ __host__ __device__ constexpr size_t flat_fixed_bytes(bool want_vol, int alpha =
 }
 template <bool BWD>
 __host__ __device__ inline size_t flat_lds_bytes(int R, bool want_vol, bool want_tf, int alpha = 0) {
-    return flat_fixed_bytes<BWD>(want_vol, alpha) + (alpha ? align16((size_t)R * 4) : (size_t)R * 16) + ((BWD && want_tf) ? (want_vol ? DR_DTF_BYTES(R) : (size_t)R * 32) : 0);
+    return flat_fixed_bytes<BWD>(want_vol, alpha) + (alpha ? align16((size_t)R * 4) : (size_t)R * 16) + ((BWD && want_tf) ? (size_t)R * 32 : 0);
 }
 template <bool BWD, bool WANT_VOL, bool WANT_TF, int ALPHA = 0>
 __device__ __forceinline__ FlatLds flat_carve(unsigned char *smem, int R) {
@@ -178,7 +81,7 @@ __device__ __forceinline__ FlatLds flat_carve(unsigned char *smem, int R) {
     size_t o = 0;
     L.box = reinterpret_cast<float *>(smem + o); o += align16(BOX_LDS * 4);
     L.dbox = nullptr; L.dtf = nullptr; L.live = nullptr;
-    if (BWD && WANT_VOL) { L.dbox = reinterpret_cast<unsigned long long *>(smem + o); o += align16(DR_DBOX_WORDS * 8); }
+    if (BWD && WANT_VOL) { L.dbox = reinterpret_cast<unsigned long long *>(smem + o); o += align16(BOX_LDS * 8); }
     L.ray0 = reinterpret_cast<float4 *>(smem + o); o += (size_t)EC * 16;
     L.ray1 = reinterpret_cast<float4 *>(smem + o); o += (size_t)EC * 16;
     L.s_rel = reinterpret_cast<int *>(smem + o); o += (size_t)EC * 4;
@@ -678,9 +581,6 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
     // words of the rays' "unlit" layer masks this pass may use (uniform): the forward's own; for the d_volume-only backward what the
     // forward LEFT (header word ST_MASKS, written with the fingerprint checked above), for every other backward none
     const int lmw = BWD ? ((WANT_VOL && !WANT_TF && P.lm_words > 0 && (int)P.stats[ST_MASKS] == P.lm_words) ? P.lm_words : 0) : P.lm_words;
-#if DR_PHASE_TIMING == 3
-    const long long tq0 = clock64();
-#endif
     // backward: records, flags, items and coarse tape are only touched if THIS call's forward wrote them (ws_fingerprint)
     if (BWD && P.stats[ST_MARK] != P.mark) return;  // uniform; B2 then marches every ray
     const f3 cam = make_f3(P.cam[3 * view], P.cam[3 * view + 1], P.cam[3 * view + 2]);
@@ -692,16 +592,14 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
         if (P.vflags[P.n_views + view] ? !P.pp_first : (c.layer < P.pp_l0 || c.layer >= P.pp_l1)) return;
     }
     // backward after a flat forward: bricks in which the forward marched nothing (rays terminated before them) have no work
-    if (BWD && !DR_PHASE_TIMING && c.live == 0) return;  // uniform
+    if (BWD && c.live == 0) return;  // uniform
     // ... and bricks the forward found EMPTY (no sample composites: every TF texel their voxels can index has alpha exactly 0) give
     // d_volume nothing: a sample's intensity adjoint is r_bar (r_hi - r_lo) + ... + a_bar (a_hi - a_lo) with r/g/b_bar = L op T go = 0
     // and a_hi = a_lo = 0, its normal-path adjoint carries the factor op = 0. (d_tf is another matter: alpha = 0 has a slope, the
     // air's texels collect a_bar from every such sample -- with a TF gradient wanted the brick is marched like any other.)
-    if (BWD && WANT_VOL && !WANT_TF && !DR_PHASE_TIMING && (c.maybe_empty & 2) != 0) return;  // uniform
+    if (BWD && WANT_VOL && !WANT_TF && (c.maybe_empty & 2) != 0) return;  // uniform
 
-#if DR_SETPRIO
     __builtin_amdgcn_s_setprio(3);  // the staging / listing prologue is short and latency-bound: let it overtake sample loops
-#endif
     FlatLds L = flat_carve<BWD, WANT_VOL, WANT_TF, ALPHA>(smem, P.R);
     VolView<VT> vol = P.vol;
     vol.p += view * P.vol_vs;
@@ -710,10 +608,6 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
     const int ncand_all = (c.i1 - c.i0 + 1) * (c.j1 - c.j0 + 1);
     const int ncand = min(ncand_all, c_hi);  // this item's candidates: [c_lo, ncand)
     if (c_lo >= ncand) return;               // uniform
-#if DR_PHASE_TIMING
-    const long long tk0 = clock64();
-    long long tk2 = 0;
-#endif
     // The rounds run over candidate indices [r_lo, r_hi). An overflow item of a heavy brick first puts its candidates through
     // the geometric pre-test (most of the bounding rectangle of a brick next to the eye are pixels whose lines miss it) and
     // runs its rounds over the compacted list of hits, in LDS behind the regular layout; no hit, no work.
@@ -749,9 +643,6 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
         r_lo = 0; r_hi = *nhit;
         if (r_hi == 0) return;  // uniform
     }
-#if DR_PHASE_TIMING == 3
-    const long long tq1 = clock64();   // (the brick record has arrived: c.i0 .. were compared above)
-#endif
     // A work item that follows another item of the same brick in its workgroup finds the voxel box (and the TF) in LDS already.
     // (Forward and pre-pass only: the backward's gradient box is flushed per item.)
     const bool reuse_box = HEAVY && !BWD && box_valid != 0;  // uniform
@@ -773,8 +664,8 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
         if (BWD && WANT_VOL) cand_grad_range<VT, FNT>(P, c, view, r_lo, r_hi, hits, c_lo, ncand_all, gm, gn);  // upstream gradients of the candidates,
         if (!reuse_box) box_issue<VT, FNT, ALPHA != 0>(P, vol, c, P.tf + view * P.tf_vs, stage);      // voxel box + TF: in flight ...
         if (BWD) {
-            if (WANT_VOL) for (int k = threadIdx.x; k < DR_DBOX_WORDS; k += FNT) L.dbox[k] = 0ull;
-            if (WANT_TF) for (int k = threadIdx.x; k < (WANT_VOL ? (int)(DR_DTF_BYTES(P.R) / 8) : 4 * P.R); k += FNT) L.dtf[k] = 0ull;
+            if (WANT_VOL) for (int k = threadIdx.x; k < BOX_LDS; k += FNT) L.dbox[k] = 0ull;
+            if (WANT_TF) for (int k = threadIdx.x; k < 4 * P.R; k += FNT) L.dtf[k] = 0ull;
             if (WANT_VOL) {
                 gm = wave_max_f(gm); gn = wave_min_f(gn);
                 if ((threadIdx.x & 63) == 0) { L.gmax[threadIdx.x >> 6] = gm; L.gmax[8 + (threadIdx.x >> 6)] = gn; }
@@ -782,26 +673,11 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
         }
         flat_build_entries<VT, MODE, BWD, WANT_VOL, ALPHA, KS>(P, c, cam, view, cd, L, nE0, M0, live_flag, count_stats, lmw);  // ... while the segments are listed
     }
-#if DR_PHASE_TIMING == 3
-    const long long tq2 = clock64();   // candidates loaded and listed
-#endif
     if (!reuse_box) box_commit<VT, FNT, ALPHA != 0>(P, vol, c, P.tf + view * P.tf_vs, stage, L);
     const bool test_empty = !BWD && !TAPE && !reuse_box && (c.maybe_empty & 1) != 0;  // uniform
     if constexpr (!BWD) { if (test_empty) brick_empty_publish<FNT>(stage, L); }
     if (!reuse_box) box_valid = 1;
-#if DR_PHASE_TIMING == 3
-    const long long tq3 = clock64();   // box arrived and stored
-#endif
     __syncthreads();
-#if DR_PHASE_TIMING == 3
-    if (!BWD && !ALPHA && threadIdx.x == 0) {  // forward prologue, thread 0 (tools/phase_times.py)
-        unsigned long long *tt = reinterpret_cast<unsigned long long *>(P.stats + ST_TIMING);
-        atomicAdd(tt + 0, (unsigned long long)(tq1 - tq0));
-        atomicAdd(tt + 1, (unsigned long long)(tq2 - tq1));
-        atomicAdd(tt + 2, (unsigned long long)(tq3 - tq2));
-        atomicAdd(tt + 3, (unsigned long long)(clock64() - tq3));
-    }
-#endif
     bool brick_empty = false;  // uniform: no sample of this brick composites anything (forward passes only)
     if constexpr (!BWD) {
         if (test_empty) {
@@ -827,12 +703,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
         fs = make_fix_scale(gm);
         if (acc64 && threadIdx.x == 0) atomicAdd(&P.stats[ST_F64_BRICKS], 1u);
     }
-#if DR_PHASE_TIMING
-    const long long tk1 = clock64();
-#endif
-#if DR_SETPRIO
     __builtin_amdgcn_s_setprio(0);
-#endif
     const f3 light = make_f3(cam.x + 0.0f, cam.y + 1.0f, cam.z + 0.0f);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     bool any = false;
@@ -880,9 +751,6 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
             }
         }
         const int fa = 0, fb = skip_loop ? 0 : M;
-#if DR_PHASE_TIMING
-        if (cbase == 0) tk2 = clock64();
-#endif
         Over carry = {0.f, 0.f, 0.f, 0.f};
         Over2 carry2 = {0.f, 0.f};  // the backward's pair (gC . C, A)
         int carry_e = -1;  // entry whose composite so far is in `carry` (continues into the next chunk)
@@ -1224,13 +1092,6 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                     }
                     vm_fwd[j] = __ballot(vj);
                     tm_fwd[j] = __ballot(lit && (!TAPE || ej.a != 0.0f) && ej.a < DR_D4_TINY_OP);   // (ej.a = the opacity of a lit sample)
-#ifdef DR_LANE_STATS
-                    if (lane == 0 && j < ks) {  // lane slots issued / holding a listed sample / holding an in-brick sample
-                        atomicAdd(reinterpret_cast<unsigned long long *>(P.stats + ST_TIMING + 32), 64ull);
-                        atomicAdd(reinterpret_cast<unsigned long long *>(P.stats + ST_TIMING + 34), (unsigned long long)__popcll(__ballot(actj)));
-                        atomicAdd(reinterpret_cast<unsigned long long *>(P.stats + ST_TIMING + 36), (unsigned long long)__popcll(vm_fwd[j]));
-                    }
-#endif
                     el = (j == 0) ? ej : over(el, ej);  // over(x, 0) == x exactly
                 }
             }
@@ -1295,12 +1156,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                     const float suffix = ((go.x * of.x + go.y * of.y + go.z * of.z) - absw) + go.w * (of.w - absa);
                     sample_adjoint<true>(sm, vd, T, suffix, last, go, P.inv_sr, ad);
                 }
-#ifdef DR_ABL_NOSCATTER
-                asm volatile("" :: "v"(ad.r_bar), "v"(ad.g_bar), "v"(ad.b_bar), "v"(ad.a_bar), "v"(ad.gx), "v"(ad.gy), "v"(ad.gz));
-                if (false) {
-#else
                 if (WANT_TF) {
-#endif
                     // neighbouring lanes are consecutive samples of a ray: long runs fall between the same two
                     // texels. Sum each run across lanes (DPP) and let its last lane do the eight LDS adds. Runs stop
                     // at segment boundaries, so the upstream colour gradient go.xyz is constant over a run and
@@ -1325,7 +1181,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                     // d_tf accumulates in double; a NaN or an absurd run total takes the sanitising path
                     if (__any(emit && !(vmax <= ACC_LIM))) {
                         if (emit) {
-                            unsigned long long *d0 = L.dtf + 4 * DR_DTF_TEXEL(sm.lo), *d1 = L.dtf + 4 * DR_DTF_TEXEL(sm.hi);
+                            unsigned long long *d0 = L.dtf + 4 * sm.lo, *d1 = L.dtf + 4 * sm.hi;
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 acc_add_f64(d0 + q, acc_sanitise(v8[q]));
@@ -1333,7 +1189,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                             }
                         }
                     } else if (emit) {
-                        unsigned long long *d0 = L.dtf + 4 * DR_DTF_TEXEL(sm.lo), *d1 = L.dtf + 4 * DR_DTF_TEXEL(sm.hi);
+                        unsigned long long *d0 = L.dtf + 4 * sm.lo, *d1 = L.dtf + 4 * sm.hi;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             acc_add_f64(d0 + q, v8[q]);
@@ -1341,16 +1197,12 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                         }
                     }
                 }
-#ifdef DR_ABL_NOSCATTER
-                if (false) {
-#else
                 if (WANT_VOL) {
-#endif
                     // d_volume: fixed-point adds into the LDS gradient box (dr_brick_common.h). A 32-bit addend
                     // suffices unless some adjoint of the wave exceeds 2^31 / 2^shift (then: exact wide path).
                     // the 24 tap coordinates are cheap to rebuild from the position (45 VALU) and expensive to keep
                     // alive across shading and the adjoint (the kernel is register-bound: spills go to scratch)
-                    const int cbase_i = valid ? DR_DBOX_IDX(t.lx * BOX_SX + t.ly * BOX_SY + t.lz) : 0;
+                    const int cbase_i = valid ? (t.lx * BOX_SX + t.ly * BOX_SY + t.lz) : 0;
                     float I_bar = 0.f;
                     float gq[3] = {0.f, 0.f, 0.f};
                     if (valid) {
@@ -1424,33 +1276,8 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
         if (n_eval != 0u && lane == 0)
             atomicAdd(reinterpret_cast<unsigned long long *>(P.stats + (BWD ? ST_EVAL_BWD : (ALPHA ? ST_EVAL_PRE : ST_EVAL_FWD))), (unsigned long long)n_eval);
     }
-#if DR_PHASE_TIMING == 2
-    if (BWD && lane == 0)  // sample-loop time of each of the workgroup's waves (slot = wave)
-        atomicAdd(reinterpret_cast<unsigned long long *>(P.stats + ST_TIMING) + (wave & 7), (unsigned long long)(clock64() - tk2));
-#elif DR_PHASE_TIMING == 1
-    if (!ALPHA && threadIdx.x == 0) {  // per-phase clocks of this workgroup, summed over the grid (tools/phase_times.py)
-        const long long tk3 = clock64();
-        unsigned long long *tt = reinterpret_cast<unsigned long long *>(P.stats + ST_TIMING) + (BWD ? 3 : 0);
-        atomicAdd(tt + 0, (unsigned long long)(tk1 - tk0));   // staging: candidate + box loads, first segment listing
-        atomicAdd(tt + 1, (unsigned long long)(tk2 - tk1));   // wave split
-        atomicAdd(tt + 2, (unsigned long long)(tk3 - tk2));   // sample loop (+ further rounds)
-    }
-#endif
     if (!BWD) return;
-#if DR_PHASE_TIMING == 1
-    const long long tk4 = clock64();
-#endif
-#ifdef DR_ABL_NOBARRIER
-    return;  // what-if (wrong results): every wave leaves after its own samples -- no wait for the slowest wave, no flush
-#endif
     if (!__syncthreads_or(any)) return;  // uniform; also: every wave's LDS adds are done before the flush
-#ifdef DR_ABL_NOFLUSH
-    return;  // what-if (wrong results): the wait for the slowest wave stays, the flush goes
-#endif
-#if DR_PHASE_TIMING == 1
-    if (threadIdx.x == 0)  // wave 0 waiting for the slowest wave of the workgroup
-        atomicAdd(reinterpret_cast<unsigned long long *>(P.stats + ST_TIMING) + 7, (unsigned long long)(clock64() - tk4));
-#endif
     // flush: one pass of global float atomics per brick, walking the gradient's fastest axis
     if (WANT_VOL) {
         GradView dv = P.dvol;
@@ -1462,11 +1289,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
             for (int r = row; r < BOX * BOX; r += FNT / 16) {
                 int b, d;
                 box_row(r, b, d);
-                const unsigned long long raw = L.dbox[DR_DBOX_FLUSH_IDX(a * w.la + b * w.lb + d * w.ld)];
-#ifdef DR_ABL_SMALLBOX
-                // (the aliased what-if box holds garbage in elements that lie outside the volume: keep the flush inside it)
-                if (!((unsigned)(w.oa + a) < (unsigned)w.Va && (unsigned)(w.ob + b) < (unsigned)w.Vb && (unsigned)(w.od + d) < (unsigned)w.Vd)) continue;
-#endif
+                const unsigned long long raw = L.dbox[a * w.la + b * w.lb + d * w.ld];
                 if (raw != 0ull)  // in range whenever raw != 0
                     atomic_add_sat(base + (a * w.ga + b * w.gb + d * w.gd), acc64 ? acc_f64_to_float(raw) : fix_to_float(raw, fs));
             }
@@ -1475,65 +1298,23 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
     if (WANT_TF) {
         float *dtf = P.d_tf + view * P.dtf_vs * 4;
         for (int k = threadIdx.x; k < 4 * P.R; k += FNT) {
-            const unsigned long long raw = L.dtf[WANT_VOL ? DR_DTF_FLUSH_IDX(k) : k];
+            const unsigned long long raw = L.dtf[k];
             if (raw != 0ull) atomic_add_sat(dtf + k, acc_f64_to_float(raw));
         }
     }
-#if DR_PHASE_TIMING == 1
-    __syncthreads();
-    if (threadIdx.x == 0)  // whole lifetime of a backward workgroup, gradient flush included
-        atomicAdd(reinterpret_cast<unsigned long long *>(P.stats + ST_TIMING) + 6, (unsigned long long)(clock64() - tk0));
-#endif
 }
 
-#ifndef DR_ITEM_GRID_FWD
-#define DR_ITEM_GRID_FWD 1280
-#endif
-#ifndef DR_ITEM_GRID_BWD
-#define DR_ITEM_GRID_BWD 512
-#endif
 // workgroups of the overflow launch (they loop over the items): what is resident at once on 256 CUs -- a workgroup that starts
 // only after another has left would work off its first, statically assigned run of items at the very end
 constexpr int ITEM_GRID_FWD = DR_ITEM_GRID_FWD, ITEM_GRID_BWD = DR_ITEM_GRID_BWD;
-#ifndef DR_ITEM_RUN
-#define DR_ITEM_RUN 2   // camera inside a 512^3 volume, fwd / bwd ms: static striding 11.3 / 19.8; runs of 1: 10.0 / 17.9, 2: 9.2 / 16.2, 3: 9.3 / 16.5, 4: 9.9 / 17.4, 8: 13.2 / 22.6
-#endif
 constexpr int ITEM_RUN = DR_ITEM_RUN;   // consecutive items a workgroup takes at a time
 
 template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, int ALPHA = 0, int KF = 1, bool NARROW = true, bool TAPE = false>
 __global__ __launch_bounds__((FlatCfg<BWD, WANT_VOL, ALPHA>::FNT), (FlatCfg<BWD, WANT_VOL, ALPHA>::WAVES)) void brick_flat_kernel(BrickParams<VT> P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-#ifdef DR_VIEW_FASTEST
-    // (tried: consecutive workgroups = the same brick of consecutive views, so that the box comes from L2 after its first
-    // read -- 2 % slower with 8 views, 13 % on the demo loop)
-    const int nv = P.n_views;
-    int bv = 0;
-    brick_flat_body<VT, MODE, BWD, WANT_VOL, WANT_TF, ALPHA, KF, false, NARROW>(P, smem, blockIdx.x / nv, blockIdx.x % nv, 0, MAIN_CAND, bv);
-#else
     int bv = 0;
     brick_flat_body<VT, MODE, BWD, WANT_VOL, WANT_TF, ALPHA, KF, false, NARROW, TAPE>(P, smem, blockIdx.x, blockIdx.y,
                                                                                      0, MAIN_CAND, bv);
-#endif
-}
-// Tuning experiment (right results): the main launch as a RESIDENT grid -- DR_F1_RESIDENT workgroups that draw
-// (view, brick) slots near-first through a ticket instead of one workgroup per slot -- against the ramp / drain of 8.3 rounds of
-// workgroups at 256^3. Forward march only (not the pre-pass, not the backward).
-#ifndef DR_F1_RESIDENT
-#define DR_F1_RESIDENT 0
-#endif
-template <typename VT, int MODE, int KF, bool NARROW>
-__global__ __launch_bounds__((FlatCfg<false, false>::FNT), (FlatCfg<false, false>::WAVES)) void brick_flat_resident_kernel(BrickParams<VT> P, int nbricks, int total) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ int s_next;
-    for (int slot = blockIdx.x; slot < total;) {  // uniform
-        int bv = 0;
-        brick_flat_body<VT, MODE, false, false, false, false, KF, false, NARROW>(P, smem, slot % nbricks, slot / nbricks, 0, MAIN_CAND, bv);
-        __syncthreads();
-        if (threadIdx.x == 0) s_next = (int)gridDim.x + (int)atomicAdd(&P.stats[ST_TICKET_MAIN], 1u);
-        __syncthreads();
-        slot = s_next;
-    }
-    if (threadIdx.x == 0 && atomicAdd(&P.stats[ST_DONE_MAIN], 1u) == gridDim.x - 1) { P.stats[ST_TICKET_MAIN] = 0u; P.stats[ST_DONE_MAIN] = 0u; }
 }
 // the overflow items of heavy bricks (all views), worked off by a fixed, small grid
 template <typename VT, int MODE, bool BWD, bool WANT_VOL, bool WANT_TF, int ALPHA = 0, int KF = 1, bool NARROW = true, bool TAPE = false>
@@ -1603,30 +1384,12 @@ static inline bool taps_narrow(const MarchArgs &a) {
     const int m = a.VX > a.VY ? (a.VX > a.VZ ? a.VX : a.VZ) : (a.VY > a.VZ ? a.VY : a.VZ);
     return m - 1 <= 990;   // delta = 1e-3 world units = 1e-3 * (m - 1) / 2 voxels <= 0.495
 }
-#ifdef DR_VIEW_FASTEST
-#define DR_GRID1 dim3(grid1.x * grid1.y)
-#else
-#define DR_GRID1 grid1
-#endif
 // one pass over the bricks: the main launch (one workgroup per brick and view) + the overflow items of heavy bricks
-#ifndef DR_ABL_EXTRA_LDS_ALPHA
-#define DR_ABL_EXTRA_LDS_ALPHA 0   // what-if: bytes of unused LDS per workgroup of the alpha pre-pass (fewer workgroups per CU)
-#endif
-#ifdef DR_ABL_NOITEMS   // what-if (WRONG results when heavy bricks exist): the work-item launch is never issued
-#define DR_ABL_NOITEMS_ 1
-#else
-#define DR_ABL_NOITEMS_ 0
-#endif
 #define DR_LAUNCH_BOTH_N(MODE_, BWD_, VOL_, TF_, ALPHA_, K_, NT_, NARROW_)                                                             \
     {                                                                                                                                 \
         if ((e = allow_lds(brick_flat_kernel<VT, MODE_, BWD_, VOL_, TF_, ALPHA_, K_, NARROW_>, lds)) != hipSuccess) return (int)e;    \
         if ((e = allow_lds(brick_flat_items_kernel<VT, MODE_, BWD_, VOL_, TF_, ALPHA_, K_, NARROW_>, align16(lds) + ITEM_EXTRA_LDS)) != hipSuccess) return (int)e; \
-        if constexpr (DR_F1_RESIDENT > 0 && !(BWD_) && !(ALPHA_)) {                                                                   \
-            const int total_ = (int)(grid1.x * grid1.y);                                                                              \
-            hipLaunchKernelGGL((brick_flat_resident_kernel<VT, MODE_, K_, NARROW_>), dim3(total_ < DR_F1_RESIDENT ? total_ : DR_F1_RESIDENT), dim3(NT_), lds, stream, P, (int)grid1.x, total_); \
-        } else                                                                                                                        \
-        hipLaunchKernelGGL((brick_flat_kernel<VT, MODE_, BWD_, VOL_, TF_, ALPHA_, K_, NARROW_>), DR_GRID1, dim3(NT_), lds + ((ALPHA_) ? DR_ABL_EXTRA_LDS_ALPHA : 0), stream, P);         \
-        if (!DR_ABL_NOITEMS_)                                                                                                         \
+        hipLaunchKernelGGL((brick_flat_kernel<VT, MODE_, BWD_, VOL_, TF_, ALPHA_, K_, NARROW_>), grid1, dim3(NT_), lds, stream, P);         \
         hipLaunchKernelGGL((brick_flat_items_kernel<VT, MODE_, BWD_, VOL_, TF_, ALPHA_, K_, NARROW_>), dim3(BWD_ ? (VOL_ ? ITEM_GRID_BWD : 2 * ITEM_GRID_BWD) : ITEM_GRID_FWD), dim3(NT_), align16(lds) + ITEM_EXTRA_LDS, stream, P); \
     }
 // NARROW (delta below half a voxel: every edge <= 991 voxels) selects the cheaper shared-lerp taps (dr_brick_common.h); the alpha
@@ -1646,7 +1409,7 @@ template <typename VT>
 int flat_bwd_vol_launch(const MarchArgs &a, BrickParams<VT> P, dim3 grid1, bool want_tf, hipStream_t stream) {
     hipError_t e = hipSuccess;
     // (the LDS size is this translation unit's own: tuning / what-if switches may be given to it alone, tools/mkvariant.sh BWDVOL_EXTRA)
-    const size_t lds = flat_lds_bytes<true>(a.R, true, want_tf) + DR_ABL_EXTRA_LDS_BWD;
+    const size_t lds = flat_lds_bytes<true>(a.R, true, want_tf);
     if (want_tf) DR_LAUNCH_BOTH(DR_MODE_DIFF, true, true, true, false, 1, (FlatCfg<true, true>::FNT))
     else DR_LAUNCH_BOTH(DR_MODE_DIFF, true, true, false, false, 1, (FlatCfg<true, true>::FNT))
     return (int)hipGetLastError();
@@ -1668,13 +1431,6 @@ static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     BrickParams<VT> P = make_brick_params<VT>(a, w);
     P.tape = w.tape; P.tape_stride = tstride;
     hipError_t e;
-#if DR_PHASE_TIMING
-    if ((e = hipMemsetAsync(w.stats + ST_TIMING, 0, 64, stream)) != hipSuccess) return (int)e;  // the timing slots
-#endif
-#ifdef DR_ABL_NOMEMSET
-    // what-if (WRONG results unless the caller zeroed the workspace): the bound for folding the count memset into another kernel
-    e = hipSuccess;
-#else
     // Non-differentiable render with an alpha pre-pass: the pre-pass tells the colour march which (ray, layer) segments hold no
     // sample with alpha > 1e-3 ("unlit" masks behind seg_cnt, BrickParams::unlit); such segments keep the pre-pass's count and
     // zero partial, so seg_cnt is NOT cleared between the two passes (see below).
@@ -1683,7 +1439,6 @@ static int flat_fwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     P.lm_words = unlit_masks ? w.lm_words : 0;
     // the item counter (brick_ctx_kernel appends) and seg_cnt behind it (and the masks behind that)
     e = hipMemsetAsync(w.n_items, 0, 16 + (unlit_masks ? align16(w.cnt_bytes) + w.unlit_bytes : w.cnt_bytes), stream);
-#endif
     if (e != hipSuccess) return (int)e;
     const size_t lds = flat_lds_bytes<false>(a.R, false, false);
     const int nbricks = g.NBx * g.NBy * g.NBz;
@@ -1803,7 +1558,7 @@ static int flat_bwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     if (!a.workspace || a.workspace_bytes < need) return DR_EINVAL;
     BrickParams<VT> P = make_brick_params<VT>(a, w);
     P.lm_words = (wv && !wt && DR_UNLIT_SKIP > 1) ? w.lm_words : 0;   // the d_volume-only backward may skip unlit segments (if the forward left masks)
-    const size_t lds = flat_lds_bytes<true>(a.R, wv, wt) + DR_ABL_EXTRA_LDS_BWD;
+    const size_t lds = flat_lds_bytes<true>(a.R, wv, wt);
     const dim3 grid1(g.NBx * g.NBy * g.NBz, a.n_views);
     hipError_t e = hipSuccess;
     // (the brick records, live flags and work items are the forward's: same inputs, same workspace)

@@ -12,6 +12,7 @@
 // Reference functions replaced: get_final_image[_nondiff] (VR.py:353-372) and the early-termination test of
 // raycast / raycast_nondiff (VR.py:267,318).
 #include "dr_brick_common.h"
+#include "dr_tuning.h"
 
 namespace dr {
 
@@ -83,9 +84,6 @@ __global__ __launch_bounds__(256) void ray_compose_kernel(BrickParams<VT> P) {
             // (four layers per step, their loads issued together: the walk is a chain of memory latencies otherwise)
             int total = 0;
             D4Bound b0 = d4_zero(), b1 = d4_zero(), b2 = d4_zero(), b3 = d4_zero();   // D4 bounds of the four channels (dr_brick_common.h)
-#ifndef DR_F2_WIDE
-#define DR_F2_WIDE 4   // layers per step of the walk
-#endif
 
             constexpr int FW = DR_F2_WIDE;
             for (int l = 0; l <= l_hi; l += FW) {
@@ -115,9 +113,6 @@ __global__ __launch_bounds__(256) void ray_compose_kernel(BrickParams<VT> P) {
                     }
                     d4_risk(C0, T * sg[k].x, cf, rcf, tiny, b0); d4_risk(C1, T * sg[k].y, cf, rcf, tiny, b1);
                     d4_risk(C2, T * sg[k].z, cf, rcf, tiny, b2); d4_risk(A, T * sg[k].w, cf, rcf, tiny, b3);
-#ifdef DR_D4_DEBUG   // (the pixel to trace: workspace header word ST_TIMING, set by tools/d4_terms_probe.py; -1 = none)
-                    if (pl == (int)P.stats[ST_TIMING] && view == 0) printf("l %d cnt %d tiny %g sg %g %g %g %g pre %g %g %g %g lin %g %g %g %g sq %g %g %g %g\n", l + k, cnt[k], tiny, sg[k].x, sg[k].y, sg[k].z, sg[k].w, C0, C1, C2, A, b0.lin, b1.lin, b2.lin, b3.lin, b0.sq, b1.sq, b2.sq, b3.sq);
-#endif
                     C0 = fmaf(T, sg[k].x, C0); C1 = fmaf(T, sg[k].y, C1); C2 = fmaf(T, sg[k].z, C2);
                     A = fmaf(T, sg[k].w, A);
                     total += cnt[k];
@@ -129,15 +124,6 @@ __global__ __launch_bounds__(256) void ray_compose_kernel(BrickParams<VT> P) {
                 if (MODE == DR_MODE_DIFF) P.fin[p] = make_float4(C0, C1, C2, A);   // what the stored prefixes add up to: the backward's "final"
                 const float e0 = b0.total(), e1 = b1.total(), e2 = b2.total(), e3 = b3.total();
                 want_exact = fmaxf(fmaxf(e0, e1), fmaxf(e2, e3)) > DR_D4_BUDGET || nmarch > DR_D4_LONG_RAY;
-#ifdef DR_D4_DEBUG   // (tools/d4_bound_probe.py: the image holds the four bounds instead of the composite, nothing is recomputed)
-                want_exact = false;
-                {   // the channel with the largest bound: (linear part, quadrature part, total, channel)
-                    const D4Bound *bb[4] = {&b0, &b1, &b2, &b3};
-                    int km = 0;
-                    for (int q = 1; q < 4; ++q) if (bb[q]->total() > bb[km]->total()) km = q;
-                    C0 = bb[km]->lin; C1 = 2.0f * sqrtf(bb[km]->sq); C2 = bb[km]->total(); A = (float)km;
-                }
-#endif
             }
         }
         if (!regular) {
@@ -301,18 +287,12 @@ __device__ __forceinline__ float cross_opacity(const BrickParams<VT> &P, const V
 // is monotone in op_s). These are the rays that get here -- the re-associated alpha crossed, the sequential
 // one does not -- and they then march to their last sample: if even the largest opacity of a pass leaves A
 // unchanged, so do all 64.
-#ifndef DR_CROSS_BATCH
-#define DR_CROSS_BATCH 4   // 64-sample passes whose gathers are in flight together (8 and 16: no faster -- the walk is VALU-bound)
-#endif
 template <typename VT, int MODE>
 __device__ __forceinline__ int cross_exact_walk(const BrickParams<VT> &P, const VolView<VT> &vol, const float4 *lds_tf, const RayGeom &rg,
                                                 f3 cam, int nmarch, int lane) {
     float A = 0.0f;
     int s = 0;
     bool done = false;
-#ifdef DR_CROSS_STATS
-    const long long tx0 = clock64();
-#endif
     constexpr int CB = DR_CROSS_BATCH;
     for (int base = 0; base < nmarch && !done; base += 64 * CB) {  // uniform
         float op4[CB];
@@ -325,14 +305,8 @@ __device__ __forceinline__ int cross_exact_walk(const BrickParams<VT> &P, const 
             float opmax = op4[j];
             for (int o = 32; o > 0; o >>= 1) opmax = fmaxf(opmax, __shfl_xor(opmax, o));
             if (A < 0.99f && fmaf(1.0f - A, opmax, A) == A) {  // uniform
-#ifdef DR_CROSS_STATS
-                if (lane == 0) atomicAdd(&P.stats[ST_TIMING + 18], 1u);
-#endif
                 s += cnt; continue;
             }
-#ifdef DR_CROSS_STATS
-            if (lane == 0) atomicAdd(&P.stats[ST_TIMING + 19], 1u);
-#endif
             if (cnt == 64) {
                 // A whole pass without looking at the threshold: alpha never decreases, so if it is still below 0.99
                 // after the 64th sample it was below it before every one of them -- the same 64 roundings as the
@@ -352,15 +326,6 @@ __device__ __forceinline__ int cross_exact_walk(const BrickParams<VT> &P, const 
             }
         }
     }
-#ifdef DR_CROSS_STATS
-    if (lane == 0) {
-        const unsigned long long dt = (unsigned long long)(clock64() - tx0);
-        atomicAdd(reinterpret_cast<unsigned long long *>(P.stats + ST_TIMING + 24), dt);       // ticks in the exact walk, all rays
-        atomicMax(reinterpret_cast<unsigned long long *>(P.stats + ST_TIMING + 26), dt);       // ... the longest one
-        atomicAdd(&P.stats[ST_TIMING + 17], 1u);
-        atomicAdd(reinterpret_cast<unsigned long long *>(P.stats + ST_TIMING + 20) + 1, (unsigned long long)s);
-    }
-#endif
     return s;
 }
 
@@ -409,15 +374,6 @@ __global__ __launch_bounds__(256) void ray_cross_kernel(BrickParams<VT> P) {
         // decided at A (>= 0.99, or the ray ran out of samples) with A_prev (< 0.99) before it
         const float band = 2e-6f + parked.z + (float)n_tiny * 3.0e-8f;
         bool ambiguous = fabsf(A - 0.99f) < band || fabsf(A_prev - 0.99f) < band;
-#ifdef DR_CROSS_STATS
-        if (lane == 0) {  // diagnostics (tools/cross_stats.py): rays resolved, rays that needed the exact restart, samples walked
-            atomicAdd(&P.stats[ST_TIMING + 16], 1u);
-            atomicAdd(reinterpret_cast<unsigned long long *>(P.stats + ST_TIMING + 20), (unsigned long long)(s - __float_as_int(parked.y)));
-        }
-#endif
-#ifdef DR_CROSS_NORESTART
-        ambiguous = false;  // (timing experiment only: wrong decisions for ambiguous rays)
-#endif
         if (ambiguous) s = cross_exact_walk<VT, MODE>(P, vol, lds_tf, rg, cam, nmarch, lane);  // ---- round 1
         if (lane == 0) P.ws_steps[p] = s;
     }
@@ -487,15 +443,6 @@ __global__ __launch_bounds__(256) void ray_cross_quad_kernel(BrickParams<VT> P) 
         // decided at A (>= 0.99, or the ray ran out of samples) with A_prev (< 0.99) before it
         const float band = 2e-6f + parked.z + (float)n_tiny * 3.0e-8f;
         bool ambiguous = act && (fabsf(A - 0.99f) < band || fabsf(A_prev - 0.99f) < band);
-#ifdef DR_CROSS_STATS
-        if (act && rl == 0) {
-            atomicAdd(&P.stats[ST_TIMING + 16], 1u);
-            atomicAdd(reinterpret_cast<unsigned long long *>(P.stats + ST_TIMING + 20), (unsigned long long)(s - __float_as_int(parked.y)));
-        }
-#endif
-#ifdef DR_CROSS_NORESTART
-        ambiguous = false;
-#endif
         const unsigned long long ambm = __ballot(ambiguous);
         if (ambm != 0ull) {  // wave-uniform, rare
             for (int r = 0; r < 4; ++r) {
@@ -629,9 +576,6 @@ int launch_ray_compose(const MarchArgs &a, hipStream_t stream) {
 
 // F3: the rays F2 listed, if any -- a resident grid that reads the count from the workspace header and leaves at once when it is 0
 // (what every forward pays: one small launch)
-#ifndef DR_EXACT_GRID
-#define DR_EXACT_GRID 1280   // five four-wave workgroups per CU
-#endif
 template <typename VT>
 static int ray_exact_dispatch(const MarchArgs &a, hipStream_t stream) {
     const BrickGrid g = make_brick_grid(a.VX, a.VY, a.VZ);
@@ -662,16 +606,10 @@ static int ray_alpha_dispatch(const MarchArgs &a, hipStream_t stream, bool cross
     // the TF once and striding over the rays -- not one workgroup per four rays: 131 072 of them for the demo's 8 x 256^2 rays,
     // each paying the TF load and a barrier first (demo loop 10.25 -> 10.20 ms; 2 048 workgroups: +0.1 ms, rays queue up behind
     // long ones). DR_CROSS_GRID = workgroups over all views.
-#ifndef DR_CROSS_GRID
-#define DR_CROSS_GRID 8192
-#endif
     const int cross_cap = (DR_CROSS_GRID + a.n_views - 1) / a.n_views < 64 ? 64 : (DR_CROSS_GRID + a.n_views - 1) / a.n_views;
     const dim3 grid2((NP + 255) / 256, a.n_views), grid3((NP + 3) / 4 < cross_cap ? (NP + 3) / 4 : cross_cap, a.n_views);
     const size_t lds3 = (size_t)a.R * 16;
     // below sampling rate 2 a crossing segment is short: four rays per wave (ray_cross_quad_kernel)
-#ifndef DR_CROSS_QUAD_BELOW
-#define DR_CROSS_QUAD_BELOW 2.0f
-#endif
     const bool quad = a.sr < DR_CROSS_QUAD_BELOW;
     const dim3 grid3q((NP + 15) / 16 < cross_cap ? (NP + 15) / 16 : cross_cap, a.n_views);
     if (a.mode == DR_MODE_DIFF) {

@@ -15,12 +15,10 @@
 // Replaces, for d_tf: raycast.grad + get_final_image.grad (VR.py:460-461,470-471).
 #include "dr_brick_common.h"
 #include "dr_wave.h"
+#include "dr_tuning.h"
 
 namespace dr {
 
-#ifndef DR_TAPE_GRID
-#define DR_TAPE_GRID 2560   // workgroups per launch over all views (ten per CU: 35 KB of LDS at R = 256, 8 waves per SIMD by registers)
-#endif
 
 template <typename VT>
 __global__ __launch_bounds__(256) void tf_tape_bwd_kernel(BrickParams<VT> P) {

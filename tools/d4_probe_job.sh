@@ -1,5 +1,6 @@
 #!/bin/bash
 # GPU box: the three dumps of tools/d4_bound_probe.py for one configuration, then the comparison.  usage: tools/d4_probe_job.sh N WH SR TF [MODE]
+# needs ab_libs/d4dbg.so (PATCH=closed_experiments tools/mkvariant.sh d4dbg -DDR_D4_DEBUG) and ab_libs/d4off.so (tools/mkvariant.sh d4off -DDR_D4_BUDGET_OVERRIDE=3.0e38f)
 set -e
 O=gpurun_out/d4probe; mkdir -p $O
 T="$1_$2_$3_$4_${5:-0}"

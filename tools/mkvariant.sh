@@ -7,6 +7,15 @@ set -e
 name=$1; shift
 src=differender_amd/csrc; out=ab_libs/obj_$name
 mkdir -p $out
+# PATCH=closed_experiments (or any tools/patches/NAME.patch): build from a scratch copy of csrc/ with that patch applied -- the switches
+# of experiments that are closed (what-if ablations, per-phase clocks, lane / crossing statistics, the D4 bound's debug output) live
+# there, not in the shipped sources; the -D flags of tools/README.md work on the patched copy as they always did
+if [ -n "$PATCH" ]; then
+  tmp=$(mktemp -d); mkdir -p $tmp/differender_amd $tmp/include
+  cp -r $src $tmp/differender_amd/csrc; cp include/*.h $tmp/include/
+  (cd $tmp/differender_amd/csrc && patch -s -p1 < $OLDPWD/tools/patches/$PATCH.patch)
+  src=$tmp/differender_amd/csrc
+fi
 COMMON="$(make -s -C $src print-common)"
 if [ -n "${NO_LICM_FLAG+x}" ]; then COMMON="${COMMON//-mllvm -disable-machine-licm/}"; fi
 pids=()
@@ -20,4 +29,5 @@ if [ "${BWDVOL_SCHED:-iterative-minreg}" = default ]; then SCHED=""; else SCHED=
 for p in "${pids[@]}"; do wait $p; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ab_libs/$name.so $out/*.o -ldl
 rm -rf $out
+if [ -n "$tmp" ]; then rm -rf $tmp; fi
 echo built ab_libs/$name.so
