@@ -114,11 +114,12 @@ def parse_args(argv=None):
     ap.add_argument("--hints", default="auto", choices=["auto", "off"],
                     help="caller hints of dr_march_fwd (DR_HINT_*): 'auto' = derived from the TF's largest alpha once it is "
                          "known (functional._TerminationHints, no host sync); 'off' = never")
-    ap.add_argument("--dssim", action="store_true",
-                    help="opt workload: the reference's full loss, DSSIM + MSE (examples/test_opt_tf.py:70-72), through the torch "
-                         "restatement of pytorch_msssim.ssim (differender_amd/utils/losses.py): +2.7 ms per iteration of torch "
-                         "convolutions outside the raycasting path. Default: MSE only, as every round measured the loop")
-    ap.add_argument("--no-dssim", action="store_true", help="(default; kept for tools/abn_opt.sh)")
+    ap.add_argument("--dssim", action="store_true", help="(default since round 6; kept so that older command lines still parse)")
+    ap.add_argument("--no-dssim", action="store_true",
+                    help="opt workload: MSE only instead of the reference's DSSIM + MSE (examples/test_opt_tf.py:70-72). The DSSIM "
+                         "term runs through the torch restatement of pytorch_msssim.ssim (differender_amd/utils/losses.py): +2.7 ms "
+                         "per iteration of torch convolutions outside the raycasting path -- rounds 1-5 quoted the loop without it "
+                         "(tools/abn_opt.sh still does: same-device A/B of the raycasting path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tape", action="store_true", help="--grads tf: the brick-centric TF-only backward instead of the per-sample tape (DR_TAPE_TF)")
     ap.add_argument("--cpu-img", type=int, default=None,
@@ -762,6 +763,7 @@ def main_opt(args):
     IMG = args.img or 256
     R = args.tf_res or 128
     BS = args.views or 8
+    args.dssim = not args.no_dssim   # the reference's loss unless asked otherwise
     world, rank, dev, dist, backend = init_dist(args)
     from differender.utils import get_tf, in_circles as ic, get_rand_pos
     from differender.volume_raycaster import Raycaster

@@ -392,10 +392,13 @@ struct D4Bound {
     __device__ __forceinline__ float total() const { return lin + 2.0f * __builtin_amdgcn_sqrtf(sq); }
 };
 __device__ __forceinline__ D4Bound d4_zero() { D4Bound b; b.lin = b.sq = b.mprev = 0.0f; b.dprev = 3.0e38f; return b; }
-// `contrib` = T * partial of the channel over `cnt` samples (rcnt = 1 / cnt), `tiny` of them of tiny opacity, onto the running
-// value `pre`.
-__device__ __forceinline__ void d4_risk(float pre, float contrib, float cnt, float rcnt, float tiny, D4Bound &b) {
-    const float hu = 0.5f * ulp_of(pre), c = fabsf(contrib);
+// `contrib` = T * partial of the channel over `cnt` samples (rcnt = 1 / cnt), `tiny` of them of tiny opacity, taking the running
+// value to `post`. The ulp is that of the value AFTER the segment -- the largest the running value gets inside it: a segment that
+// builds most of the composite itself (a ray that spends 800 samples in its first brick) rounds against its own growing sum, not
+// against the prefix it started from (fuzz seed 4100169, round 6: alpha off by 1.3e-5 on a ray whose first segment held 660 of
+// its 861 samples, all of tiny opacity, on a prefix of 0).
+__device__ __forceinline__ void d4_risk(float post, float contrib, float cnt, float rcnt, float tiny, D4Bound &b) {
+    const float hu = 0.5f * ulp_of(post), c = fabsf(contrib);
     const float m = c * rcnt;
     // drift of the mean: the LARGER of the last two differences -- along a smooth ray the contributions pass through extrema, where two
     // neighbouring segments have the same mean by coincidence while the samples inside them still vary by many ulps; only a run of

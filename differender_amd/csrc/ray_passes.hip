@@ -111,10 +111,10 @@ __global__ __launch_bounds__(256) void ray_compose_kernel(BrickParams<VT> P) {
                         const float ea = b3.total();
                         b0.lin = fmaf(ea, fabsf(sg[k].x), b0.lin); b1.lin = fmaf(ea, fabsf(sg[k].y), b1.lin); b2.lin = fmaf(ea, fabsf(sg[k].z), b2.lin);
                     }
-                    d4_risk(C0, T * sg[k].x, cf, rcf, tiny, b0); d4_risk(C1, T * sg[k].y, cf, rcf, tiny, b1);
-                    d4_risk(C2, T * sg[k].z, cf, rcf, tiny, b2); d4_risk(A, T * sg[k].w, cf, rcf, tiny, b3);
-                    C0 = fmaf(T, sg[k].x, C0); C1 = fmaf(T, sg[k].y, C1); C2 = fmaf(T, sg[k].z, C2);
-                    A = fmaf(T, sg[k].w, A);
+                    const float n0 = fmaf(T, sg[k].x, C0), n1 = fmaf(T, sg[k].y, C1), n2 = fmaf(T, sg[k].z, C2), n3 = fmaf(T, sg[k].w, A);
+                    d4_risk(n0, T * sg[k].x, cf, rcf, tiny, b0); d4_risk(n1, T * sg[k].y, cf, rcf, tiny, b1);
+                    d4_risk(n2, T * sg[k].z, cf, rcf, tiny, b2); d4_risk(n3, T * sg[k].w, cf, rcf, tiny, b3);
+                    C0 = n0; C1 = n1; C2 = n2; A = n3;
                     total += cnt[k];
                 }
             }
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void ray_alpha_kernel(BrickParams<VT> P) {
             const float sa = P.seg_rgba[si].w;
             const float A_after = fmaf(1.0f - A, sa, A);
             D4Bound b2 = bA;
-            d4_risk(A, (1.0f - A) * sa, (float)cnt, __builtin_amdgcn_rcpf((float)cnt), tiny, b2);
+            d4_risk(A_after, (1.0f - A) * sa, (float)cnt, __builtin_amdgcn_rcpf((float)cnt), tiny, b2);
             if (!(A_after < 0.99f - 1e-5f - b2.total())) {  // the crossing segment (with a margin for the re-associated partials and for what
                                                            // sequential rounding may have done so far) starts at sample sacc: resolved by ray_cross_kernel
                 *park = make_float4(A, __int_as_float(sacc), bA.total(), 0.f);

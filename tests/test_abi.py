@@ -172,3 +172,20 @@ def test_stale_library_raises_import_error_with_the_rebuild_hint(tmp_path):
         r = subprocess.run([sys.executable, "-c", probe], env=dict(os.environ, DIFFERENDER_HIP_LIB=so, PYTHONPATH=ROOT),
                            capture_output=True, text=True)
         assert r.returncode != 0 and "ImportError" in r.stderr and expect in r.stderr and "rebuild it" in r.stderr, r.stderr
+
+
+def test_closed_experiments_patch_applies(tmp_path):
+    """tools/patches/closed_experiments.patch (the switches of closed experiments, kept out of the shipped kernels since round 6) must
+    keep applying to csrc/ without fuzz or rejects -- tools/mkvariant.sh PATCH=closed_experiments builds the what-if and diagnostic
+    variants from it -- and the patched sources must still carry the marks that make such a build refuse to load as the product."""
+    import shutil
+    import subprocess
+    csrc = os.path.join(ROOT, "differender_amd", "csrc")
+    work = tmp_path / "csrc"
+    shutil.copytree(csrc, work, ignore=shutil.ignore_patterns("*.o", "*.so", ".flag_probe.mk"))
+    r = subprocess.run(["patch", "-p1", "--fuzz=0", "-i", os.path.join(ROOT, "tools", "patches", "closed_experiments.patch")],
+                       cwd=work, capture_output=True, text=True)
+    assert r.returncode == 0 and "rej" not in r.stdout, (r.stdout, r.stderr)
+    patched = (work / "march_flat.hip").read_text()
+    assert "DR_PHASE_TIMING" in patched and "DR_ABL_NOFLUSH" in patched
+    assert "DR_PHASE_TIMING" not in open(os.path.join(csrc, "march_flat.hip")).read()

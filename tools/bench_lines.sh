@@ -5,9 +5,12 @@ run() { name=$1; shift; echo "== $name: bench.py $@"; python3 bench.py "$@" 2> $
 run headline
 run c2_fwd_256 --vol 256 --img 256 --grads none --steps 20 --no-cpu-baseline --pmc off
 run c3_tf_only --grads tf --no-cpu-baseline --pmc off
+run c3_tf_only_bricks --grads tf --no-tape --no-cpu-baseline --pmc off
+run c3_tf1 --grads tf --tf tf1 --no-cpu-baseline --pmc off
 run tf1 --tf tf1 --no-cpu-baseline --pmc off
 run c5_view_1024_f16 --vol 1024 --img 1024 --vol-dtype f16 --jitter --steps 3 --warmup 1 --no-cpu-baseline --pmc off
 run ct_scene_tf1 --tf tf1 --scene ct --no-cpu-baseline --pmc off
+run ct_scene_tf1_grads_vol --tf tf1 --scene ct --grads vol --no-cpu-baseline --pmc off
 run views8_256 --vol 256 --img 256 --views 8 --steps 10 --no-cpu-baseline --pmc off
 run inside_camera --cam inside --steps 5 --no-cpu-baseline --pmc off
 run opt_demo --workload opt --steps 10 --warmup 3
