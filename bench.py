@@ -676,6 +676,12 @@ def main():
 
     b_fwd, b_bwd_vol, b_bwd_tf = algorithmic_bytes(args.vol_dtype)
     roof_fwd = roof("march_fwd", fwd_ms, b_fwd, "march_fwd")
+    if evaluated is not None and evaluated.get("alpha_prepass") and fwd_ms > 0:
+        # the timed forward also ran the alpha pre-pass (a centre tap per sample, live or behind a termination point): the same byte
+        # model over everything the forward's kernels evaluated, beside the colour march's own figure
+        both = (evaluated["alpha_prepass"] + evaluated["march_fwd"]) / max(evaluated["marched"], 1) * steps_per_launch
+        roof_fwd["frac_incl_alpha_prepass"] = round(min(both * b_fwd / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 1.0), 5)
+        roof_fwd["evaluated_incl_alpha_prepass_per_launch"] = int(both)
     roof_bwd = roof("march_bwd", bwd_ms, b_bwd_vol if want_vol else b_bwd_tf, "march_bwd") if want_bwd else None
 
     # roofline.traffic: HBM-side bytes per launch of the dominant kernels

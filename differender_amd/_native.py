@@ -70,12 +70,17 @@ def lib():
             version = handle.dr_abi_version()
         except AttributeError as exc:
             raise ImportError(f"{LIB_PATH} does not export dr_abi_version: not this package's library; {rebuild}") from exc
-        if abs(version) != ABI_VERSION:
+        # (same-device A/B against the library of an EARLIER round -- tools/abn.sh with ab_libs/r05.so: DIFFERENDER_AB_OLD_ABI=8 accepts
+        #  that one older version; entry points it lacks are simply absent, and whatever needs them fails when it is called)
+        ab_old = os.environ.get("DIFFERENDER_AB_OLD_ABI") == str(abs(version)) and abs(version) < ABI_VERSION
+        if abs(version) != ABI_VERSION and not ab_old:
             raise ImportError(f"{LIB_PATH}: ABI version {version}, expected {ABI_VERSION}; {rebuild}")
         for name, (res, args) in SIGNATURES.items():
             try:
                 fn = getattr(handle, name)
             except AttributeError as exc:
+                if ab_old:
+                    continue
                 raise ImportError(f"{LIB_PATH} reports ABI version {version} but does not export `{name}`; {rebuild}") from exc
             fn.restype = res
             fn.argtypes = args

@@ -474,9 +474,10 @@ __global__ __launch_bounds__(256) void ray_cross_quad_kernel(BrickParams<VT> P) 
 // views). Only the image changes: sample counts, ray flags, the stored prefixes and `fin` stay -- the backward's tape-free
 // identity wants a final value consistent with its prefixes, and gets it from `fin`.
 // Two shapes, both launched, one of them leaves at once: up to EXACT_FEW rays are a matter of LATENCY (a ray of 3 500 samples in
-// 256-sample rounds takes 14 of them one after the other) and get 1024 threads each; more are a matter of throughput and get
-// four-wave workgroups, five to a CU.
-constexpr unsigned int EXACT_FEW = 768;
+// 256-sample rounds takes 14 of them one after the other) and get 1024 threads each (one workgroup per ray and CU); more are a
+// matter of throughput and get four-wave workgroups, five to a CU. (What a forward that lists nothing pays: 9 200 waves that load
+// one word and leave.)
+constexpr unsigned int EXACT_FEW = 256;
 template <typename VT, int MODE, int EXACT_NT>
 __global__ __launch_bounds__(EXACT_NT) void ray_exact_kernel(BrickParams<VT> P) {
     __shared__ float4 park[2][EXACT_NT];
