@@ -784,15 +784,16 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                 // KS consecutive samples per lane, multiplied up in registers before the cross-lane product scan.
                 const int slen = L.slen[e];
                 float Tl = 1.0f;
-                int cnt_lane = 0;  // in-brick samples of this lane
-                unsigned long long tmask[KS];  // ... lanes whose sub-sample j has a tiny opacity (D4; rare: counted only where some lane has one)
+                // in-brick samples of this lane, and in the bits from ALPHA_TINY_SHIFT up those of them with a tiny opacity (D4): one number,
+                // one scan -- a piece has at most 64 * KS samples, so neither field of the piece's sum leaves its bits nor the float's 24
+                constexpr int ALPHA_TINY_SHIFT = 10;
+                static_assert(64 * KS < (1 << ALPHA_TINY_SHIFT) && 64 * KS <= (1 << (24 - ALPHA_TINY_SHIFT)), "packed piece counts");
+                int cnt_lane = 0;
                 bool lit_lane = false;  // some sample of this lane composites (alpha > 1e-3 / opacity != 0)
 #pragma unroll
                 for (int j = 0; j < KS; ++j) {
-                    tmask[j] = 0ull;
                     if (j >= ks) continue;  // uniform
                     Sample sa;
-                    bool tiny_j = false;
                     int x0 = 0, y0 = 0, z0 = 0;
                     float fx = 0.f, fy = 0.f, fz = 0.f;
                     bool va = act && (f + j - eoff) < slen;
@@ -812,7 +813,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                             // sample's intensity adjoint vanishes (it carries the factor a_hi - a_lo next to terms with the factor op)
                             lit_lane = lit_lane || opj != 0.0f || L.tfa[sa.lo] != 0.0f || L.tfa[sa.hi] != 0.0f;
                             Tl *= 1.0f - opj;
-                            tiny_j = opj != 0.0f && opj < DR_D4_TINY_OP;
+                            cnt_lane += (opj != 0.0f && opj < DR_D4_TINY_OP) ? (1 << ALPHA_TINY_SHIFT) : 0;
                         }
                         ++cnt_lane;
                     }
@@ -822,10 +823,13 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                         const bool vis = va && sa.a > 1e-3f;
                         lit_lane = lit_lane || vis;
                         if (__any(vis)) {
-                            if (vis) { const float opj = opacity_of_alpha(sa.a, P.inv_sr); Tl *= 1.0f - opj; tiny_j = opj < DR_D4_TINY_OP; }
+                            if (vis) {
+                                const float opj = opacity_of_alpha(sa.a, P.inv_sr);
+                                Tl *= 1.0f - opj;
+                                cnt_lane += (opj < DR_D4_TINY_OP) ? (1 << ALPHA_TINY_SHIFT) : 0;
+                            }
                         }
                     }
-                    tmask[j] = __ballot(tiny_j);   // (wave-uniform: taken where the lanes have reconverged)
                 }
                 Tl = seg_scan_prod(Tl, lane, sl);
                 const int e_first = __builtin_amdgcn_readfirstlane(e);
@@ -838,24 +842,14 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                 }
                 const bool seg_end = act && (f + ks >= offs[e + 1]);
                 // in-brick samples of the piece [sl, lane]: inclusive lane-sum of the per-lane counts
-                float cf[2] = {(float)cnt_lane, 0.0f};
-                unsigned long long tany = 0ull;
-#pragma unroll
-                for (int j = 0; j < KS; ++j) tany |= tmask[j];
-                if (tany != 0ull) {   // wave-uniform, rare: the pass holds samples of tiny opacity -- count them per segment as well
-#pragma unroll
-                    for (int j = 0; j < KS; ++j) cf[1] += (float)((tmask[j] >> lane) & 1ull);
-                    seg_scan_sum<2>(cf, lane, sl);
-                } else {
-                    float c1[1] = {cf[0]};
-                    seg_scan_sum<1>(c1, lane, sl);
-                    cf[0] = c1[0];
-                }
+                float cf[1] = {(float)cnt_lane};
+                seg_scan_sum<1>(cf, lane, sl);
                 const bool piece_end = act && (seg_end || lane == 63 || f + ks >= fb);
                 // nondiff: does the piece [sl, lane] hold a lit sample? (bit VALID_LIT of the segment's counter collects the pieces)
                 const unsigned long long litm = __ballot(lit_lane);
                 if (piece_end) {
-                    const int cntp = (int)cf[0] + ((int)cf[1] << VALID_TINY_SHIFT);   // (the tiny count rides in the upper bits)
+                    const int cpk = (int)cf[0];   // (the tiny count rides in the upper bits, here and in L.valid)
+                    const int cntp = (cpk & ((1 << ALPHA_TINY_SHIFT) - 1)) + ((cpk >> ALPHA_TINY_SHIFT) << VALID_TINY_SHIFT);
                     int before = cntp ? atomicAdd(&L.valid[e], cntp) : L.valid[e];
                     bool seg_lit = true;
                     {
@@ -1019,7 +1013,8 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
             Over el = {0.f, 0.f, 0.f, 0.f};
             Over2 el2 = {0.f, 0.f};  // backward
             unsigned long long vm_fwd[KS];  // forward: which lanes hold an in-brick sample, per sub-sample
-            unsigned long long tm_fwd[KS];  // ... and a sample of tiny opacity (D4)
+            unsigned int tbits = 0u;        // ... bit j: this lane's sub-sample j is lit with a tiny opacity (D4; kept per lane: masks held in
+                                            // scalar registers across the sample loop cost spills)
             // Lighting only matters where the sample has opacity: c = L*rgb*op is exactly 0 for op == 0 whatever L
             // is (the nondiff path skips alpha <= 1e-3 by definition, VR.py:334). Lanes are consecutive samples of a
             // ray, so empty stretches of the transfer function are wave-uniform: skip the six normal taps (48 of the
@@ -1057,7 +1052,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                     const unsigned long long vmask = __ballot(valid);
                     if (BWD) n_eval += (unsigned int)__popcll(vmask);   // (the forward passes count from their segment counts, below)
                     vm_fwd[0] = BWD ? 0ull : vmask;
-                    tm_fwd[0] = BWD ? 0ull : __ballot(lit && sm.op < DR_D4_TINY_OP);
+                    if (!BWD && lit && sm.op < DR_D4_TINY_OP) tbits = 1u;
                 }
             } else {
                 // forward, KS consecutive samples per lane: composited in registers, so that the cross-lane scan and
@@ -1065,7 +1060,7 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                 const int slen = L.slen[e];
 #pragma unroll
                 for (int j = 0; j < KS; ++j) {
-                    if (j >= ks) { vm_fwd[j] = 0ull; tm_fwd[j] = 0ull; continue; }  // uniform
+                    if (j >= ks) { vm_fwd[j] = 0ull; continue; }  // uniform
                     const bool actj = act && (f + j - eoff) < slen;
                     bool vj = false;
                     if (actj) {
@@ -1086,12 +1081,12 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                             sample_normal_taps_shared_lds<NARROW>(L.box, t, cl, dx, dy, dz);
                             shade_from_grad<true>(dx, dy, dz, light, vd, MODE == DR_MODE_DIFF, sm);
                             ej.c0 = sm.L * sm.r * sm.op; ej.c1 = sm.L * sm.g * sm.op; ej.c2 = sm.L * sm.b * sm.op; ej.a = sm.op;
+                            if (sm.op < DR_D4_TINY_OP && (!TAPE || sm.op != 0.0f)) tbits |= 1u << j;
                             if constexpr (TAPE)   // (lanes are consecutive samples of a ray: 512 contiguous bytes per wave and ray)
                                 P.tape[((size_t)view * NP + (size_t)__float_as_int(r1.w)) * (size_t)P.tape_stride + (size_t)(s + j)] = make_float2(sm.I, sm.L);
                         }
                     }
                     vm_fwd[j] = __ballot(vj);
-                    tm_fwd[j] = __ballot(lit && (!TAPE || ej.a != 0.0f) && ej.a < DR_D4_TINY_OP);   // (ej.a = the opacity of a lit sample)
                     el = (j == 0) ? ej : over(el, ej);  // over(x, 0) == x exactly
                 }
             }
@@ -1121,19 +1116,17 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
             if (!BWD) {
                 // count the in-brick samples of each segment piece, store finished segments
                 const bool piece_end = act && (seg_end || lane == 63 || f + ks >= fb);
-                unsigned long long tany = 0ull;
+                const unsigned long long below = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+                const unsigned long long from = ~((1ull << sl) - 1ull);
+                int tiny_piece = 0;   // samples of tiny opacity in the piece [sl, lane]
+                if (__ballot(tbits != 0u) != 0ull) {   // wave-uniform, rare: the masks are made here, where all lanes are
 #pragma unroll
-                for (int j = 0; j < KS; ++j) tany |= tm_fwd[j];
+                    for (int j = 0; j < KS; ++j) tiny_piece += __popcll(__ballot(((tbits >> j) & 1u) != 0u) & below & from);
+                }
                 if (piece_end) {
-                    const unsigned long long below = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
-                    const unsigned long long from = ~((1ull << sl) - 1ull);
-                    int cntp = 0;
+                    int cntp = tiny_piece << VALID_TINY_SHIFT;
 #pragma unroll
                     for (int j = 0; j < KS; ++j) cntp += __popcll(vm_fwd[j] & below & from);
-                    if (tany != 0ull) {   // wave-uniform, rare
-#pragma unroll
-                        for (int j = 0; j < KS; ++j) cntp += __popcll(tm_fwd[j] & below & from) << VALID_TINY_SHIFT;
-                    }
                     const int before = cntp ? atomicAdd(&L.valid[e], cntp) : L.valid[e];
                     // a (ray, layer) slot belongs to the one brick that holds samples of the ray: a candidate
                     // segment without any in-brick sample must not touch it
