@@ -41,9 +41,13 @@ def algorithmic_bytes(vol_dtype):
     """Algorithmic bytes per voxel-step, from the volume's STORAGE type: the forward
     gathers the 8 corners of the centre cell (8 x sizeof(voxel)); the backward w.r.t. the TF re-marches (the same);
     the backward w.r.t. the volume adds the read-modify-write of the centre cell's 8 f32 gradients (8 x 4 B x 2).
-    f32: 32 / 32 / 96; f16: 16 / 16 / 80."""
+    f32: 32 / 32 / 96; f16: 16 / 16 / 80. With the per-sample tape (DR_TAPE_TF) the forward also writes TAPE_BYTES per sample and the
+    TF-only backward reads those and no voxel: forward + 8, backward 8."""
     b_fwd = 8.0 * {"f32": 4, "f16": 2}[vol_dtype]
     return b_fwd, b_fwd + 64.0, b_fwd   # forward, backward w.r.t. volume (+TF), backward w.r.t. TF only
+
+
+TAPE_BYTES = 8.0   # (intensity, lighting term) of a marched sample: two floats
 
 
 def synth_volume_torch(N, device, seed=1234):
@@ -675,6 +679,8 @@ def main():
         return roofline_entry(name, ms, bytes_per_step, steps_per_launch, evaluated, evaluated_key)
 
     b_fwd, b_bwd_vol, b_bwd_tf = algorithmic_bytes(args.vol_dtype)
+    if use_tape:   # the tape's bytes are algorithmic bytes of these two kernels, the voxels are not the backward's
+        b_fwd, b_bwd_tf = b_fwd + TAPE_BYTES, TAPE_BYTES
     roof_fwd = roof("march_fwd", fwd_ms, b_fwd, "march_fwd")
     if evaluated is not None and evaluated.get("alpha_prepass") and fwd_ms > 0:
         # the timed forward also ran the alpha pre-pass (a centre tap per sample, live or behind a termination point): the same byte

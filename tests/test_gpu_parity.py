@@ -1275,16 +1275,19 @@ def test_sub_ulp_contributions_behind_opaque_structures_D4(oracle, hiplib, sr):
     assert int(Fn.workspace_stats(ws0)[15]) <= 0.02 * WH[0] * WH[1], int(Fn.workspace_stats(ws0)[15])
 
 
-@pytest.mark.parametrize("case", ["sr1", "sr2_terminating", "sr0.6_jitter_clipped", "views_per_view_tf", "f16"])
+@pytest.mark.parametrize("case", ["sr1", "sr2_terminating", "sr0.6_jitter_clipped", "views_per_view_tf", "f16", "sr4_noise_R300"])
 def test_tf_only_backward_over_the_per_sample_tape(oracle, hiplib, case):
     """DR_TAPE_TF (BASELINE config C3: the gradient w.r.t. the transfer function alone): the forward leaves (intensity, lighting) of
     every marched sample on a tape, the backward is a per-ray pass over it (csrc/tf_tape.hip) -- no brick, no tap. Same image (to an
     ulp or two) as without the flag; d_tf within the bar of the oracle's (VR.py:460-461,470-471 restated) AND of the brick-centric
-    TF-only backward it replaces."""
+    TF-only backward it replaces. (sr4_noise_R300: rays of 300-440 samples -- passes of four samples per lane -- through white noise
+    under a 300-entry TF: consecutive samples hardly ever share a TF cell, so a lane's four samples are up to four runs of d_tf.)"""
     from differender_amd import functional as Fn
     from differender_amd.utils import get_tf
-    N, WH, R = 64, (40, 48), 64
+    N, WH, R = 64, (40, 48), (300 if case == "sr4_noise_R300" else 64)
     vol_h = oracle.synth_volume(N)
+    if case == "sr4_noise_R300":
+        vol_h = np.random.RandomState(11).rand(N, N, N).astype(np.float32)
     sr, S, seed, V = 1.0, 1 << 20, 0, 1
     tf_h = oracle.bench_tf(R, 0.02)
     tf_h[:, 3] = np.linspace(0.0, 0.05, R)
@@ -1293,6 +1296,9 @@ def test_tf_only_backward_over_the_per_sample_tape(oracle, hiplib, case):
         tf_h = get_tf("tf1", R).t().contiguous().numpy()
     if case == "sr0.6_jitter_clipped":
         sr, S, seed = 0.6, 40, 777
+    if case == "sr4_noise_R300":
+        sr = 4.0
+        tf_h[:, 3] = np.linspace(0.0, 0.01, R)
     cams = np.stack([oracle.in_circles(0.3), oracle.in_circles(2.2)])[: (2 if case == "views_per_view_tf" else 1)]
     V = len(cams)
     tfs_h = np.stack([tf_h, np.clip(tf_h * 1.3, 0, 1)])[:V] if case == "views_per_view_tf" else tf_h
