@@ -1082,8 +1082,12 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                             shade_from_grad<true>(dx, dy, dz, light, vd, MODE == DR_MODE_DIFF, sm);
                             ej.c0 = sm.L * sm.r * sm.op; ej.c1 = sm.L * sm.g * sm.op; ej.c2 = sm.L * sm.b * sm.op; ej.a = sm.op;
                             if (sm.op < DR_D4_TINY_OP && (!TAPE || sm.op != 0.0f)) tbits |= 1u << j;
-                            if constexpr (TAPE)   // (lanes are consecutive samples of a ray: 512 contiguous bytes per wave and ray)
-                                P.tape[((size_t)view * NP + (size_t)__float_as_int(r1.w)) * (size_t)P.tape_stride + (size_t)(s + j)] = make_float2(sm.I, sm.L);
+                            if constexpr (TAPE) {   // (lanes are consecutive samples of a ray: 512 contiguous bytes per wave and ray)
+                                // (a ray longer than the tape's stride -- ray buffers made for another sampling rate than this call's -- stays
+                                //  inside its slot: F2 hands such a ray to the per-ray kernels, forward and backward)
+                                if (s + j < P.tape_stride)
+                                    P.tape[((size_t)view * NP + (size_t)__float_as_int(r1.w)) * (size_t)P.tape_stride + (size_t)(s + j)] = make_float2(sm.I, sm.L);
+                            }
                         }
                     }
                     vm_fwd[j] = __ballot(vj);

@@ -69,6 +69,9 @@ __global__ __launch_bounds__(256) void ray_compose_kernel(BrickParams<VT> P) {
         // bricks marched every planned sample, early termination was not applied -- march every ray of the view whole
         // (uniform over the view; correct, slow, counted)
         if (P.hint_noterm && P.vflags[view] != 0u) regular = false;
+        // DR_TAPE_TF: the per-sample tape has room for the longest ray the volume allows at THIS call's sampling rate; a longer one (ray
+        // buffers made for another rate) is marched whole here and by the per-ray backward
+        if (P.tape_stride > 0 && nmarch > P.tape_stride) regular = false;
         // with an alpha pre-pass the bricks marched exactly the live samples of the ray
         const bool use_live = P.use_live && P.vflags[view] != 0u;
         if (regular && use_live) nmarch = min(nmarch, P.ws_steps[p]);
@@ -572,6 +575,8 @@ static int ray_compose_dispatch(const MarchArgs &a, hipStream_t stream) {
     Workspace w;
     ws_layout(a.workspace, a.n_views, NP, g, &w);
     BrickParams<VT> P = make_brick_params<VT>(a, w);
+    // (a forward that leaves a per-sample tape: F2 needs its stride, to keep rays longer than that off the tape path)
+    if ((a.hints & DR_TAPE_TF) && a.mode == DR_MODE_DIFF) P.tape_stride = tape_stride_for(a.VX, a.VY, a.VZ, a.sr, a.S);
     const dim3 grid2((NP + 255) / 256, a.n_views);
     const size_t lds2 = (size_t)a.R * 16;
     if (a.mode == DR_MODE_DIFF)

@@ -101,6 +101,15 @@ def alloc_workspace(n_views, out_shape, vol_shape, R, device, tape=None):
     return torch.empty(nbytes, dtype=torch.uint8, device=device)
 
 
+def tape_workspace_bytes(n_views, out_shape, vol_shape, R, max_samples, sampling_rate):
+    """Bytes alloc_workspace(..., tape=(max_samples, sampling_rate)) would ask for (0: only the baseline kernels serve this problem).
+    The tape has a fixed stride per ray -- the longest march the volume allows at this rate -- so it is known before any ray is:
+    6.4 GB for one 512^2 view of a 512^3 volume at rate 1, 49 GB for a 1024^2 view of a 1024^3 volume."""
+    W, H = int(out_shape[0]), int(out_shape[1])
+    VX, VY, VZ = (int(s) for s in vol_shape)
+    return int(N.lib().dr_workspace_bytes_tape(int(n_views), W, H, VX, VY, VZ, int(R), int(max_samples), float(sampling_rate)))
+
+
 def workspace_stats(workspace):
     """Diagnostics the last forward left in the workspace header: [0] = rays whose segments failed the
     sample-count check and were marched individually (expected 0), [2] = all rays the per-ray fallback marched

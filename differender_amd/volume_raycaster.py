@@ -14,6 +14,7 @@ Differences from the reference that a caller can observe (all documented in DESI
   * flat-normal samples contribute no normal-path gradient instead of NaN (H3).
 """
 import math
+import os
 import warnings
 
 import torch
@@ -238,6 +239,16 @@ class VolumeRaycaster:
         self._tf_tex_grad = dt if self._tf_tex_grad is None else self._tf_tex_grad + dt
 
 
+def tape_fits(n_views, out_shape, vol_shape, R, max_samples, sampling_rate):
+    """Is the per-sample tape of a TF-only forward (DR_TAPE_TF) worth its memory here? It has a fixed stride per ray (8 B x the longest
+    march the volume allows), known up front: 6.4 GB per 512^2 view of a 512^3 volume, 49 GB per 1024^2 view of a 1024^3 one. Above
+    DIFFERENDER_TAPE_MAX_GIB (default 64 of the card's 288) the brick-centric TF-only backward serves the call instead: same results,
+    ~1.4x the step, no tape."""
+    cap = int(float(os.environ.get("DIFFERENDER_TAPE_MAX_GIB", "64")) * (1 << 30))
+    need = F.tape_workspace_bytes(n_views, out_shape, vol_shape, R, max_samples, sampling_rate)
+    return 0 < need <= cap
+
+
 class RaycastFunction(torch.autograd.Function):
     """Autograd boundary (VR.py:392-476). `apply(vr, volume, tf, look_from, sampling_rate, (batched, bs), jitter)`.
 
@@ -259,7 +270,8 @@ class RaycastFunction(torch.autograd.Function):
         e, x, r, n = F.ray_setup(cam, vr.resolution, volume.shape[-3:], sampling_rate, vr.fov_deg, vr.near, seed)
         # only the transfer function is being optimised (the reference's TF demo; BASELINE config C3): the forward leaves a
         # per-sample tape of (intensity, lighting) and the backward never touches the volume again (csrc/tf_tape.hip)
-        tape = bool(ctx.needs_input_grad[2] and not ctx.needs_input_grad[1])
+        tape = bool(ctx.needs_input_grad[2] and not ctx.needs_input_grad[1]) and tape_fits(
+            cam.shape[0], vr.resolution, volume.shape[-3:], tf.shape[-2], vr.max_samples, sampling_rate)
         ws = F.alloc_workspace(cam.shape[0], vr.resolution, volume.shape[-3:], tf.shape[-2], volume.device,
                                tape=(vr.max_samples, sampling_rate) if tape else None)
         tape = tape and ws is not None

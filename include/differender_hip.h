@@ -61,7 +61,9 @@ enum { DR_VARIANT_AUTO = 0, DR_VARIANT_BASELINE = 1 };
  *       per marched sample, the two things of a sample the TF gradient needs from the volume -- behind the ordinary workspace
  *       (dr_workspace_bytes_tape), and the backward is a per-ray pass over that tape: no brick is staged, no tap is taken
  *       again. Same results as without the flag (a choice between ways of computing the same thing); the backward checks on
- *       the device that the workspace holds this forward's tape and marches the rays one by one if it does not. */
+ *       the device that the workspace holds this forward's tape and marches the rays one by one if it does not. A ray with more
+ *       samples than the tape reserves per ray (ray buffers made for a higher sampling rate than this call's) never leaves its
+ *       slot: forward and backward march it with the per-ray kernels (counted in header word 2). */
 enum { DR_HINT_NO_EARLY_TERMINATION = 0x100, DR_HINT_EARLY_TERMINATION = 0x200, DR_COUNT_EVALUATED = 0x400, DR_TAPE_TF = 0x800 };
 
 enum {

@@ -1235,6 +1235,36 @@ def test_volume_only_backward_skips_unlit_segments(oracle, hiplib, sr):
     assert grad_close(dvo.cpu().numpy(), dv2)[0]
 
 
+def test_rays_longer_than_the_per_sample_tape_take_the_per_ray_kernels(oracle, hiplib):
+    """DR_TAPE_TF reserves, per ray, the longest march the volume allows at the CALL's sampling rate. Ray buffers made for another rate
+    (here: ray_setup at rate 2, march at rate 1 -- legal through the C ABI, the march takes its samples from the buffers) hold rays
+    longer than that: they must not write past their slot of the tape. F2 hands them to the per-ray kernels, counted; results as the
+    oracle's for the same buffers."""
+    from differender_amd import functional as Fn
+    N, WH, R = 48, (24, 20), 32
+    vol_h = oracle.synth_volume(N)
+    tf_h = oracle.bench_tf(R, 0.02)
+    tf_h[:, 3] = np.linspace(0.0, 0.03, R)
+    cam_h = oracle.in_circles(1.1)
+    S = 1 << 20
+    vol, tf, cam = T(vol_h), T(tf_h), T(cam_h[None])
+    e, x, r, n = Fn.ray_setup(cam, WH, vol_h.shape, 2.0)            # twice the samples the tape of a rate-1 call has room for
+    ws = Fn.alloc_workspace(1, WH, vol_h.shape, R, dev(), tape=(S, 1.0))
+    stride = (int(np.floor(2.0 * np.sqrt(3.0) * np.sqrt(3.0) * (N - 1))) + 2 + 1) & ~1
+    assert int(n.max()) > stride
+    out, steps = Fn.march_fwd(vol, tf, cam, e, x, r, n, S, 1.0, workspace=ws, tape=True)
+    long_rays = int((n > stride).sum())
+    assert int(Fn.workspace_stats(ws)[2]) >= long_rays > 0    # marched by the per-ray kernels, and counted
+    eo, xo, ro, no = oracle.ray_setup(cam_h, *WH, vol_h.shape, sr=2.0)
+    ref, sref = oracle.march_fwd(vol_h, tf_h, cam_h, eo, xo, ro, no, S, 1.0, 0)
+    assert np.array_equal(steps[0].cpu().numpy(), sref) and np.abs(out[0].cpu().numpy() - ref).max() <= FWD_TOL
+    g = np.random.RandomState(4).randn(1, *WH, 4).astype(np.float32)
+    _, dt = Fn.march_bwd(vol, tf, cam, e, x, r, n, S, 1.0, T(g), out, want_vol=False, workspace=ws, tape=True)
+    _, dt_ref = oracle.march_bwd(vol_h, tf_h, cam_h, eo, xo, ro, no, S, 1.0, g[0], want_vol=False)
+    ok, err = grad_close(dt.cpu().numpy(), dt_ref, tol=1e-3)   # (rays of the plain kernels' float-atomic d_tf among them: their bar)
+    assert ok, err
+
+
 @pytest.mark.parametrize("sr", [2.0, 4.0, 8.0])
 def test_sub_ulp_contributions_behind_opaque_structures_D4(oracle, hiplib, sr):
     """a TF whose transparent ranges carry a tiny alpha (1e-6) instead of 0, around opaque peaks, at sampling rates

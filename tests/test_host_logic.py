@@ -175,3 +175,21 @@ def test_get_tf_generate_returns_a_random_peaked_tf():
     assert seen == {1, 2}
     with pytest.raises(Exception, match="Invalid Transfer function identifier"):
         get_tf("nope", 16)
+
+
+def test_tape_fits_its_memory_cap(hiplib, monkeypatch):
+    """The TF-only forward's per-sample tape has a fixed stride per ray, known before any ray is (host arithmetic of the C ABI:
+    dr_workspace_bytes_tape). RaycastFunction asks for it only below DIFFERENDER_TAPE_MAX_GIB; above, the brick-centric TF-only
+    backward serves the call."""
+    from differender_amd import functional as Fn
+    from differender_amd.volume_raycaster import tape_fits
+    one = Fn.tape_workspace_bytes(1, (512, 512), (512, 512, 512), 256, 1 << 20, 1.0)
+    plain = int(Fn.N.lib().dr_workspace_bytes(1, 512, 512, 512, 512, 512, 256))
+    stride = (int(math.floor(2.0 * math.sqrt(3.0) * math.sqrt(3.0) * 511)) + 2 + 1) & ~1
+    assert 0 <= one - plain - 512 * 512 * stride * 8 < 4096         # the plain workspace + 8 B per ray and possible sample (+ alignment)
+    assert Fn.tape_workspace_bytes(1, (512, 512), (512, 512, 512), 256, 1024, 1.0) < one     # max_samples caps the stride
+    assert tape_fits(1, (512, 512), (512, 512, 512), 256, 1 << 20, 1.0)                     # 6.4 GB
+    assert not tape_fits(8, (1024, 1024), (1024, 1024, 1024), 256, 1 << 20, 1.0)            # 8 x 51 GB
+    monkeypatch.setenv("DIFFERENDER_TAPE_MAX_GIB", "1")
+    assert not tape_fits(1, (512, 512), (512, 512, 512), 256, 1 << 20, 1.0)
+    assert not tape_fits(1, (16, 16), (4000, 8, 8), 16, 64, 1.0)                            # no fast path at all: no tape either
