@@ -195,9 +195,10 @@ __global__ __launch_bounds__(256) void ray_alpha_kernel(BrickParams<VT> P) {
         float A = 0.f;
         D4Bound bA = d4_zero();   // how far the reference's sequential alpha may be from this one (D4, dr_brick_common.h)
         int sacc = 0;
+        int slit = 0;   // ... of them in segments that moved alpha at all (a segment of air has the partial 0 exactly and rounds nothing)
         // (between the phases of the pre-pass the bound travels as ONE number, its total so far: the quadrature part is folded in and
         //  the drift history starts afresh -- a phase's first two segments are then not charged for standing still)
-        if (!P.pp_first) { const float4 st = *park; A = st.x; sacc = __float_as_int(st.y); bA.lin = st.z; }
+        if (!P.pp_first) { const float4 st = *park; A = st.x; sacc = __float_as_int(st.y); bA.lin = st.z; slit = __float_as_int(st.w); }
         const size_t seg0 = (size_t)view * P.g.NL * NP + pl;
         const f3 cam = make_f3(P.cam[3 * view], P.cam[3 * view + 1], P.cam[3 * view + 2]);
         // this phase's bricks have camera-based layers [pp_l0, pp_l1); along a ray from a camera outside the volume
@@ -229,18 +230,21 @@ __global__ __launch_bounds__(256) void ray_alpha_kernel(BrickParams<VT> P) {
                 const float A_after = fmaf(1.0f - A, sa, A);
                 D4Bound b2 = bA;
                 d4_risk(A_after, (1.0f - A) * sa, (float)cnt, __builtin_amdgcn_rcpf((float)cnt), tiny, b2);
-                if (!(A_after < 0.99f - 1e-5f - b2.total())) {  // the crossing segment (with a margin for the re-associated partials and for what
-                                                               // sequential rounding may have done so far) starts at sample sacc: resolved by ray_cross_kernel
-                    *park = make_float4(A, __int_as_float(sacc), bA.total(), 0.f);
+                // the crossing segment (with a margin for the re-associated partials -- 1e-5, or the random walk of the sequential roundings
+                // where a ray has tens of thousands of samples behind it: cross_band -- and for what sequential rounding may have done
+                // systematically so far) starts at sample sacc: resolved by ray_cross_kernel
+                if (!(A_after < 0.99f - fmaxf(1e-5f, 5.2e-8f * __builtin_amdgcn_sqrtf((float)(slit + cnt))) - b2.total())) {
+                    *park = make_float4(A, __int_as_float(sacc), bA.total(), __int_as_float(slit));
                     P.ws_steps[p] = -1;
                     return;
                 }
                 A = A_after;
                 bA = b2;
                 sacc += cnt;
+                slit += (sa != 0.0f) ? cnt : 0;
             }
         }
-        *park = make_float4(A, __int_as_float(sacc), bA.total(), 0.f);
+        *park = make_float4(A, __int_as_float(sacc), bA.total(), __int_as_float(slit));
     }
     if (P.pp_first) P.ws_steps[p] = nmarch;  // alive (so far): every planned sample is live
 }
@@ -342,6 +346,14 @@ __device__ __forceinline__ int cross_exact_walk(const BrickParams<VT> &P, const 
     return s;
 }
 
+// How far the reference's SEQUENTIAL alpha may be from the re-associated one after s samples, from ordinary rounding alone: a random
+// walk of 0.29 ulp per sample (an ulp of an alpha below 1: 6e-8), three sigma -- 5.2e-8 sqrt(s). The 2e-6 the band has had since
+// round 2 is that for 1 500 samples; rays of 10 000 samples and more (sampling rate 16 through a 288-voxel volume: fuzz seed 90320 at
+// FUZZ_SCALE=3, round 6 -- the sequential alpha crossed one sample early, 3.5e-6 from the re-associated one) need the wider one.
+// s counts the samples that can have rounded anything: those of the segments before the crossing one whose alpha partial is not 0
+// (ray_alpha_kernel parks their number) and the crossing segment's own -- the air a ray crosses first does not widen its band.
+__device__ __forceinline__ float cross_band(int s) { return fmaxf(2e-6f, 5.2e-8f * __builtin_amdgcn_sqrtf((float)s)); }
+
 template <typename VT, int MODE>
 __global__ __launch_bounds__(256) void ray_cross_kernel(BrickParams<VT> P) {
     extern __shared__ __attribute__((aligned(16))) float4 lds_tf[];
@@ -385,7 +397,7 @@ __global__ __launch_bounds__(256) void ray_cross_kernel(BrickParams<VT> P) {
             break;
         }
         // decided at A (>= 0.99, or the ray ran out of samples) with A_prev (< 0.99) before it
-        const float band = 2e-6f + parked.z + (float)n_tiny * 3.0e-8f;
+        const float band = cross_band(__float_as_int(parked.w) + (s - __float_as_int(parked.y))) + parked.z + (float)n_tiny * 3.0e-8f;
         bool ambiguous = fabsf(A - 0.99f) < band || fabsf(A_prev - 0.99f) < band;
         if (ambiguous) s = cross_exact_walk<VT, MODE>(P, vol, lds_tf, rg, cam, nmarch, lane);  // ---- round 1
         if (lane == 0) P.ws_steps[p] = s;
@@ -454,7 +466,7 @@ __global__ __launch_bounds__(256) void ray_cross_quad_kernel(BrickParams<VT> P) 
             }
         }
         // decided at A (>= 0.99, or the ray ran out of samples) with A_prev (< 0.99) before it
-        const float band = 2e-6f + parked.z + (float)n_tiny * 3.0e-8f;
+        const float band = cross_band(__float_as_int(parked.w) + (s - __float_as_int(parked.y))) + parked.z + (float)n_tiny * 3.0e-8f;
         bool ambiguous = act && (fabsf(A - 0.99f) < band || fabsf(A_prev - 0.99f) < band);
         const unsigned long long ambm = __ballot(ambiguous);
         if (ambm != 0ull) {  // wave-uniform, rare
