@@ -1058,6 +1058,10 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                 // forward, KS consecutive samples per lane: composited in registers, so that the cross-lane scan and
                 // the per-chunk bookkeeping below are paid once per KS*64 samples
                 const int slen = L.slen[e];
+                float2 tape_v[KS];   // TAPE: what the lane's samples leave on the per-sample tape ...
+                bool tape_ok[KS];    // ... those that are marched at all
+#pragma unroll
+                for (int j = 0; j < KS; ++j) { tape_v[j] = make_float2(0.f, 0.f); tape_ok[j] = false; }
 #pragma unroll
                 for (int j = 0; j < KS; ++j) {
                     if (j >= ks) { vm_fwd[j] = 0ull; continue; }  // uniform
@@ -1082,16 +1086,30 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
                             shade_from_grad<true>(dx, dy, dz, light, vd, MODE == DR_MODE_DIFF, sm);
                             ej.c0 = sm.L * sm.r * sm.op; ej.c1 = sm.L * sm.g * sm.op; ej.c2 = sm.L * sm.b * sm.op; ej.a = sm.op;
                             if (sm.op < DR_D4_TINY_OP && (!TAPE || sm.op != 0.0f)) tbits |= 1u << j;
-                            if constexpr (TAPE) {   // (lanes are consecutive samples of a ray: 512 contiguous bytes per wave and ray)
+                            if constexpr (TAPE) {
                                 // (a ray longer than the tape's stride -- ray buffers made for another sampling rate than this call's -- stays
                                 //  inside its slot: F2 hands such a ray to the per-ray kernels, forward and backward)
-                                if (s + j < P.tape_stride)
-                                    P.tape[((size_t)view * NP + (size_t)__float_as_int(r1.w)) * (size_t)P.tape_stride + (size_t)(s + j)] = make_float2(sm.I, sm.L);
+                                tape_v[j] = make_float2(sm.I, sm.L); tape_ok[j] = s + j < P.tape_stride;
                             }
                         }
                     }
                     vm_fwd[j] = __ballot(vj);
                     el = (j == 0) ? ej : over(el, ej);  // over(x, 0) == x exactly
+                }
+                if constexpr (TAPE) {
+                    // lanes are consecutive samples of a ray, a lane's own samples neighbours on the tape: one 16-byte store per pair
+                    // (1 KB contiguous per wave and ray), single samples -- the ends of a segment -- on their own
+                    float2 *tq = P.tape + ((size_t)view * NP + (size_t)__float_as_int(r1.w)) * (size_t)P.tape_stride + (size_t)s;
+#pragma unroll
+                    for (int h = 0; h < KS / 2; ++h) {
+                        if (tape_ok[2 * h] && tape_ok[2 * h + 1]) {
+                            // (only 8-byte aligned where the ray's first sample in this brick has an odd index: global memory takes that)
+                            *reinterpret_cast<float4 *>(tq + 2 * h) = make_float4(tape_v[2 * h].x, tape_v[2 * h].y, tape_v[2 * h + 1].x, tape_v[2 * h + 1].y);
+                        } else {
+                            if (tape_ok[2 * h]) tq[2 * h] = tape_v[2 * h];
+                            if (tape_ok[2 * h + 1]) tq[2 * h + 1] = tape_v[2 * h + 1];
+                        }
+                    }
                 }
             }
             // segmented inclusive scan of "over" across the wave (segments = entries)
