@@ -367,8 +367,10 @@ __device__ __forceinline__ bool segment_range(const BrickCtx &c, f3 cam, f3 vd, 
 //       many ulps. (A mean that DRIFTS leaves a sawtooth of roundings that cancels but for a partial cycle of random sign; charging
 //       those remainders was tried and flagged thousands of rays whose true error was below 1e-6 -- a segment's sample count says
 //       nothing about how many of its samples contribute at all: profiles/r06_ab_experiments.txt. They belong to the random walk.)
-//   (3) rays of more than DR_D4_LONG_RAY live samples: the random walk of the sequential roundings alone (0.29 ulp per sample,
-//       3 sigma of 12 000 samples of a composite near 1: 5.7e-6) leaves no room under the 1e-5 bar -- recomputed whatever (1) and (2) say.
+//   (3) long rays: the random walk of the sequential roundings alone (0.29 ulp per sample; the ulp of the ray's largest final
+//       channel bounds every running value's) leaves no room under the 1e-5 bar once 3 sigma = 0.87 ulp sqrt(samples) passes
+//       DR_D4_WALK = 5.7e-6 -- 12 000 samples of a composite in [0.5, 1), 3 000 of a colour in [1, 2) (unclamped highlights of the
+//       differentiable march), 48 000 of a dim one: recomputed whatever (1) and (2) say.
 // An error in alpha also moves every later contribution: bound(alpha) * later partial (the callers add that). A ray whose bound
 // exceeds DR_D4_BUDGET has its pixel recomputed sample by sample (ray_exact_kernel); in the crossing search the bound widens the
 // band inside which the early-termination decision is repeated exactly.
@@ -381,7 +383,7 @@ __device__ __forceinline__ bool segment_range(const BrickCtx &c, f3 cam, f3 vd, 
 #endif
 #define DR_D4_TINY_OP 1.0e-4f
 #define DR_D4_TINY_RUN 16.0f
-#define DR_D4_LONG_RAY 12000
+#define DR_D4_WALK 5.68e-6f   // = 0.87 x 5.96e-8 x sqrt(12 000)
 __device__ __forceinline__ float ulp_of(float x) {   // spacing of the floats at |x| (0 below 2^-100: nothing to lose there)
     const unsigned int e = __float_as_uint(x) & 0x7f800000u;
     return e > (27u << 23) ? __uint_as_float(e - (23u << 23)) : 0.0f;

@@ -126,7 +126,11 @@ __global__ __launch_bounds__(256) void ray_compose_kernel(BrickParams<VT> P) {
             else {
                 if (MODE == DR_MODE_DIFF) P.fin[p] = make_float4(C0, C1, C2, A);   // what the stored prefixes add up to: the backward's "final"
                 const float e0 = b0.total(), e1 = b1.total(), e2 = b2.total(), e3 = b3.total();
-                want_exact = fmaxf(fmaxf(e0, e1), fmaxf(e2, e3)) > DR_D4_BUDGET || nmarch > DR_D4_LONG_RAY;
+                // (3): the random walk of nmarch sequential roundings, each in ulps of a running value that never exceeds the final one
+                // (the non-differentiable image is clamped to 1, VR.py:358: what a channel does above 1 is not seen)
+                const float cmax = fminf(fmaxf(fmaxf(C0, C1), fmaxf(C2, A)), MODE == DR_MODE_NONDIFF ? 0.99999994f : 3.0e38f);
+                const bool long_walk = 0.87f * ulp_of(cmax) * __builtin_amdgcn_sqrtf((float)nmarch) > DR_D4_WALK;
+                want_exact = fmaxf(fmaxf(e0, e1), fmaxf(e2, e3)) > DR_D4_BUDGET || long_walk;
             }
         }
         if (!regular) {
