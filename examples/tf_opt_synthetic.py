@@ -32,18 +32,19 @@ if __name__ == "__main__":
     tf_gt = get_tf("tf1", R).t().contiguous().float().to(dev)  # (R,4)
     tf = get_tf("gray", R).t().contiguous().float().to(dev)
     mom = torch.zeros_like(tf)
-    ws = F.alloc_workspace(1, WH, vol.shape, R, dev)
     cam = in_circles(1.7).float().to(dev)[None]
     sr = args.bw_sampling_rate
+    # only the TF is optimised: the forward leaves a per-sample tape (DR_TAPE_TF) and the backward never touches the volume again
+    ws = F.alloc_workspace(1, WH, vol.shape, R, dev, tape=(S, sr))
     e, x, r, n = F.ray_setup(cam, WH, vol.shape, sr)
     ref, _ = F.march_fwd(vol, tf_gt, cam, e, x, r, n, S, sr, workspace=ws)
     ref = ref.clone()
     lr, losses = args.lr, []
     for i in range(args.iterations):
         e, x, r, n = F.ray_setup(cam, WH, vol.shape, sr, jitter_seed=F.new_jitter_seed())
-        out, _ = F.march_fwd(vol, tf, cam, e, x, r, n, S, sr, workspace=ws)
+        out, _ = F.march_fwd(vol, tf, cam, e, x, r, n, S, sr, workspace=ws, tape=True)
         loss, g = F.mse_loss_grad(out, ref)
-        _, d_tf = F.march_bwd(vol, tf, cam, e, x, r, n, S, sr, g, out, want_vol=False, workspace=ws)
+        _, d_tf = F.march_bwd(vol, tf, cam, e, x, r, n, S, sr, g, out, want_vol=False, workspace=ws, tape=True)
         F.tf_momentum_step(tf, d_tf, mom, lr, args.mom, args.clip_grads)
         lr *= args.lr_decay
         losses.append(loss)                                      # stays on the device until the loop is done
