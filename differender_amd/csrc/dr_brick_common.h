@@ -31,7 +31,7 @@ struct BrickParams {
                          // ray is marched whole) | SEG_CNT_TINY
     uint16_t *seg_tiny;  // [view][NL][NP]: how many of those samples have a TINY opacity (0 < op < DR_D4_TINY_OP); valid where seg_cnt
                          // carries SEG_CNT_TINY (never cleared: read only under that flag)
-    uint8_t *rayflag;    // [view][NP]: 1 = irregular ray (marched whole by F2 / B2)
+    uint8_t *rayflag;    // [view][NP]: 1 = irregular ray (marched whole by F2 / B2), 2 = recomputed by F3, its backward by B3
     int32_t *ws_steps;   // [view][NP]: live samples per ray (F2 -> B1)
     float4 *fin;         // [view][NP]: the ray's composite as F2 put it together from the partials (differentiable march): the backward's
                          //   tape-free identity needs a final value that is CONSISTENT with the stored prefixes -- the image itself may
@@ -381,6 +381,11 @@ __device__ __forceinline__ bool segment_range(const BrickCtx &c, f3 cam, f3 vd, 
 #else
 #define DR_D4_BUDGET 3.0e-6f
 #endif
+// ... and a ray whose bound exceeds DR_D4_BWD_BUDGET has its BACKWARD formed from the sequential composites too (ray_exact_bwd_kernel):
+// the tape-free identity takes prefixes and final value from the composites, an adjoint built on partials that are `bound` away is
+// ~7 bound off in relative terms, and a TF with tiny alphas lists a sixth of the rays -- below 1e-5 even ALL rays at the budget stay
+// under the 1e-4 bar of the gradients, so the headline's handful of listed rays (bounds of 3e-6 .. 1e-5) keep the brick backward.
+#define DR_D4_BWD_BUDGET 1.0e-5f
 #define DR_D4_TINY_OP 1.0e-4f
 #define DR_D4_TINY_RUN 16.0f
 #define DR_D4_WALK 5.68e-6f   // = 0.87 x 5.96e-8 x sqrt(12 000)

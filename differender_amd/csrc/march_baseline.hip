@@ -119,7 +119,8 @@ __global__ __launch_bounds__(256) void march_bwd_baseline_kernel(MarchParams<VT>
     const bool stale_ws = (P.ws_mark != nullptr && *P.ws_mark != P.ws_mark_expect) || (P.ws_aux != nullptr && *P.ws_aux != P.ws_aux_expect);
     if (stale_ws && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
         atomicAdd(const_cast<unsigned int *>(P.ws_mark) + 6, 1u);   // header word 9 (ST_STALE_BWD): the host layer warns
-    if (active && P.only_flagged && !stale_ws) active = P.only_flagged[((size_t)view * P.W + i) * P.H + j] != 0;
+    // (flag 1: irregular rays; 2 = rays of the exact pass, whose backward is ray_exact_bwd_kernel's)
+    if (active && P.only_flagged && !stale_ws) active = P.only_flagged[((size_t)view * P.W + i) * P.H + j] == 1;
     if (active) {
         const size_t p = ((size_t)view * P.W + i) * P.H + j;
         VolView<VT> vol = P.vol;

@@ -1567,7 +1567,9 @@ static int flat_bwd_dispatch(const MarchArgs &a, hipStream_t stream) {
         b.only_flagged = w.rayflag;
         b.ws_mark = w.stats + ST_MARK; b.ws_mark_expect = ws_fingerprint(a);
         b.ws_aux = w.stats + ST_TAPE_STRIDE; b.ws_aux_expect = (unsigned int)tstride;
-        return launch_march_bwd_baseline(b, stream);
+        const int rc2 = launch_march_bwd_baseline(b, stream);
+        if (rc2) return rc2;
+        return launch_ray_exact_bwd(a, stream);   // B3: the rays the forward recomputed sequentially
     }
     const size_t need = ws_layout(a.workspace, a.n_views, NP, g, &w);
     if (!a.workspace || a.workspace_bytes < need) return DR_EINVAL;
@@ -1585,7 +1587,9 @@ static int flat_bwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     MarchArgs b = a;
     b.only_flagged = w.rayflag;  // B2: irregular rays through the baseline backward (every ray, if the workspace is not this call's)
     b.ws_mark = w.stats + ST_MARK; b.ws_mark_expect = P.mark;
-    return launch_march_bwd_baseline(b, stream);
+    const int rc2 = launch_march_bwd_baseline(b, stream);
+    if (rc2) return rc2;
+    return launch_ray_exact_bwd(a, stream);   // B3: the rays the forward recomputed sequentially
 }
 
 int launch_march_bwd_flat(const MarchArgs &a, hipStream_t stream) {

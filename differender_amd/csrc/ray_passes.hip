@@ -12,6 +12,7 @@
 // Reference functions replaced: get_final_image[_nondiff] (VR.py:353-372) and the early-termination test of
 // raycast / raycast_nondiff (VR.py:267,318).
 #include "dr_brick_common.h"
+#include "dr_wave.h"
 #include "dr_tuning.h"
 
 namespace dr {
@@ -54,6 +55,7 @@ __global__ __launch_bounds__(256) void ray_compose_kernel(BrickParams<VT> P) {
     int steps = 0;
     uint8_t flag = 0;
     bool want_exact = false;   // the pixel is recomputed sample by sample (ray_exact_kernel)
+    bool want_exact_bwd = false;   // ... and so is its backward (ray_exact_bwd_kernel)
     if (pl == 0 && P.hint_noterm && P.vflags[view] != 0u) atomicAdd(&P.stats[ST_HINT_BAD], 1u);  // (see below)
     if (rg.n > 0) {
         VolView<VT> vol = P.vol;
@@ -131,6 +133,7 @@ __global__ __launch_bounds__(256) void ray_compose_kernel(BrickParams<VT> P) {
                 const float cmax = fminf(fmaxf(fmaxf(C0, C1), fmaxf(C2, A)), MODE == DR_MODE_NONDIFF ? 0.99999994f : 3.0e38f);
                 const bool long_walk = 0.87f * ulp_of(cmax) * __builtin_amdgcn_sqrtf((float)nmarch) > DR_D4_WALK;
                 want_exact = fmaxf(fmaxf(e0, e1), fmaxf(e2, e3)) > DR_D4_BUDGET || long_walk;
+                want_exact_bwd = want_exact && fmaxf(fmaxf(e0, e1), fmaxf(e2, e3)) > DR_D4_BWD_BUDGET;   // (only a listed ray: B3 walks the list)
             }
         }
         if (!regular) {
@@ -161,7 +164,9 @@ __global__ __launch_bounds__(256) void ray_compose_kernel(BrickParams<VT> P) {
     reinterpret_cast<float4 *>(P.out)[p] = make_float4(C0, C1, C2, A);
     if (P.steps) P.steps[p] = steps;
     P.ws_steps[p] = steps;
-    P.rayflag[p] = flag;
+    // 1: a ray F2 marched whole (B2 takes its backward); 2: a ray F3 recomputes whose partials are too far from the sequential composites
+    // for a backward from them (B3 takes it); a listed ray below that keeps B1
+    P.rayflag[p] = want_exact_bwd ? (uint8_t)2 : flag;
     // rays for ray_exact_kernel: one list for all views, one atomic per wave
     const unsigned long long xm = __ballot(want_exact);
     if (xm != 0ull) {   // wave-uniform
@@ -562,6 +567,183 @@ __global__ __launch_bounds__(EXACT_NT) void ray_exact_kernel(BrickParams<VT> P) 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ B3
+// The backward of the rays F3 recomputed. Their image is the reference's sequential composite, and the reference's adjoint is built
+// from the sequential composites too -- the tape-free identity with the prefix BEFORE each sample and the final value as the
+// sequential recurrence produced them (VR.py:460-461 on the tape of :300-302). Where the partials and the sequential values part
+// company by 1e-4 of a composite (what such a ray was listed for), a backward from the partials is 1e-4 off per ray, and a TF whose
+// transparent ranges carry tiny alphas lists a sixth of the rays: d_tf 1e-4 .. 5e-4 of its maximum at 256^3 and 512^3 (tools/
+// diff_sweep.py, round 6). So F2 flags the listed rays (rayflag 2): B1 and the tape pass leave them alone, the per-ray pass B2
+// (one LANE per ray: 8 ms for a handful of rays) does too, and this kernel serves them -- one 1024-thread workgroup per ray:
+// samples evaluated side by side with the sequential kernels' arithmetic (classify / shade: exact normalisations, global taps),
+// their contributions chained by the first wave into the composite before every sample (LDS), then every thread forms its
+// sample's adjoint exactly as march_bwd_baseline_kernel does and scatters it (d_volume: global float atomics; d_tf: a double
+// table in LDS, flushed per view). A resident grid that leaves at once when nothing is listed.
+// the eight corner weights of tri_scatter_global (dr_device.h), times adj -- same products, same order
+__device__ __forceinline__ void tri_corner_weights(const Cell &c, float adj, float (&w)[8]) {
+    const float gx = 1.0f - c.fx, gy = 1.0f - c.fy, gz = 1.0f - c.fz;
+    w[0] = gx * gy * gz * adj; w[1] = c.fx * gy * gz * adj; w[2] = gx * c.fy * gz * adj; w[3] = c.fx * c.fy * gz * adj;
+    w[4] = gx * gy * c.fz * adj; w[5] = c.fx * gy * c.fz * adj; w[6] = gx * c.fy * c.fz * adj; w[7] = c.fx * c.fy * c.fz * adj;
+}
+constexpr int EXACT_BWD_NT = 1024;
+template <typename VT>
+__global__ __launch_bounds__(EXACT_BWD_NT) void ray_exact_bwd_kernel(BrickParams<VT> P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b3[];
+    unsigned long long *lds_dtf = reinterpret_cast<unsigned long long *>(smem_b3);                      // [R][4] doubles
+    float4 *park = reinterpret_cast<float4 *>(smem_b3 + (size_t)P.R * 32);                              // [NT] contributions
+    float4 *pre = park + EXACT_BWD_NT;                                                                  // [NT] composite before the sample
+    // only after the forward of THIS call (else B2 marches every ray and nothing is left to do here)
+    if (P.stats[ST_MARK] != P.mark) return;   // uniform
+    if (P.tape_stride > 0 && P.stats[ST_TAPE_STRIDE] != (unsigned int)P.tape_stride) return;
+    const unsigned int count = P.stats[ST_EXACT_RAYS];
+    if (count == 0u) return;
+    const int NP = P.W * P.H;
+    const bool want_vol = P.dvol.p != nullptr, want_tf = P.d_tf != nullptr;
+    const float delta = 1e-3f;
+    int cur_view = -1;   // whose d_tf the LDS table holds
+    auto flush = [&]() {   // (all threads)
+        __syncthreads();
+        if (want_tf && cur_view >= 0) {
+            float *dtf = P.d_tf + cur_view * P.dtf_vs * 4;
+            for (int k = threadIdx.x; k < 4 * P.R; k += EXACT_BWD_NT) {
+                const unsigned long long raw = lds_dtf[k];
+                if (raw != 0ull) atomic_add_sat(dtf + k, acc_f64_to_float(raw));
+                lds_dtf[k] = 0ull;
+            }
+        }
+        __syncthreads();
+    };
+    for (unsigned int i = blockIdx.x; i < count; i += gridDim.x) {   // uniform
+        const size_t p = P.exact_list[i];
+        if (P.rayflag[p] != 2) continue;   // uniform: listed for its image only (a bound between the two budgets, a long ray): B1 has it
+        const int view = (int)(p / (size_t)NP);
+        if (view != cur_view) {
+            if (cur_view >= 0) flush();
+            else { if (want_tf) for (int k = threadIdx.x; k < 4 * P.R; k += EXACT_BWD_NT) lds_dtf[k] = 0ull; __syncthreads(); }
+            cur_view = view;
+        }
+        const float4 *tfg = P.tf + view * P.tf_vs;
+        VolView<VT> vol = P.vol;
+        vol.p += view * P.vol_vs;
+        GradView dv = P.dvol;
+        if (want_vol) dv.p += view * P.dvol_vs;
+        RayGeom rg;
+        load_ray(P.entry, P.exit_, P.rays, P.nsamp, p, rg);
+        const f3 cam = make_f3(P.cam[3 * view], P.cam[3 * view + 1], P.cam[3 * view + 2]);
+        const f3 light = make_f3(cam.x + 0.0f, cam.y + 1.0f, cam.z + 0.0f);
+        const f3 vd = make_f3(rg.vx, rg.vy, rg.vz);
+        const int live = P.ws_steps[p];   // the samples the sequential march takes (F2; exact: D3)
+        const float4 go = reinterpret_cast<const float4 *>(P.grad_out)[p];
+        const float4 of = reinterpret_cast<const float4 *>(P.out_fwd)[p];   // the image: F3's sequential composite
+        float C0 = 0.f, C1 = 0.f, C2 = 0.f, A = 0.f;   // (first wave)
+        for (int base = 0; base < live; base += EXACT_BWD_NT) {   // uniform
+            const int s = base + (int)threadIdx.x;
+            const bool have = s < live;
+            Sample sm;
+            float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (have) {
+                sample_pos(rg, cam.x, cam.y, cam.z, s, sm.px, sm.py, sm.pz);
+                classify(vol, tfg, P.R, P.tf_len, P.inv_sr, sm);
+                shade(vol, light, vd, true, sm);
+                c = make_float4(sm.L * sm.r * sm.op, sm.L * sm.g * sm.op, sm.L * sm.b * sm.op, sm.op);
+            }
+            park[threadIdx.x] = c;
+            __syncthreads();
+            if (threadIdx.x < 64) {
+                // the sequential recurrence; every lane carries the same composite, lane j keeps the one before sample kb + j in
+                // registers and the wave stores 64 of them at a time (a store inside the chain would order every broadcast load
+                // behind it: 143 cycles per sample instead of 25). Samples beyond the ray's last are parked as zeros: fma(T, 0, C) = C.
+                const int cnt = min(EXACT_BWD_NT, live - base);
+                const int lane = (int)threadIdx.x;
+                for (int kb = 0; kb < cnt; kb += 64) {   // uniform
+                    float4 mine = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+                    for (int j = 0; j < 64; ++j) {
+                        const float4 v = park[kb + j];
+                        if (j == lane) mine = make_float4(C0, C1, C2, A);
+                        const float T = 1.0f - A;
+                        C0 = fmaf(T, v.x, C0); C1 = fmaf(T, v.y, C1); C2 = fmaf(T, v.z, C2);
+                        A = fmaf(T, v.w, A);
+                    }
+                    pre[kb + lane] = mine;
+                }
+            }
+            __syncthreads();
+            // every thread forms its sample's adjoint exactly as march_bwd_baseline_kernel does
+            float V8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // d_tf addends: (r, g, b, a) for the lower texel, then the upper
+            int key = -1 - (int)(threadIdx.x & 63), key_hi = 0;       // TF cell (no sample: a key of its own)
+            if (have) {
+                const float4 b = pre[threadIdx.x];
+                const float T = 1.0f - b.w;
+                const float a0 = fmaf(T, c.x, b.x), a1 = fmaf(T, c.y, b.y), a2 = fmaf(T, c.z, b.z), a3 = fmaf(T, c.w, b.w);   // after the sample
+                const bool last = s == live - 1;
+                const float suffix = (go.x * (of.x - a0) + go.y * (of.y - a1) + go.z * (of.z - a2)) + go.w * (of.w - a3);
+                SampleAdj ad;
+                sample_adjoint(sm, vd, T, suffix, last, go, P.inv_sr, ad);
+                float I_bar = want_vol ? intensity_adjoint(sm, tfg[sm.lo], tfg[sm.hi], ad, P.tf_len) : 0.0f;
+                // (the fast backward promises finite gradients: a NaN adjoint is dropped, infinities are clamped -- as in B2)
+                ad.r_bar = acc_sanitise(ad.r_bar); ad.g_bar = acc_sanitise(ad.g_bar); ad.b_bar = acc_sanitise(ad.b_bar);
+                ad.a_bar = acc_sanitise(ad.a_bar); ad.gx = acc_sanitise(ad.gx); ad.gy = acc_sanitise(ad.gy);
+                ad.gz = acc_sanitise(ad.gz); I_bar = acc_sanitise(I_bar);
+                if (want_tf) {
+                    const float w0 = 1.0f - sm.fr, w1 = sm.fr;   // (the products are f32, as in the oracle)
+                    V8[0] = w0 * ad.r_bar; V8[1] = w0 * ad.g_bar; V8[2] = w0 * ad.b_bar; V8[3] = w0 * ad.a_bar;
+                    V8[4] = w1 * ad.r_bar; V8[5] = w1 * ad.g_bar; V8[6] = w1 * ad.b_bar; V8[7] = w1 * ad.a_bar;
+                    key = sm.lo; key_hi = sm.hi;
+                }
+                if (want_vol) {
+                    // the seven taps of a sample lie 1e-3 apart: nearly always in ONE cell -- their adjoints are added up per corner in
+                    // registers and leave as eight atomics instead of 56 (a tap in a neighbouring cell goes on its own)
+                    Cell c0;
+                    tri_cell(vol, sm.px, sm.py, sm.pz, c0);
+                    float acc[8];
+                    tri_corner_weights(c0, I_bar, acc);
+                    auto tap = [&](float qx, float qy, float qz, float adj) {
+                        Cell cq;
+                        tri_cell(vol, qx, qy, qz, cq);
+                        if (cq.x0 == c0.x0 && cq.y0 == c0.y0 && cq.z0 == c0.z0) {
+                            float wq[8];
+                            tri_corner_weights(cq, adj, wq);
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) acc[q] += wq[q];
+                        } else {
+                            tri_scatter_global(vol, dv, qx, qy, qz, adj);
+                        }
+                    };
+                    if (!sm.flat) {
+                        tap(sm.px + delta, sm.py, sm.pz, ad.gx); tap(sm.px - delta, sm.py, sm.pz, -ad.gx);
+                        tap(sm.px, sm.py + delta, sm.pz, ad.gy); tap(sm.px, sm.py - delta, sm.pz, -ad.gy);
+                        tap(sm.px, sm.py, sm.pz + delta, ad.gz); tap(sm.px, sm.py, sm.pz - delta, -ad.gz);
+                    }
+                    float *b00 = dv.p + c0.x0 * dv.sx + c0.y0 * dv.sy, *b10 = dv.p + c0.x1 * dv.sx + c0.y0 * dv.sy;
+                    float *b01 = dv.p + c0.x0 * dv.sx + c0.y1 * dv.sy, *b11 = dv.p + c0.x1 * dv.sx + c0.y1 * dv.sy;
+                    const int64_t o0 = c0.z0 * dv.sz, o1 = c0.z1 * dv.sz;
+                    unsafeAtomicAdd(b00 + o0, acc[0]); unsafeAtomicAdd(b10 + o0, acc[1]); unsafeAtomicAdd(b01 + o0, acc[2]); unsafeAtomicAdd(b11 + o0, acc[3]);
+                    unsafeAtomicAdd(b00 + o1, acc[4]); unsafeAtomicAdd(b10 + o1, acc[5]); unsafeAtomicAdd(b01 + o1, acc[6]); unsafeAtomicAdd(b11 + o1, acc[7]);
+                }
+            }
+            if (want_tf) {   // uniform
+                // lanes are consecutive samples: runs of them share a TF cell -- summed across the lanes (DPP), one set of LDS adds per run
+                const int lane = (int)(threadIdx.x & 63);
+                const int prev = wave_up1(key, key);
+                const bool start = lane == 0 || key != prev;
+                const unsigned long long starts = __ballot(start);
+                const unsigned long long upto = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+                const int rs = 63 - __clzll((long long)(starts & upto));   // first lane of this lane's run
+                seg_scan_sum<8>(V8, lane, rs);
+                const bool run_end = lane == 63 || ((starts >> ((lane + 1) & 63)) & 1ull);
+                if (key >= 0 && run_end) {
+                    unsigned long long *d0 = lds_dtf + 4 * key, *d1 = lds_dtf + 4 * key_hi;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { acc_add_f64(d0 + q, V8[q]); acc_add_f64(d1 + q, V8[4 + q]); }
+                }
+            }
+            __syncthreads();   // park / pre are free again
+        }
+    }
+    if (cur_view >= 0) flush();
+}
+
 // ------------------------------------------------------------------------------------------------ host
 size_t brick_workspace_bytes(int n_views, int W, int H, int VX, int VY, int VZ) {
     const BrickGrid g = make_brick_grid(VX, VY, VZ);
@@ -604,6 +786,24 @@ static int ray_compose_dispatch(const MarchArgs &a, hipStream_t stream) {
 
 int launch_ray_compose(const MarchArgs &a, hipStream_t stream) {
     return a.vol_dtype == DR_F16 ? ray_compose_dispatch<__half>(a, stream) : ray_compose_dispatch<float>(a, stream);
+}
+
+// B3: after B1 / the tape pass and B2 (what every backward pays: one small launch)
+template <typename VT>
+static int ray_exact_bwd_dispatch(const MarchArgs &a, hipStream_t stream) {
+    const BrickGrid g = make_brick_grid(a.VX, a.VY, a.VZ);
+    Workspace w;
+    ws_layout(a.workspace, a.n_views, a.W * a.H, g, &w);
+    BrickParams<VT> P = make_brick_params<VT>(a, w);
+    if ((a.hints & DR_TAPE_TF) && !a.d_vol) P.tape_stride = tape_stride_for(a.VX, a.VY, a.VZ, a.sr, a.S);   // (checked against the header)
+    const size_t lds = (size_t)a.R * 32 + (size_t)EXACT_BWD_NT * 32;
+    const hipError_t e = allow_lds(ray_exact_bwd_kernel<VT>, lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((ray_exact_bwd_kernel<VT>), dim3(DR_EXACT_BWD_GRID), dim3(EXACT_BWD_NT), lds, stream, P);
+    return (int)hipGetLastError();
+}
+int launch_ray_exact_bwd(const MarchArgs &a, hipStream_t stream) {
+    return a.vol_dtype == DR_F16 ? ray_exact_bwd_dispatch<__half>(a, stream) : ray_exact_bwd_dispatch<float>(a, stream);
 }
 
 // F3: the rays F2 listed, if any -- a resident grid that reads the count from the workspace header and leaves at once when it is 0

@@ -414,3 +414,36 @@ def test_ct_like_scene_needs_no_repairs(scene):
     # (Until round 4 the sequential kernels summed d_tf with f32 LDS atomics and carried 1e-3 of rounding noise on that texel;
     # they accumulate in double now, like the oracle and the fast path.)
     assert float((dt - dtb).abs().max()) <= 2e-5 * float(dtb.abs().max())
+
+
+@pytest.mark.parametrize("tape", [False, True], ids=["bricks", "tape"])
+def test_backward_of_the_sequentially_recomputed_rays_B3(hiplib, tape):
+    """DESIGN.md D4, the gradients: tf1 with 1e-6 in its transparent ranges at 256^3, sampling rate 2 -- a sixth of the rays are
+    recomputed sample by sample (F3), their partials up to 1e-4 of a composite away from the sequential values. The reference's adjoint
+    is built on the sequential composites (VR.py:460-461 over the tape of :300-302); from the partials, d_tf was 4.7e-4 of its maximum
+    off the sequential kernels' on this camera (tools/diff_sweep.py, round 6: 0.9 % of 3 763 random configurations beyond 1e-4, up to
+    4.7e-4). Rays whose bound exceeds 1e-5 now take ray_exact_bwd_kernel (B3): the sequential kernels' own arithmetic, a workgroup
+    per ray. Whole tensors, a random upstream gradient, against the sequential kernels (the oracle's twin)."""
+    import bench
+    from differender_amd import functional as F
+    from differender_amd.utils import get_tf
+    dev = torch.device("cuda:0")
+    Nv, IMG, Rr, sr, S = 256, 256, 128, 2.0, 1 << 20
+    vol = bench.synth_volume_torch(Nv, dev)
+    tf = get_tf("tf1", Rr).t().contiguous().float().to(dev)
+    tf[:, 3] = torch.where(tf[:, 3] == 0, torch.full_like(tf[:, 3], 1e-6), tf[:, 3])
+    cam = torch.tensor([[-0.66518, 1.061, 0.63672]], dtype=torch.float32, device=dev)
+    e, x, r, n = F.ray_setup(cam, (IMG, IMG), vol.shape, sr, jitter_seed=259974809)
+    ws = F.alloc_workspace(1, (IMG, IMG), vol.shape, Rr, dev, tape=(S, sr) if tape else None)
+    out, steps = F.march_fwd(vol, tf, cam, e, x, r, n, S, sr, workspace=ws, tape=tape)
+    ref, sref = F.march_fwd(vol, tf, cam, e, x, r, n, S, sr, variant=F.N.DR_VARIANT_BASELINE)
+    assert torch.equal(steps, sref) and float((out - ref).abs().max()) <= 1e-5
+    assert int(F.workspace_stats(ws)[15]) > 0.05 * IMG * IMG          # a good part of the image went through the exact pass
+    g = torch.randn(1, IMG, IMG, 4, generator=torch.Generator().manual_seed(11)).to(dev)
+    dv0, dt0 = F.march_bwd(vol, tf, cam, e, x, r, n, S, sr, g, ref, variant=F.N.DR_VARIANT_BASELINE)
+    if tape:
+        _, dt = F.march_bwd(vol, tf, cam, e, x, r, n, S, sr, g, out, want_vol=False, workspace=ws, tape=True)
+    else:
+        dv, dt = F.march_bwd(vol, tf, cam, e, x, r, n, S, sr, g, out, workspace=ws)
+        assert float((dv - dv0).abs().max()) <= 1e-4 * float(dv0.abs().max())
+    assert float((dt - dt0).abs().max()) <= 1e-4 * float(dt0.abs().max())
