@@ -383,9 +383,11 @@ __device__ __forceinline__ bool segment_range(const BrickCtx &c, f3 cam, f3 vd, 
 #endif
 // ... and a ray whose bound exceeds DR_D4_BWD_BUDGET has its BACKWARD formed from the sequential composites too (ray_exact_bwd_kernel):
 // the tape-free identity takes prefixes and final value from the composites, an adjoint built on partials that are `bound` away is
-// ~7 bound off in relative terms, and a TF with tiny alphas lists a sixth of the rays -- below 1e-5 even ALL rays at the budget stay
-// under the 1e-4 bar of the gradients, so the headline's handful of listed rays (bounds of 3e-6 .. 1e-5) keep the brick backward.
-#define DR_D4_BWD_BUDGET 1.0e-5f
+// ~7 bound off in relative terms -- per RAY, and a voxel of d_volume hears from a handful of rays only. Measured (tools/d4_bound_hist.py,
+// 512^3): the bench TF's listed rays, 0-4 per camera, have bounds of 3e-6 .. 5e-6 and keep the brick backward (nothing to pay at the
+// headline); a TF with tiny alphas all over has 2 500 rays per view there, 10 000 between 5e-6 and 1e-5, 60 000 above. (At 1e-5 the
+// real-size sweep still found d_volume 1.2e-4 .. 2.7e-4 off in 0.25 % of such configurations.)
+#define DR_D4_BWD_BUDGET 5.0e-6f
 #define DR_D4_TINY_OP 1.0e-4f
 #define DR_D4_TINY_RUN 16.0f
 #define DR_D4_WALK 5.68e-6f   // = 0.87 x 5.96e-8 x sqrt(12 000)

@@ -104,7 +104,7 @@
 #define DR_EXACT_GRID 1280      // four-wave workgroups of ray_exact_kernel when many rays are listed (five per CU)
 #endif
 #ifndef DR_EXACT_BWD_GRID
-#define DR_EXACT_BWD_GRID 512  // workgroups (1024 threads) of ray_exact_bwd_kernel: two per CU
+#define DR_EXACT_BWD_GRID 1024 // four-wave workgroups of ray_exact_bwd_kernel: four per CU (123 VGPRs)
 #endif
 #ifndef DR_TAPE_GRID
 #define DR_TAPE_GRID 2560       // workgroups of tf_tape_bwd_kernel over all views (ten per CU: 12 KB of LDS at R = 256)

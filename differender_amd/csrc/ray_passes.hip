@@ -573,19 +573,21 @@ __global__ __launch_bounds__(EXACT_NT) void ray_exact_kernel(BrickParams<VT> P) 
 // sequential recurrence produced them (VR.py:460-461 on the tape of :300-302). Where the partials and the sequential values part
 // company by 1e-4 of a composite (what such a ray was listed for), a backward from the partials is 1e-4 off per ray, and a TF whose
 // transparent ranges carry tiny alphas lists a sixth of the rays: d_tf 1e-4 .. 5e-4 of its maximum at 256^3 and 512^3 (tools/
-// diff_sweep.py, round 6). So F2 flags the listed rays (rayflag 2): B1 and the tape pass leave them alone, the per-ray pass B2
-// (one LANE per ray: 8 ms for a handful of rays) does too, and this kernel serves them -- one 1024-thread workgroup per ray:
-// samples evaluated side by side with the sequential kernels' arithmetic (classify / shade: exact normalisations, global taps),
-// their contributions chained by the first wave into the composite before every sample (LDS), then every thread forms its
-// sample's adjoint exactly as march_bwd_baseline_kernel does and scatters it (d_volume: global float atomics; d_tf: a double
-// table in LDS, flushed per view). A resident grid that leaves at once when nothing is listed.
+// diff_sweep.py, round 6). So F2 flags the listed rays whose bound exceeds DR_D4_BWD_BUDGET (rayflag 2): B1 and the tape pass leave
+// them alone, the per-ray pass B2 (one LANE per ray: 8 ms for a handful of rays) does too, and this kernel serves them -- one
+// four-wave workgroup per ray, four to a CU: 256 samples at a time evaluated side by side with the sequential kernels' arithmetic
+// (classify / shade: exact normalisations, global taps), their contributions chained by the first wave into the composite before
+// every sample (LDS), then every thread forms its sample's adjoint exactly as march_bwd_baseline_kernel does and scatters it
+// (d_volume: global float atomics, one set of eight per run of samples in a cell; d_tf: run sums into a double table in LDS,
+// flushed per view). A resident grid that leaves at once when nothing is flagged. It is a slow path -- the per-ray gathers and the
+// chain are what they are: a TF with tiny alphas all over (28 % of the rays flagged at 512^3) pays 10-20 x the brick backward.
 // the eight corner weights of tri_scatter_global (dr_device.h), times adj -- same products, same order
 __device__ __forceinline__ void tri_corner_weights(const Cell &c, float adj, float (&w)[8]) {
     const float gx = 1.0f - c.fx, gy = 1.0f - c.fy, gz = 1.0f - c.fz;
     w[0] = gx * gy * gz * adj; w[1] = c.fx * gy * gz * adj; w[2] = gx * c.fy * gz * adj; w[3] = c.fx * c.fy * gz * adj;
     w[4] = gx * gy * c.fz * adj; w[5] = c.fx * gy * c.fz * adj; w[6] = gx * c.fy * c.fz * adj; w[7] = c.fx * c.fy * c.fz * adj;
 }
-constexpr int EXACT_BWD_NT = 1024;
+constexpr int EXACT_BWD_NT = 256;
 template <typename VT>
 __global__ __launch_bounds__(EXACT_BWD_NT) void ray_exact_bwd_kernel(BrickParams<VT> P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b3[];
@@ -672,6 +674,10 @@ __global__ __launch_bounds__(EXACT_BWD_NT) void ray_exact_bwd_kernel(BrickParams
             // every thread forms its sample's adjoint exactly as march_bwd_baseline_kernel does
             float V8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // d_tf addends: (r, g, b, a) for the lower texel, then the upper
             int key = -1 - (int)(threadIdx.x & 63), key_hi = 0;       // TF cell (no sample: a key of its own)
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // d_volume addends for the eight corners of the sample's cell
+            int cell_key = -1 - (int)(threadIdx.x & 63);              // ... which cell
+            float *cb00 = nullptr, *cb10 = nullptr, *cb01 = nullptr, *cb11 = nullptr;
+            int64_t co0 = 0, co1 = 0;
             if (have) {
                 const float4 b = pre[threadIdx.x];
                 const float T = 1.0f - b.w;
@@ -693,10 +699,10 @@ __global__ __launch_bounds__(EXACT_BWD_NT) void ray_exact_bwd_kernel(BrickParams
                 }
                 if (want_vol) {
                     // the seven taps of a sample lie 1e-3 apart: nearly always in ONE cell -- their adjoints are added up per corner in
-                    // registers and leave as eight atomics instead of 56 (a tap in a neighbouring cell goes on its own)
+                    // registers (a tap in a neighbouring cell goes on its own), and so are, below, the samples of consecutive lanes
+                    // that share the cell: eight atomics per run of samples in a cell instead of 56 per sample
                     Cell c0;
                     tri_cell(vol, sm.px, sm.py, sm.pz, c0);
-                    float acc[8];
                     tri_corner_weights(c0, I_bar, acc);
                     auto tap = [&](float qx, float qy, float qz, float adj) {
                         Cell cq;
@@ -715,11 +721,25 @@ __global__ __launch_bounds__(EXACT_BWD_NT) void ray_exact_bwd_kernel(BrickParams
                         tap(sm.px, sm.py + delta, sm.pz, ad.gy); tap(sm.px, sm.py - delta, sm.pz, -ad.gy);
                         tap(sm.px, sm.py, sm.pz + delta, ad.gz); tap(sm.px, sm.py, sm.pz - delta, -ad.gz);
                     }
-                    float *b00 = dv.p + c0.x0 * dv.sx + c0.y0 * dv.sy, *b10 = dv.p + c0.x1 * dv.sx + c0.y0 * dv.sy;
-                    float *b01 = dv.p + c0.x0 * dv.sx + c0.y1 * dv.sy, *b11 = dv.p + c0.x1 * dv.sx + c0.y1 * dv.sy;
-                    const int64_t o0 = c0.z0 * dv.sz, o1 = c0.z1 * dv.sz;
-                    unsafeAtomicAdd(b00 + o0, acc[0]); unsafeAtomicAdd(b10 + o0, acc[1]); unsafeAtomicAdd(b01 + o0, acc[2]); unsafeAtomicAdd(b11 + o0, acc[3]);
-                    unsafeAtomicAdd(b00 + o1, acc[4]); unsafeAtomicAdd(b10 + o1, acc[5]); unsafeAtomicAdd(b01 + o1, acc[6]); unsafeAtomicAdd(b11 + o1, acc[7]);
+                    // (11 bits per coordinate, the top one dropped: consecutive samples never lie 512 cells apart; fast-path volumes are below 2048)
+                    cell_key = (c0.x0 | (c0.y0 << 11) | (c0.z0 << 22)) & 0x7fffffff;
+                    cb00 = dv.p + c0.x0 * dv.sx + c0.y0 * dv.sy; cb10 = dv.p + c0.x1 * dv.sx + c0.y0 * dv.sy;
+                    cb01 = dv.p + c0.x0 * dv.sx + c0.y1 * dv.sy; cb11 = dv.p + c0.x1 * dv.sx + c0.y1 * dv.sy;
+                    co0 = c0.z0 * dv.sz; co1 = c0.z1 * dv.sz;
+                }
+            }
+            if (want_vol) {   // uniform
+                const int lane = (int)(threadIdx.x & 63);
+                const int prev = wave_up1(cell_key, cell_key);
+                const bool start = lane == 0 || cell_key != prev;
+                const unsigned long long starts = __ballot(start);
+                const unsigned long long upto = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+                const int rs = 63 - __clzll((long long)(starts & upto));   // first lane of this lane's run of samples in one cell
+                seg_scan_sum<8>(acc, lane, rs);
+                const bool run_end = lane == 63 || ((starts >> ((lane + 1) & 63)) & 1ull);
+                if (cell_key >= 0 && run_end) {
+                    unsafeAtomicAdd(cb00 + co0, acc[0]); unsafeAtomicAdd(cb10 + co0, acc[1]); unsafeAtomicAdd(cb01 + co0, acc[2]); unsafeAtomicAdd(cb11 + co0, acc[3]);
+                    unsafeAtomicAdd(cb00 + co1, acc[4]); unsafeAtomicAdd(cb10 + co1, acc[5]); unsafeAtomicAdd(cb01 + co1, acc[6]); unsafeAtomicAdd(cb11 + co1, acc[7]);
                 }
             }
             if (want_tf) {   // uniform
