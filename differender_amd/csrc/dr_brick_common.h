@@ -16,6 +16,7 @@ constexpr int ITEM_CAP = 1 << 18;     // items the workspace holds, 4 MB (a 512^
 constexpr int CTX_MAIN_CAND = 1024;   // candidates of a brick the main launch takes (= MAIN_CAND of march_flat.hip)
 constexpr int CTX_ITEM_MAX_CAND = 4096;  // candidates per item at most (its list of hits: 16-bit offsets, 8 KB of LDS -- two backward workgroups still fit a CU)
 
+constexpr int DTF64_R = 2048;   // TF entries the workspace's double d_tf table has room for (the fast path serves R <= 2030)
 template <typename VT>
 struct BrickParams {
     VolView<VT> vol; int64_t vol_vs;
@@ -37,6 +38,10 @@ struct BrickParams {
                          //   tape-free identity needs a final value that is CONSISTENT with the stored prefixes -- the image itself may
                          //   have been recomputed sample by sample (ray_exact_kernel)
     unsigned int *exact_list;  // [view * NP]: rays F2 sent to ray_exact_kernel (stats[ST_EXACT_RAYS] of them)
+    double *dtf64;       // [view][DTF64_R][4]: d_tf of ONE backward call, summed across its workgroups in double (global f64 atomics) and
+                         //   committed to the caller's float tensor by dtf_commit_kernel, which leaves it zero again (the forward zeroes it too).
+                         //   80 000 per-brick partials met in float atomics before: 1e-4 of d_tf's maximum where a texel collects 1e8
+                         //   cancelling terms (the air's texels under a random upstream gradient: tools/diff_sweep.py, round 6)
     float2 *tape;        // DR_TAPE_TF: [view][NP][tape_stride] (intensity, lighting term) of every marched sample (forward -> tf_tape.hip)
     int tape_stride;     //   samples reserved per ray (0: no tape)
     unsigned long long *unlit;  // [view][lm_words][NP]: non-differentiable renders with an alpha pre-pass -- bit l of a ray's mask: the pre-pass
@@ -292,6 +297,8 @@ static __global__ __launch_bounds__(256) void brick_ctx_kernel(BrickParams<VT> P
             }
         }
     }
+    if (forward)   // the double d_tf table of the backward that follows starts at zero (dtf_commit_kernel leaves it so as well)
+        for (int k = b; k < 4 * DTF64_R; k += (int)gridDim.x * 256) P.dtf64[(size_t)view * 4 * DTF64_R + k] = 0.0;
     if (b >= nbricks) return;
     const f3 cam = make_f3(P.cam[3 * view], P.cam[3 * view + 1], P.cam[3 * view + 2]);
     BrickCtx c;
@@ -562,6 +569,10 @@ __device__ __forceinline__ float acc_sanitise(float x) { return (x == x) ? fminf
 __device__ __forceinline__ void acc_add_f64(unsigned long long *p, float x) {
     atomicAdd(reinterpret_cast<double *>(p), (double)x);  // ds_add_f64
 }
+// a workgroup's double d_tf sum (bit pattern, as acc_add_f64 leaves it in LDS) into the call's table in the workspace
+__device__ __forceinline__ void dtf64_add(double *table, int view, int k, unsigned long long raw) {
+    unsafeAtomicAdd(table + (size_t)view * 4 * DTF64_R + k, __longlong_as_double((long long)raw));   // global_atomic_add_f64
+}
 __device__ __forceinline__ float acc_f64_to_float(unsigned long long v) {
     return fminf(fmaxf((float)__longlong_as_double((long long)v), -3.0e38f), 3.0e38f);
 }
@@ -645,7 +656,7 @@ static __global__ __launch_bounds__(256) void clear_counts_if_prepass_kernel(uin
 // ------------------------------------------------------------------------------------------------ host
 struct Workspace {
     float4 *seg_rgba; uint16_t *seg_cnt; int32_t *ws_steps; uint8_t *rayflag; unsigned int *stats, *vflags, *n_items;
-    float4 *fin; unsigned int *exact_list; uint16_t *seg_tiny; float2 *tape;
+    float4 *fin; unsigned int *exact_list; uint16_t *seg_tiny; float2 *tape; double *dtf64;
     unsigned long long *unlit; size_t unlit_bytes; int lm_words;   // right behind seg_cnt: one memset clears the counts and the masks
     BrickCtxRec *ctx;
     BrickItem *items;
@@ -687,6 +698,8 @@ static inline size_t ws_layout(void *base, int n_views, int NP, const BrickGrid 
     o += align16((size_t)n_views * NP * 4);
     if (w) w->seg_tiny = reinterpret_cast<uint16_t *>(b + o);
     o += align16(nseg * 2);
+    if (w) w->dtf64 = reinterpret_cast<double *>(b + o);
+    o += (size_t)n_views * DTF64_R * 4 * 8;
     o = (o + 255) & ~(size_t)255;
     if (w) w->tape = tape_stride > 0 ? reinterpret_cast<float2 *>(b + o) : nullptr;
     o += (size_t)n_views * NP * (size_t)tape_stride * 8;
@@ -713,7 +726,7 @@ static inline BrickParams<VT> make_brick_params(const MarchArgs &a, const Worksp
     P.near_ = (float)a.near_plane; P.near_h = (float)near_h; P.near_w = (float)(near_h * ((double)P.imgW / (double)a.H));
     P.g = make_brick_grid(a.VX, a.VY, a.VZ);
 
-    P.seg_rgba = w.seg_rgba; P.seg_cnt = w.seg_cnt; P.rayflag = w.rayflag; P.stats = w.stats; P.vflags = w.vflags; P.n_views = a.n_views; P.ws_steps = w.ws_steps; P.fin = w.fin; P.exact_list = w.exact_list; P.seg_tiny = w.seg_tiny; P.tape = nullptr; P.tape_stride = 0; P.unlit = w.unlit; P.lm_words = 0;
+    P.seg_rgba = w.seg_rgba; P.seg_cnt = w.seg_cnt; P.rayflag = w.rayflag; P.stats = w.stats; P.vflags = w.vflags; P.n_views = a.n_views; P.ws_steps = w.ws_steps; P.fin = w.fin; P.exact_list = w.exact_list; P.seg_tiny = w.seg_tiny; P.dtf64 = w.dtf64; P.tape = nullptr; P.tape_stride = 0; P.unlit = w.unlit; P.lm_words = 0;
     P.hint_noterm = (a.hints & DR_HINT_NO_EARLY_TERMINATION) ? 1 : 0;
     P.count_eval = (a.hints & DR_COUNT_EVALUATED) ? 1 : 0;
     P.nondiff = a.mode == DR_MODE_NONDIFF ? 1 : 0;

@@ -49,6 +49,7 @@ int launch_tf_tape_bwd(const MarchArgs &a, hipStream_t stream);     // TF-only b
 int launch_ray_compose(const MarchArgs &a, hipStream_t stream);      // F2
 int launch_ray_exact(const MarchArgs &a, hipStream_t stream);        // F3: the rays F2 listed, sample by sample
 int launch_ray_exact_bwd(const MarchArgs &a, hipStream_t stream);   // B3: the backward of the rays F3 recomputed
+int launch_dtf_commit(const MarchArgs &a, hipStream_t stream);      // the backward's double d_tf table -> the caller's float tensor
 int launch_ray_alpha(const MarchArgs &a, hipStream_t stream);        // alpha pre-pass: per-ray composition of one phase
 int launch_ray_cross(const MarchArgs &a, hipStream_t stream);        // alpha pre-pass: exact termination sample of crossing rays
 bool flat_strides_ok(int64_t sx, int64_t sy, int64_t sz);  // 32-bit in-box offsets

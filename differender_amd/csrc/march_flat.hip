@@ -1310,11 +1310,10 @@ __device__ __forceinline__ void brick_flat_body(const BrickParams<VT> &P, unsign
             }
         }
     }
-    if (WANT_TF) {
-        float *dtf = P.d_tf + view * P.dtf_vs * 4;
+    if (WANT_TF) {   // (into the call's double table: dtf_commit_kernel hands the sums to the caller's tensor)
         for (int k = threadIdx.x; k < 4 * P.R; k += FNT) {
             const unsigned long long raw = L.dtf[k];
-            if (raw != 0ull) atomic_add_sat(dtf + k, acc_f64_to_float(raw));
+            if (raw != 0ull) dtf64_add(P.dtf64, view, k, raw);
         }
     }
 }
@@ -1569,7 +1568,9 @@ static int flat_bwd_dispatch(const MarchArgs &a, hipStream_t stream) {
         b.ws_aux = w.stats + ST_TAPE_STRIDE; b.ws_aux_expect = (unsigned int)tstride;
         const int rc2 = launch_march_bwd_baseline(b, stream);
         if (rc2) return rc2;
-        return launch_ray_exact_bwd(a, stream);   // B3: the rays the forward recomputed sequentially
+        const int rc3 = launch_ray_exact_bwd(a, stream);   // B3: the rays the forward recomputed sequentially
+        if (rc3) return rc3;
+        return launch_dtf_commit(a, stream);
     }
     const size_t need = ws_layout(a.workspace, a.n_views, NP, g, &w);
     if (!a.workspace || a.workspace_bytes < need) return DR_EINVAL;
@@ -1589,7 +1590,9 @@ static int flat_bwd_dispatch(const MarchArgs &a, hipStream_t stream) {
     b.ws_mark = w.stats + ST_MARK; b.ws_mark_expect = P.mark;
     const int rc2 = launch_march_bwd_baseline(b, stream);
     if (rc2) return rc2;
-    return launch_ray_exact_bwd(a, stream);   // B3: the rays the forward recomputed sequentially
+    const int rc3 = launch_ray_exact_bwd(a, stream);   // B3: the rays the forward recomputed sequentially
+    if (rc3 || !wt) return rc3;
+    return launch_dtf_commit(a, stream);
 }
 
 int launch_march_bwd_flat(const MarchArgs &a, hipStream_t stream) {

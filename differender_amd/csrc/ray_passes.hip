@@ -606,10 +606,9 @@ __global__ __launch_bounds__(EXACT_BWD_NT) void ray_exact_bwd_kernel(BrickParams
     auto flush = [&]() {   // (all threads)
         __syncthreads();
         if (want_tf && cur_view >= 0) {
-            float *dtf = P.d_tf + cur_view * P.dtf_vs * 4;
             for (int k = threadIdx.x; k < 4 * P.R; k += EXACT_BWD_NT) {
                 const unsigned long long raw = lds_dtf[k];
-                if (raw != 0ull) atomic_add_sat(dtf + k, acc_f64_to_float(raw));
+                if (raw != 0ull) dtf64_add(P.dtf64, cur_view, k, raw);   // (the call's double table: dtf_commit_kernel)
                 lds_dtf[k] = 0ull;
             }
         }

@@ -199,11 +199,40 @@ __global__ __launch_bounds__(256) void tf_tape_bwd_kernel(BrickParams<VT> P) {
         if (base < live) tape_pass<2>(r, base, lane, carry);
     }
     if (!__syncthreads_or(any)) return;   // uniform; also: every wave's LDS adds are done before the flush
-    float *dtf = P.d_tf + view * P.dtf_vs * 4;
-    for (int k = threadIdx.x; k < 4 * P.R; k += 256) {
+    for (int k = threadIdx.x; k < 4 * P.R; k += 256) {   // (into the call's double table: dtf_commit_kernel)
         const unsigned long long raw = lds_dtf[k];
-        if (raw != 0ull) atomic_add_sat(dtf + k, acc_f64_to_float(raw));
+        if (raw != 0ull) dtf64_add(P.dtf64, view, k, raw);
     }
+}
+
+// The double d_tf table of this backward call -> the caller's float tensor (added: the caller zero-filled it, the per-ray pass B2 may have
+// put its few rays' share there already), clamped into the finite floats; the table is zero again afterwards. Only if
+// the workspace holds this call's forward (else no kernel has added anything and the table is not ours to read).
+template <typename VT>
+__global__ __launch_bounds__(256) void dtf_commit_kernel(BrickParams<VT> P) {
+    if (P.stats[ST_MARK] != P.mark) return;   // uniform
+    if (P.tape_stride > 0 && P.stats[ST_TAPE_STRIDE] != (unsigned int)P.tape_stride) return;
+    const int k = blockIdx.x * 256 + threadIdx.x, view = blockIdx.y;
+    if (k >= 4 * P.R) return;
+    double *t = P.dtf64 + (size_t)view * 4 * DTF64_R + k;
+    const double v = *t;
+    if (v != 0.0) {
+        *t = 0.0;
+        atomic_add_sat(P.d_tf + view * P.dtf_vs * 4 + k, fminf(fmaxf((float)v, -3.0e38f), 3.0e38f));
+    }
+}
+template <typename VT>
+static int dtf_commit_dispatch(const MarchArgs &a, hipStream_t stream) {
+    const BrickGrid g = make_brick_grid(a.VX, a.VY, a.VZ);
+    Workspace w;
+    ws_layout(a.workspace, a.n_views, a.W * a.H, g, &w);
+    BrickParams<VT> P = make_brick_params<VT>(a, w);
+    if ((a.hints & DR_TAPE_TF) && !a.d_vol) P.tape_stride = tape_stride_for(a.VX, a.VY, a.VZ, a.sr, a.S);
+    hipLaunchKernelGGL((dtf_commit_kernel<VT>), dim3((4 * a.R + 255) / 256, a.n_views), dim3(256), 0, stream, P);
+    return (int)hipGetLastError();
+}
+int launch_dtf_commit(const MarchArgs &a, hipStream_t stream) {
+    return a.vol_dtype == DR_F16 ? dtf_commit_dispatch<__half>(a, stream) : dtf_commit_dispatch<float>(a, stream);
 }
 
 template <typename VT>
