@@ -105,7 +105,8 @@ int dr_ray_setup(const float *cam, int n_views, int W, int H, int VX, int VY, in
  * atomics on the caller's tensor), and read a larger TF where it lies.
  * The caller allocates it (device memory, 256-byte aligned), passes it to dr_march_fwd and, unchanged,
  * to the dr_march_bwd of the same inputs: the forward leaves the per-segment composite prefixes and the
- * per-ray live sample counts there (the "coarse tape", ~22 B per ray per brick layer). Replaces the
+ * per-ray live sample counts there (the "coarse tape", ~22 B per ray per brick layer; the backward also sums d_tf there, in
+ * double, before it hands the totals to the caller's tensor). Replaces the
  * reference's render_tape field (VR.py:82,102-103: 16 B per ray per SAMPLE, twice with its gradient). */
 size_t dr_workspace_bytes(int n_views, int W, int H, int VX, int VY, int VZ, int R);
 /* ... the same plus the per-sample tape of a DR_TAPE_TF forward: 8 B x min(max_samples, longest possible ray at this sampling
